@@ -1,0 +1,144 @@
+/*
+ * eae_coder.h -- C ABI of the host-side lossless coder (libeae_coder.so).
+ *
+ * Drop-in boundary for the reference's only native FFI on the hot path:
+ *
+ *   kodak_tensorflow/lossless/interface_cython.pyx:6-11
+ *       cdef extern from "c++/source/compression.h":
+ *           numpy.uint32_t compress_lossless(const uint32_t&, const int16_t* const, int16_t* const,
+ *                                            const uint8_t&, const double* const) except +
+ *   kodak_tensorflow/lossless/c++/source/compression.h:41-45   (C++ linkage, throws)
+ *
+ * Everything here is extern "C", plain pointers and sizes, no exceptions across the ABI: functions return an
+ * eae_error_code; where the reference throws std::runtime_error("Error of type N <stage>") the stage is reported
+ * through an out-parameter so a binding can rebuild the exact message.
+ *
+ * Bit-exactness contract (tests/test_coder_host.py): for every input, the bit counts, the two byte streams
+ * (LSB-first packing, Bitstream.cpp:30-79) and the decoded symbols are identical to the reference's.
+ * Threading: every function is re-entrant; the *_maps entry points fan independent maps out over an internal
+ * thread pool (the reference is single-threaded; maps are independent streams, compression.py:67-81).
+ */
+#ifndef EAE_CODER_H
+#define EAE_CODER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* utils.h:12-19 (same numeric values) + two ABI-level codes for what the reference raises as C++ exceptions. */
+typedef enum {
+    EAE_SUCCESS = 0,
+    EAE_CAPACITY_ERROR = 1,    /* bitstream full                       (Bitstream.cpp:32-35) */
+    EAE_RESOURCE_ERROR = 2,    /* bypass stream under-run              (Bitstream.cpp:63-66) */
+    EAE_PRECISION_ERROR = 3,   /* low/high left the 16-bit range       (BinaryArithmeticCoder.cpp:184-187) */
+    EAE_PROBABILITY_ERROR = 4, /* p is NaN or outside ]0,1[            (BinaryArithmeticCoder.cpp:146-153) */
+    EAE_OUT_OF_RANGE = 5,      /* std::out_of_range: m_probabilities.at(i) with L == 0 (LosslessCoder.cpp:173,189,208) */
+    EAE_NULL_POINTER = -1,     /* std::invalid_argument                (compression.cpp:9-12) */
+    EAE_BAD_ALLOC = -2
+} eae_error_code;
+
+/* Where compress_lossless failed -> the tail of the reference's runtime_error message (compression.cpp:32-62). */
+typedef enum {
+    EAE_STAGE_NONE = 0,
+    EAE_STAGE_ENCODING = 1,       /* "during the encoding." */
+    EAE_STAGE_STOP_ENCODING = 2,  /* "when stopping the binary arithmetic encoding." */
+    EAE_STAGE_START_DECODING = 3, /* "when starting the binary arithmetic decoding." */
+    EAE_STAGE_DECODING = 4        /* "during the decoding." */
+} eae_stage;
+
+const char* eae_coder_version(void);
+
+/* ---- (1) reference-equivalent entry point ------------------------------------------------------------------------
+ * Replaces compress_lossless (compression.cpp:3-65): encodes all symbols, flushes, counts bits, decodes all symbols.
+ * *nb_bits = BAC bits + bypass bits. Internal stream capacity is size*max(32,L) bits each, as in the reference
+ * (compression.cpp:24), so capacity errors occur for exactly the same inputs. */
+int eae_coder_compress_lossless(uint32_t size, const int16_t* array_input, int16_t* array_output,
+                                uint8_t truncated_unary_length, const double* probabilities,
+                                uint32_t* nb_bits, int* stage);
+
+/* ---- (2) split encode / decode: the streams the reference never returns (compression.cpp:27-64) ------------------
+ * eae_coder_stream_capacity_bytes: bytes the caller must provide per stream = ceil(size*max(32,L)/8).
+ * encode: writes the BAC stream (after stop_encoding) and the bypass stream; *_bits = number of valid bits.
+ * decode: inverse; needs both streams and their bit lengths. */
+uint32_t eae_coder_stream_capacity_bytes(uint32_t size, uint8_t truncated_unary_length);
+int eae_coder_encode(uint32_t size, const int16_t* array_input, uint8_t truncated_unary_length,
+                     const double* probabilities,
+                     uint8_t* bac_bytes, uint32_t* bac_bits, uint8_t* bypass_bytes, uint32_t* bypass_bits, int* stage);
+int eae_coder_decode(uint32_t size, int16_t* array_output, uint8_t truncated_unary_length,
+                     const double* probabilities,
+                     const uint8_t* bac_bytes, uint32_t bac_bits, const uint8_t* bypass_bytes, uint32_t bypass_bits,
+                     int* stage);
+
+/* ---- (3) batched, threaded: all maps of a batch of images after ONE device->host copy -----------------------------
+ * symbols: n_maps contiguous maps of map_size int16 each (channel-major / planar: map m = symbols + m*map_size; this
+ *          is `ref_int16[:, :, i].flatten()` of compression.py:77 for every (image, i), laid out back to back).
+ * prob_row[m]: row of `probabilities` ([n_rows][L], row-major float64 -- binary_probabilities[i, :] of
+ *          compression.py:79) used for map m, or -1 to skip the map (the exception map, compression.py:68-75, whose
+ *          cost is computed by the caller from its histogram); skipped maps get nb_bits[m] = 0, status[m] = 0 and,
+ *          when `reconstruction` is given, a verbatim copy.
+ * mode:    EAE_MODE_ROUNDTRIP = encode + decode + write `reconstruction` (what compress_lossless does per map);
+ *          EAE_MODE_ENCODE_ONLY = encode and count bits only (`reconstruction` may be NULL).
+ * nb_bits[m], status[m], stage[m]: per-map results. Return value: 0, or the first non-zero status encountered.
+ * n_threads <= 0 -> all hardware threads (capped at n_maps). */
+enum { EAE_MODE_ROUNDTRIP = 0, EAE_MODE_ENCODE_ONLY = 1 };
+int eae_coder_compress_maps(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, int16_t* reconstruction,
+                            uint8_t truncated_unary_length, const double* probabilities, const int32_t* prob_row,
+                            uint32_t* nb_bits, int32_t* status, int32_t* stage, int mode, int n_threads);
+
+/* Same, but keeps the streams: stream_offsets has n_maps+1 entries (bytes into `streams`), map m's BAC bytes start at
+ * stream_offsets[m] and its bypass bytes follow at +ceil(bac_bits[m]/8). Call once with streams == NULL to size
+ * (stream_offsets is filled from the worst-case capacities), or pass a buffer of eae_coder_stream_capacity_bytes*2 per
+ * map and read the packed sizes from bac_bits/bypass_bits. */
+int eae_coder_encode_maps(uint32_t n_maps, uint32_t map_size, const int16_t* symbols,
+                          uint8_t truncated_unary_length, const double* probabilities, const int32_t* prob_row,
+                          uint8_t* streams, uint64_t stream_stride_bytes,
+                          uint32_t* bac_bits, uint32_t* bypass_bits, int32_t* status, int32_t* stage, int n_threads);
+int eae_coder_decode_maps(uint32_t n_maps, uint32_t map_size, int16_t* symbols_out,
+                          uint8_t truncated_unary_length, const double* probabilities, const int32_t* prob_row,
+                          const uint8_t* streams, uint64_t stream_stride_bytes,
+                          const uint32_t* bac_bits, const uint32_t* bypass_bits, int32_t* status, int32_t* stage,
+                          int n_threads);
+
+/* ---- (4) the LosslessCoder object, method by method (LosslessCoder.h:12-169) --------------------------------------
+ * Needed so the reference's own unit cases (tests.cpp:134-352: sign, EG0, truncated unary, signed UEG0, raw BAC) can
+ * be replayed against this library. */
+typedef struct eae_lossless_coder eae_lossless_coder;
+eae_lossless_coder* eae_lossless_coder_new(uint32_t required_size_in_bits, uint8_t truncated_unary_length,
+                                           const double* probabilities);
+void eae_lossless_coder_free(eae_lossless_coder* c);
+uint32_t eae_lossless_coder_occupancy_in_bits_bac(const eae_lossless_coder* c);
+uint32_t eae_lossless_coder_occupancy_in_bits_bypass(const eae_lossless_coder* c);
+uint32_t eae_lossless_coder_written_bits_bac(const eae_lossless_coder* c);
+uint32_t eae_lossless_coder_written_bits_bypass(const eae_lossless_coder* c);
+/* copies ceil(written_bits/8) bytes; returns that count */
+uint32_t eae_lossless_coder_copy_bac(const eae_lossless_coder* c, uint8_t* dst, uint32_t dst_cap);
+uint32_t eae_lossless_coder_copy_bypass(const eae_lossless_coder* c, uint8_t* dst, uint32_t dst_cap);
+int eae_lossless_coder_write_sign(eae_lossless_coder* c, int16_t input);
+int eae_lossless_coder_read_sign(eae_lossless_coder* c, int16_t* output);
+int eae_lossless_coder_write_eg0(eae_lossless_coder* c, uint16_t input);
+int eae_lossless_coder_read_eg0(eae_lossless_coder* c, uint16_t* output);
+int eae_lossless_coder_write_truncated_unary(eae_lossless_coder* c, uint16_t input);
+int eae_lossless_coder_read_truncated_unary(eae_lossless_coder* c, uint16_t* output);
+int eae_lossless_coder_write_signed_ueg0(eae_lossless_coder* c, int16_t input);
+int eae_lossless_coder_read_signed_ueg0(eae_lossless_coder* c, int16_t* output);
+int eae_lossless_coder_stop_bac_encoding(eae_lossless_coder* c);
+int eae_lossless_coder_start_bac_decoding(eae_lossless_coder* c);
+int eae_lossless_coder_bac_encoding(eae_lossless_coder* c, uint8_t input, double probability);
+int eae_lossless_coder_bac_decoding(eae_lossless_coder* c, uint8_t* storage, double probability);
+
+/* utils.cpp:13-28 (count_nb_bits) -- exported for the exhaustive check against the double-log2 original. */
+uint8_t eae_coder_count_nb_bits(uint32_t input);
+
+/* ---- (5) host-side statistics that feed the coder (lossless/stats.py:136-195) -------------------------------------
+ * Per map: from int16 symbols (already centred-quantised and divided by the bin width), accumulate the truncated-
+ * unary decision counts: for |s| < L: ones[0:|s|] += 1, zeros[|s|] += 1; else ones[:] += 1.
+ * zeros/ones: [n_maps][L] int64, ACCUMULATED into (caller zeroes). */
+int eae_coder_count_binary_decisions(uint32_t n_maps, uint32_t map_size, const int16_t* symbols,
+                                     uint8_t truncated_unary_length, int64_t* zeros, int64_t* ones, int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAE_CODER_H */

@@ -1,0 +1,22 @@
+"""Prototypes of every symbol include/eae_hip.h declares (bound by `_native.hip()`)."""
+import ctypes
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+
+HIP_SYMBOLS = {
+    'eae_hip_version': (ctypes.c_char_p, []),
+    'eae_hip_device_info': (_i, [ctypes.c_char_p, _i, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i64)]),
+    'eae_hip_conv9x9s4_u8': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'eae_hip_conv5x5s2': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'eae_hip_gdn': (_i, [_vp, _vp, _vp, _i, _vp, _i64, _vp]),
+    'eae_hip_tconv5x5s2': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'eae_hip_tconv9x9s4_luma': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'eae_hip_pack_tconv9x9s4_weights': (_i, [_vp, _vp, _vp]),
+    'eae_hip_pack_tconv_weights': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'eae_hip_quantize_maps': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'eae_hip_symbol_histograms': (_i, [_vp, _vp, _i, _vp, _i, _i, _vp]),
+    'eae_hip_cast_bt601': (_i, [_vp, _vp, _i64, _vp]),
+    'eae_hip_sse_u8': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
+}

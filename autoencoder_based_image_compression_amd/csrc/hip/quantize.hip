@@ -1,0 +1,149 @@
+// quantize.hip -- the uniform quantiser and everything the coder / rate estimate need from it, in one pass over the
+// latents (HBM-bound: 4 B read + up to 10 B written per latent value):
+//   centring                     reconstructing_eae_kodak.py:170-178
+//   tls.quantize_per_map         tools/tools.py:927-929        bw * round_half_even(x / bw), float32
+//   tls.cast_float_to_int16      tools/tools.py:126-133 on cq / bw (lossless/compression.py:142)
+//   de-centring                  reconstructing_eae_kodak.py:192
+//   tls.count_nb_deads           tools/tools.py:318-320        (per-map "any non-zero" flags)
+// plus the per-map symbol histograms behind tls.count_symbols / discrete_entropy / rate_3d (tools.py:376-388,
+// 523-537, 977-989) and lossless/stats.py:181-195, as a second kernel over the planar symbols.
+#include "common.h"
+
+namespace {
+constexpr int PIX = 64;   // pixels per block
+
+__global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__ y, const float* __restrict__ map_mean,
+                                                       const float* __restrict__ bin_widths, float* __restrict__ cq_out,
+                                                       float* __restrict__ shifted_out, int16_t* __restrict__ symbols,
+                                                       unsigned int* __restrict__ nonzero, unsigned int* range_error,
+                                                       int hw, int chunks) {
+    __shared__ int16_t tile[EAE_C][PIX + 2];
+    const int tid = threadIdx.x;
+    const int c = tid & 127, half = tid >> 7;
+    const int img = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const float m = map_mean ? map_mean[c] : 0.f;
+    const float bw = bin_widths[c];
+    bool any_nonzero = false;
+    unsigned int bad = 0;
+    const int p0 = chunk * PIX + half * (PIX / 2);
+#pragma unroll 4
+    for (int i = 0; i < PIX / 2; ++i) {
+        const int pix = p0 + i;
+        if (pix < hw) {
+            const size_t idx = ((size_t)img * hw + pix) * EAE_C + c;
+            const float centered = y[idx] - m;
+            const float r = round_half_even(centered / bw);
+            const float cq = bw * r;
+            // compression.py:142: symbols come from cq / bw again (not from r), rounded half to even
+            const float rs = round_half_even(cq / bw);
+            if (!(fabsf(rs) < 32768.f)) bad++;              // tools.py:130-132 (AssertionError in the reference)
+            if (cq_out) cq_out[idx] = cq;
+            if (shifted_out) shifted_out[idx] = cq + m;
+            if (cq != 0.f) any_nonzero = true;              // NaN counts as non-zero, like sum(abs(.)) == 0 failing
+            tile[c][half * (PIX / 2) + i] = (int16_t)(int)rs;
+        }
+    }
+    if (any_nonzero && nonzero) nonzero[img * EAE_C + c] = 1u;   // benign race: every writer stores 1
+    if (bad && range_error) atomicAdd(range_error, bad);
+    if (symbols) {
+        __syncthreads();
+        // planar write: a wave covers 64 consecutive pixels of one map (128 B)
+        for (int i = tid; i < EAE_C * PIX; i += 256) {
+            const int ch = i >> 6, px = i & 63;
+            const int pix = chunk * PIX + px;
+            if (pix < hw) symbols[((size_t)img * EAE_C + ch) * hw + pix] = tile[ch][px];
+        }
+    }
+}
+
+// One block per map. LDS histogram when the bins fit, global atomics otherwise (caller zeroed hist/overflow).
+constexpr int LDS_BINS = 8192;
+__global__ __launch_bounds__(256) void hist_kernel(const int16_t* __restrict__ symbols, unsigned int* __restrict__ hist,
+                                                   int radius, unsigned int* __restrict__ overflow, int map_size) {
+    __shared__ unsigned int bins[LDS_BINS];
+    const int nb = 2 * radius + 1;
+    const int16_t* s = symbols + (size_t)blockIdx.x * map_size;
+    unsigned int* h = hist + (size_t)blockIdx.x * nb;
+    unsigned int over = 0;
+    if (nb <= LDS_BINS) {
+        for (int i = threadIdx.x; i < nb; i += 256) bins[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < map_size; i += 256) {
+            const int v = (int)s[i] + radius;
+            if (v >= 0 && v < nb) atomicAdd(&bins[v], 1u); else over++;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += 256) if (bins[i]) h[i] += bins[i];   // this block owns the row
+    } else {
+        for (int i = threadIdx.x; i < map_size; i += 256) {
+            const int v = (int)s[i] + radius;
+            if (v >= 0 && v < nb) atomicAdd(&h[v], 1u); else over++;
+        }
+    }
+    if (over) atomicAdd(&overflow[blockIdx.x], over);
+}
+
+__global__ void cast_bt601_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, long count) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        out[i] = (uint8_t)(unsigned int)round_half_even(fminf(fmaxf(x[i], 16.f), 235.f));
+}
+
+__global__ __launch_bounds__(256) void sse_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                  unsigned long long* sse, long pixels, int blocks_per_image) {
+    const int img = blockIdx.x / blocks_per_image, part = blockIdx.x % blocks_per_image;
+    const uint8_t* pa = a + (size_t)img * pixels;
+    const uint8_t* pb = b + (size_t)img * pixels;
+    unsigned long long s = 0;
+    for (long i = (long)part * 256 + threadIdx.x; i < pixels; i += (long)blocks_per_image * 256) {
+        const int d = (int)pa[i] - (int)pb[i];
+        s += (unsigned long long)(d * d);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ unsigned long long red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sse[img], red[0] + red[1] + red[2] + red[3]);
+}
+}  // namespace
+
+extern "C" int eae_hip_quantize_maps(const float* y, const float* map_mean, const float* bin_widths, float* cq_out,
+                                     float* shifted_out, int16_t* symbols_planar, uint32_t* nonzero_flags,
+                                     uint32_t* range_error, int n, int hw, void* stream) {
+    if (!y || !bin_widths || n <= 0 || hw <= 0) return EAE_HIP_BAD_ARGUMENT;
+    const int chunks = (hw + PIX - 1) / PIX;
+    hipLaunchKernelGGL(quantize_kernel, dim3(n * chunks), dim3(256), 0, (hipStream_t)stream, y, map_mean, bin_widths,
+                       cq_out, shifted_out, symbols_planar, nonzero_flags, range_error, hw, chunks);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}
+
+extern "C" int eae_hip_symbol_histograms(const int16_t* symbols_planar, uint32_t* hist, int hist_radius,
+                                         uint32_t* overflow, int n_maps, int map_size, void* stream) {
+    if (!symbols_planar || !hist || !overflow || n_maps <= 0 || map_size <= 0) return EAE_HIP_BAD_ARGUMENT;
+    if (hist_radius < 0 || hist_radius > 32768) return EAE_HIP_BAD_ARGUMENT;
+    hipLaunchKernelGGL(hist_kernel, dim3(n_maps), dim3(256), 0, (hipStream_t)stream, symbols_planar, hist, hist_radius,
+                       overflow, map_size);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}
+
+extern "C" int eae_hip_cast_bt601(const float* x, uint8_t* out, int64_t count, void* stream) {
+    if (!x || !out || count <= 0) return EAE_HIP_BAD_ARGUMENT;
+    const long blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(cast_bt601_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, x,
+                       out, (long)count);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}
+
+extern "C" int eae_hip_sse_u8(const uint8_t* a, const uint8_t* b, uint64_t* sse, int n, int64_t pixels_per_image,
+                              void* stream) {
+    if (!a || !b || !sse || n <= 0 || pixels_per_image <= 0) return EAE_HIP_BAD_ARGUMENT;
+    long bpi = (pixels_per_image + 4095) / 4096;
+    if (bpi > 64) bpi = 64;
+    hipLaunchKernelGGL(sse_kernel, dim3((unsigned)(n * bpi)), dim3(256), 0, (hipStream_t)stream, a, b,
+                       reinterpret_cast<unsigned long long*>(sse), (long)pixels_per_image, (int)bpi);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}

@@ -1,0 +1,150 @@
+"""Device-resident ops: torch tensors (used only as HBM buffers + streams) -> include/eae_hip.h entry points.
+
+Every function launches asynchronously on torch's current stream and returns device tensors. There is no CPU
+fallback: a missing libeae_hip.so or a non-CUDA tensor raises.
+"""
+import torch
+
+from . import _native
+
+NORM_NONE, NORM_GDN, NORM_IGDN = 0, 1, 2
+NB_MAPS = 128
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _check(status, what):
+    if status != 0:
+        raise HipError('{0} failed with status {1}'.format(what, status))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError('expected a device tensor')
+    if not t.is_contiguous():
+        raise HipError('expected a contiguous tensor')
+    return t.data_ptr()
+
+
+def device_info():
+    import ctypes
+    name = ctypes.create_string_buffer(128)
+    cus = ctypes.c_int(0)
+    mhz = ctypes.c_int(0)
+    mem = ctypes.c_int64(0)
+    _check(_native.hip().eae_hip_device_info(name, 128, ctypes.byref(cus), ctypes.byref(mhz), ctypes.byref(mem)), 'device_info')
+    return {'name': name.value.decode(), 'compute_units': cus.value, 'clock_mhz': mhz.value, 'hbm_bytes': mem.value}
+
+
+def conv9x9s4_u8(x_u8, w, bias, gamma=None, beta=None, out=None):
+    """conv_1 + bias_add (+ gdn_1). x_u8: uint8 [N,H,W] or [N,H,W,1] -> f32 [N,H/4,W/4,128]."""
+    if x_u8.dtype != torch.uint8:
+        raise TypeError('`x_u8.dtype` is not `torch.uint8`.')
+    (n, h, wd) = x_u8.shape[:3]
+    if out is None:
+        out = torch.empty((n, h//4, wd//4, NB_MAPS), dtype=torch.float32, device=x_u8.device)
+    _check(_native.hip().eae_hip_conv9x9s4_u8(_p(x_u8), _p(w), _p(bias), _p(gamma), _p(beta), _p(out), n, h, wd, _stream()),
+           'eae_hip_conv9x9s4_u8')
+    return out
+
+
+def conv5x5s2(x, w, bias, norm=NORM_NONE, gamma=None, beta=None, out=None):
+    (n, h, wd, c) = x.shape
+    if out is None:
+        out = torch.empty((n, h//2, wd//2, NB_MAPS), dtype=torch.float32, device=x.device)
+    _check(_native.hip().eae_hip_conv5x5s2(_p(x), _p(w), _p(bias), norm, _p(gamma), _p(beta), _p(out), n, h, wd, _stream()),
+           'eae_hip_conv5x5s2')
+    return out
+
+
+def gdn(x, gamma, beta, inverse=False, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    rows = x.numel()//NB_MAPS
+    _check(_native.hip().eae_hip_gdn(_p(x), _p(gamma), _p(beta), 1 if inverse else 0, _p(out), rows, _stream()), 'eae_hip_gdn')
+    return out
+
+
+def tconv5x5s2(x, w_packed, bias, norm=NORM_NONE, gamma=None, beta=None, out=None):
+    (n, h, wd, c) = x.shape
+    if out is None:
+        out = torch.empty((n, 2*h, 2*wd, NB_MAPS), dtype=torch.float32, device=x.device)
+    _check(_native.hip().eae_hip_tconv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma), _p(beta), _p(out), n, h, wd, _stream()),
+           'eae_hip_tconv5x5s2')
+    return out
+
+
+def tconv9x9s4_luma(x, w_phase, want_f32=False, want_u8=True, ref_u8=None, sse=None):
+    """transpose_conv_3 (+ cast_bt601, + squared error vs ref_u8). Returns (f32 or None, u8 or None, sse or None)."""
+    (n, h, wd, c) = x.shape
+    out_f32 = torch.empty((n, 4*h, 4*wd), dtype=torch.float32, device=x.device) if want_f32 else None
+    out_u8 = torch.empty((n, 4*h, 4*wd), dtype=torch.uint8, device=x.device) if want_u8 else None
+    if ref_u8 is not None and sse is None:
+        sse = torch.zeros(n, dtype=torch.int64, device=x.device)
+    _check(_native.hip().eae_hip_tconv9x9s4_luma(_p(x), _p(w_phase), _p(out_f32), _p(out_u8), _p(ref_u8), _p(sse), n, h, wd, _stream()),
+           'eae_hip_tconv9x9s4_luma')
+    return out_f32, out_u8, sse
+
+
+def pack_tconv_weights(w_tf):
+    """[k,k,out,in] (TF conv2d_transpose filter) -> [k,k,in,out]."""
+    (k, k2, co, ci) = w_tf.shape
+    out = torch.empty((k, k2, ci, co), dtype=torch.float32, device=w_tf.device)
+    _check(_native.hip().eae_hip_pack_tconv_weights(_p(w_tf), _p(out), k*k2, co, ci, _stream()), 'eae_hip_pack_tconv_weights')
+    return out
+
+
+def pack_tconv9x9s4_weights(w_tf):
+    """[9,9,1,128] -> [9,128,16]."""
+    out = torch.empty((9, NB_MAPS, 16), dtype=torch.float32, device=w_tf.device)
+    _check(_native.hip().eae_hip_pack_tconv9x9s4_weights(_p(w_tf), _p(out), _stream()), 'eae_hip_pack_tconv9x9s4_weights')
+    return out
+
+
+def quantize_maps(y, bin_widths, map_mean=None, want_cq=False, want_shifted=False, want_symbols=False, want_flags=False):
+    """One pass over y [N,h,w,128]; see include/eae_hip.h. Returns a dict of the requested device tensors."""
+    (n, h, wd, c) = y.shape
+    dev = y.device
+    res = {}
+    cq = torch.empty_like(y) if want_cq else None
+    shifted = torch.empty_like(y) if want_shifted else None
+    symbols = torch.empty((n, c, h*wd), dtype=torch.int16, device=dev) if want_symbols else None
+    flags = torch.zeros((n, c), dtype=torch.int32, device=dev) if want_flags else None
+    range_error = torch.zeros(1, dtype=torch.int32, device=dev)
+    _check(_native.hip().eae_hip_quantize_maps(_p(y), _p(map_mean), _p(bin_widths), _p(cq), _p(shifted), _p(symbols), _p(flags),
+                                               _p(range_error), n, h*wd, _stream()), 'eae_hip_quantize_maps')
+    res.update(cq=cq, shifted=shifted, symbols=symbols, nonzero_flags=flags, range_error=range_error)
+    return res
+
+
+def symbol_histograms(symbols_planar, radius):
+    """symbols [..., map_size] int16 -> (hist int32 [n_maps, 2*radius+1], overflow int32 [n_maps])."""
+    map_size = symbols_planar.shape[-1]
+    n_maps = symbols_planar.numel()//map_size
+    hist = torch.zeros((n_maps, 2*radius + 1), dtype=torch.int32, device=symbols_planar.device)
+    overflow = torch.zeros(n_maps, dtype=torch.int32, device=symbols_planar.device)
+    _check(_native.hip().eae_hip_symbol_histograms(_p(symbols_planar), _p(hist), radius, _p(overflow), n_maps, map_size, _stream()),
+           'eae_hip_symbol_histograms')
+    return hist, overflow
+
+
+def cast_bt601(x):
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _check(_native.hip().eae_hip_cast_bt601(_p(x), _p(out), x.numel(), _stream()), 'eae_hip_cast_bt601')
+    return out
+
+
+def sse_u8(a, b):
+    """Per-image sum of squared differences of two uint8 stacks [N, ...] -> int64 [N]."""
+    n = a.shape[0]
+    sse = torch.zeros(n, dtype=torch.int64, device=a.device)
+    _check(_native.hip().eae_hip_sse_u8(_p(a), _p(b), _p(sse), n, a.numel()//n, _stream()), 'eae_hip_sse_u8')
+    return sse

@@ -1,0 +1,121 @@
+/*
+ * eae_hip.h -- C ABI of the gfx950 (MI355X / CDNA4) device path (libeae_hip.so).
+ *
+ * The reference has no native code for the transforms: its hot loops are the TensorFlow kernels that
+ * `sess.run(entropy_ae.node_y)` (kodak_tensorflow/eae/batching.py:96-99) and
+ * `sess.run(isolated_decoder.node_reconstruction)` (batching.py:49-52) dispatch, plus numpy helpers
+ * (kodak_tensorflow/tools/tools.py). Each entry point below replaces one TF op / numpy helper (or a fused run of
+ * them) and cites it. All pointers are DEVICE pointers unless named host_*; `stream` is a hipStream_t passed as
+ * void* (NULL = default stream). Layout is the reference's: NHWC, C-contiguous, float32 activations.
+ * Every function returns 0 on success, a negative EAE_HIP_* code for bad arguments, or a positive hipError_t.
+ * Launches are asynchronous on `stream`.
+ *
+ * NUMERICS CONTRACT (mirrored by oracle/transforms_oracle.c, checked bit-for-bit in tests):
+ *  - every dot product is ONE f32 fused-multiply-add chain in a fixed order (conv: taps row-major, then input
+ *    channel; GDN: channel ascending), started from +0, bias/beta added afterwards -- this is what
+ *    v_mfma_f32_32x32x2_f32 / 16x16x4_f32 compute (exact f32 FMA chain, k ascending);
+ *  - division, sqrt are correctly rounded; rounding to integer is round-half-to-even (numpy.round).
+ */
+#ifndef EAE_HIP_H
+#define EAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    EAE_HIP_OK = 0,
+    EAE_HIP_BAD_ARGUMENT = -1,  /* NULL pointer, non-positive size */
+    EAE_HIP_BAD_SHAPE = -2      /* spatial size not accepted by the op (see each op) */
+};
+
+enum { EAE_NORM_NONE = 0, EAE_NORM_GDN = 1, EAE_NORM_IGDN = 2 };
+
+#define EAE_NB_MAPS 128 /* eae/graph/constants.py:42-44 (NB_MAPS_1/2/3) */
+
+const char* eae_hip_version(void);
+/* Fills name (e.g. "gfx950:sramecc+:xnack-"), CU count; returns 0, or a hipError_t when no device is usable. */
+int eae_hip_device_info(char* name, int name_cap, int* compute_units, int* clock_mhz, int64_t* hbm_bytes);
+
+/* ---- analysis transform (eae/graph/components.py:86-142) ---------------------------------------------------------*/
+
+/* conv_1 + bias_add + gdn_1  (components.py:119-125; tf.nn.conv2d 9x9, 1->128, stride 4, 'SAME' = pad 2/3;
+ * tfutils.py:393-397). x: uint8 [N][H][W] (the uint8->float32 cast of batching.py:95 is done in-kernel, no offset,
+ * no scale); w: [9][9][1][128]; out: f32 [N][H/4][W/4][128]. H, W multiples of 4.
+ * gamma == NULL skips the normalisation (plain conv + bias). */
+int eae_hip_conv9x9s4_u8(const uint8_t* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                         float* out, int n, int h, int w_in, void* stream);
+
+/* conv_2 / conv_3 + bias_add (+ gdn_2 / gdn_3)  (components.py:126-142; tf.nn.conv2d 5x5, 128->128, stride 2,
+ * 'SAME' = pad 1/2). x: f32 [N][H][W][128]; w: [5][5][128][128] (HWIO); out: [N][H/2][W/2][128]. H, W even.
+ * norm: EAE_NORM_NONE (learned-bin-width model, components.py:137-138) or EAE_NORM_GDN. */
+int eae_hip_conv5x5s2(const float* x, const float* w, const float* bias, int norm, const float* gamma,
+                      const float* beta, float* out, int n, int h, int w_in, void* stream);
+
+/* GDN / IGDN on its own (tfutils.py:363-397 / 480-509): out[r][c] = x[r][c] (/ or *) sqrt(beta[c] + sum_k x[r][k]^2
+ * gamma[k][c]); x, out: [rows][128]. Used for inverse_gdn #4 (components.py:53-58) and as a standalone op. */
+int eae_hip_gdn(const float* x, const float* gamma, const float* beta, int inverse, float* out, int64_t rows,
+                void* stream);
+
+/* ---- synthesis transform (components.py:11-84) --------------------------------------------------------------------*/
+
+/* transpose_conv_1 / _2 + bias_add + inverse_gdn of the next layer (components.py:63-78; tf.nn.conv2d_transpose 5x5,
+ * 128->128, stride 2, 'SAME'). x: [N][h][w][128]; w_packed: [5][5][128 in][128 out] = the TF filter [5][5][out][in]
+ * with its last two axes swapped (eae_hip_pack_tconv_weights); out: [N][2h][2w][128]. */
+int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma,
+                       const float* beta, float* out, int n, int h, int w_in, void* stream);
+
+/* transpose_conv_3 (components.py:79-83; 9x9, 128->1, stride 4, 'SAME', no bias) fused with what follows it on the
+ * path: tls.cast_bt601 (tools.py:93: uint8(round_half_even(clip(x,16,235)))) and the squared error of tls.psnr_2d
+ * (tools.py:873-875). x: [N][h][w][128]; w_phase: [9][128][16] from eae_hip_pack_tconv9x9s4_weights;
+ * out_f32 (nullable): [N][4h][4w] float reconstruction; out_u8 (nullable): [N][4h][4w] BT.601 cast;
+ * ref_u8 + sse (both nullable): sse[i] += sum over image i of (ref - out_u8)^2, exact uint64 (caller zeroes). */
+int eae_hip_tconv9x9s4_luma(const float* x, const float* w_phase, float* out_f32, uint8_t* out_u8,
+                            const uint8_t* ref_u8, uint64_t* sse, int n, int h, int w_in, void* stream);
+
+/* TF filter [9][9][1][128] -> [9 neighbours][128][16 output phases] (zeros where a phase has no tap); device to device. */
+int eae_hip_pack_tconv9x9s4_weights(const float* w_tf, float* w_phase, void* stream);
+
+/* [5][5][out][in] -> [5][5][in][out] (or any [taps][a][b] -> [taps][b][a]); device to device. */
+int eae_hip_pack_tconv_weights(const float* w_tf, float* w_packed, int taps, int c_out, int c_in, void* stream);
+
+/* ---- quantiser, symbols, per-map statistics ------------------------------------------------------------------------
+ * One pass over the latents y: [N][h*w][C] f32, C = 128. For every element, with m = map_mean[c] (NULL = 0) and
+ * bw = bin_widths[c]:
+ *   centered  = y - m                                   (reconstructing_eae_kodak.py:178)
+ *   r         = round_half_even(centered / bw)          (tools.py:929)
+ *   cq        = bw * r                                  (tools.py:929, `quantize_per_map`)
+ *   symbol    = int16(round_half_even(cq / bw))         (lossless/compression.py:142, tools.py:126-133)
+ *   shifted   = cq + m                                  (reconstructing_eae_kodak.py:192)
+ * Outputs (each nullable):
+ *   cq_out, shifted_out : f32 [N][h*w][C]
+ *   symbols_planar      : int16 [N][C][h*w]  -- map-major: map (i, c) is `ref_int16[:, :, c].flatten()` of
+ *                         compression.py:77 for image i; this is the buffer the single device->host copy moves
+ *   nonzero_flags       : uint32 [N][C], set to 1 when some cq of the map is != 0 (so `count_nb_deads`,
+ *                         tools.py:318-320, is the number of zero flags); caller zeroes
+ *   range_error         : uint32 [1], += number of elements with |round(cq/bw)| >= 32768 (the AssertionError of
+ *                         tools.py:130-132); caller zeroes */
+int eae_hip_quantize_maps(const float* y, const float* map_mean, const float* bin_widths,
+                          float* cq_out, float* shifted_out, int16_t* symbols_planar,
+                          uint32_t* nonzero_flags, uint32_t* range_error, int n, int hw, void* stream);
+
+/* Per-map symbol histograms (tls.count_symbols, tools.py:376-388, is this histogram restricted to [min, max]; it feeds
+ * discrete_entropy :523-537, rate_3d :977-989 and stats.count_binary_decisions, lossless/stats.py:179-195).
+ * symbols_planar: int16 [n_maps][map_size]; hist: uint32 [n_maps][2*hist_radius+1], bin = symbol + hist_radius;
+ * symbols outside the radius are counted in overflow[n_maps] instead (re-run with a larger radius; 32768 covers
+ * int16). hist and overflow are ACCUMULATED into: the caller zeroes them. */
+int eae_hip_symbol_histograms(const int16_t* symbols_planar, uint32_t* hist, int hist_radius, uint32_t* overflow,
+                              int n_maps, int map_size, void* stream);
+
+/* tls.cast_bt601 (tools.py:61-93) on its own: u8 = uint8(round_half_even(clip(x, 16, 235))). */
+int eae_hip_cast_bt601(const float* x, uint8_t* out, int64_t count, void* stream);
+
+/* Squared error per image for tls.psnr_2d (tools.py:873-875): sse[i] += sum (a - b)^2 over pixels_per_image. */
+int eae_hip_sse_u8(const uint8_t* a, const uint8_t* b, uint64_t* sse, int n, int64_t pixels_per_image, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAE_HIP_H */

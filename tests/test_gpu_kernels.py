@@ -1,0 +1,222 @@
+"""GPU parity: every gfx950 kernel, called through the C ABI (include/eae_hip.h), against the CPU oracle on the same
+seeded inputs. Floating point results are compared with `numpy.array_equal` (exact equality; -0 == +0): the kernels
+reproduce the oracle's f32 FMA-chain order, so the stated tolerance is ZERO. Integer results are bit-exact."""
+import os
+
+import numpy
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def T():
+    import torch
+    return torch
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from autoencoder_based_image_compression_amd import device
+    return device
+
+
+@pytest.fixture(scope='module')
+def orc():
+    from oracle import transforms
+    return transforms
+
+
+def _vars(seed=0, learned=False):
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables
+    return variables.random_variables(1., learned, seed=seed, bias_std=0.01)
+
+
+def _cuda(T, a):
+    return T.from_numpy(numpy.ascontiguousarray(a)).cuda()
+
+
+def _image(rng, n, h, w):
+    x = rng.randint(16, 236, size=(n, h, w)).astype(numpy.float64)
+    for _ in range(3):   # 3x box blur, SURVEY.md 8(d)
+        x = (x + numpy.roll(x, 1, 1) + numpy.roll(x, -1, 1) + numpy.roll(x, 1, 2) + numpy.roll(x, -1, 2))/5.
+    return numpy.round(x).astype(numpy.uint8)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 96), (1, 48, 80), (3, 16, 16), (1, 32, 160)])
+@pytest.mark.parametrize('with_gdn', [True, False])
+def test_conv1_gdn1(T, dev, orc, shape, with_gdn):
+    v = _vars(1)
+    x = _image(numpy.random.RandomState(2), *shape)
+    ref = orc.conv2d_same(x.astype(numpy.float32)[..., None], v['encoder/weights_1'], 4, v['encoder/biases_1'])
+    if with_gdn:
+        ref = orc.gdn(ref, v['encoder/gamma_1'], v['encoder/beta_1'])
+    got = dev.conv9x9s4_u8(_cuda(T, x), _cuda(T, v['encoder/weights_1']), _cuda(T, v['encoder/biases_1']),
+                           _cuda(T, v['encoder/gamma_1']) if with_gdn else None,
+                           _cuda(T, v['encoder/beta_1']) if with_gdn else None).cpu().numpy()
+    assert got.shape == ref.shape
+    assert numpy.array_equal(got, ref)
+
+
+@pytest.mark.parametrize('tile', ['64', '128'])
+@pytest.mark.parametrize('shape', [(2, 16, 24), (1, 32, 64), (1, 6, 10), (2, 2, 2), (1, 20, 36)])
+@pytest.mark.parametrize('norm', [0, 1])
+def test_conv5x5s2(T, dev, orc, shape, norm, tile, monkeypatch):
+    monkeypatch.setenv('EAE_HIP_FORCE_TILE', tile)
+    v = _vars(3)
+    rng = numpy.random.RandomState(4)
+    x = rng.standard_normal(size=shape + (128,)).astype(numpy.float32)
+    ref = orc.conv2d_same(x, v['encoder/weights_2'], 2, v['encoder/biases_2'])
+    if norm:
+        ref = orc.gdn(ref, v['encoder/gamma_2'], v['encoder/beta_2'])
+    got = dev.conv5x5s2(_cuda(T, x), _cuda(T, v['encoder/weights_2']), _cuda(T, v['encoder/biases_2']), norm,
+                        _cuda(T, v['encoder/gamma_2']), _cuda(T, v['encoder/beta_2'])).cpu().numpy()
+    assert numpy.array_equal(got, ref)
+
+
+@pytest.mark.parametrize('tile', ['64', '128'])
+@pytest.mark.parametrize('shape', [(2, 8, 12), (1, 16, 32), (1, 3, 5), (2, 1, 1), (1, 10, 18)])
+@pytest.mark.parametrize('norm', [0, 2])
+def test_tconv5x5s2(T, dev, orc, shape, norm, tile, monkeypatch):
+    monkeypatch.setenv('EAE_HIP_FORCE_TILE', tile)
+    v = _vars(5)
+    rng = numpy.random.RandomState(6)
+    x = rng.standard_normal(size=shape + (128,)).astype(numpy.float32)
+    ref = orc.conv2d_transpose_same(x, v['decoder/weights_4'], 2, v['decoder/biases_4'])
+    if norm:
+        ref = orc.gdn(ref, v['decoder/gamma_5'], v['decoder/beta_5'], inverse=True)
+    wp = dev.pack_tconv_weights(_cuda(T, v['decoder/weights_4']))
+    assert numpy.array_equal(wp.cpu().numpy(), numpy.ascontiguousarray(v['decoder/weights_4'].transpose(0, 1, 3, 2)))
+    got = dev.tconv5x5s2(_cuda(T, x), wp, _cuda(T, v['decoder/biases_4']), norm,
+                         _cuda(T, v['decoder/gamma_5']), _cuda(T, v['decoder/beta_5'])).cpu().numpy()
+    assert numpy.array_equal(got, ref)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 24), (1, 4, 16), (1, 5, 7), (3, 1, 1), (1, 12, 40)])
+def test_tconv9x9s4_luma(T, dev, orc, shape):
+    v = _vars(7)
+    rng = numpy.random.RandomState(8)
+    # positive weights and inputs so that the reconstruction spans the BT.601 range instead of sitting on the clip floor
+    w6 = (numpy.absolute(v['decoder/weights_6'])*numpy.float32(8.)).astype(numpy.float32)
+    x = (rng.standard_normal(size=shape + (128,)) + 1.5).astype(numpy.float32)
+    ref = orc.conv2d_transpose_same(x, w6, 4, None)[..., 0]
+    ref_u8 = numpy.round(ref.clip(min=16., max=235.)).astype(numpy.uint8)
+    target = _image(numpy.random.RandomState(9), shape[0], 4*shape[1], 4*shape[2])
+    wph = dev.pack_tconv9x9s4_weights(_cuda(T, w6))
+    f32, u8, sse = dev.tconv9x9s4_luma(_cuda(T, x), wph, want_f32=True, want_u8=True, ref_u8=_cuda(T, target))
+    assert numpy.array_equal(f32.cpu().numpy(), ref)
+    assert numpy.array_equal(u8.cpu().numpy(), ref_u8)
+    expected = ((target.astype(numpy.int64) - ref_u8.astype(numpy.int64))**2).reshape(shape[0], -1).sum(axis=1)
+    assert numpy.array_equal(sse.cpu().numpy(), expected)
+    if shape[1]*shape[2] >= 16:
+        assert len(numpy.unique(ref_u8)) > 4   # the data exercises the cast, not only the clip floor
+
+
+@pytest.mark.parametrize('rows', [1, 127, 128, 1000])
+@pytest.mark.parametrize('inverse', [False, True])
+def test_gdn(T, dev, orc, rows, inverse):
+    v = _vars(10)
+    x = numpy.random.RandomState(11).standard_normal(size=(rows, 128)).astype(numpy.float32)*3
+    ref = orc.gdn(x, v['encoder/gamma_3'], v['encoder/beta_3'], inverse=inverse)
+    got = dev.gdn(_cuda(T, x), _cuda(T, v['encoder/gamma_3']), _cuda(T, v['encoder/beta_3']), inverse=inverse).cpu().numpy()
+    assert numpy.array_equal(got, ref)
+
+
+def test_gdn_reference_known_answer(T, dev):
+    """test_tfutils.py:398-423, 493-518: gamma = 0, beta = 4 -> x/2 and x*2."""
+    x = numpy.random.RandomState(12).standard_normal(size=(2, 4, 6, 128)).astype(numpy.float32)
+    g = numpy.zeros((128, 128), dtype=numpy.float32)
+    b = numpy.full(128, 4., dtype=numpy.float32)
+    assert numpy.array_equal(dev.gdn(_cuda(T, x), _cuda(T, g), _cuda(T, b)).cpu().numpy(), x/2)
+    assert numpy.array_equal(dev.gdn(_cuda(T, x), _cuda(T, g), _cuda(T, b), inverse=True).cpu().numpy(), x*2)
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 12), (1, 32, 48), (3, 2, 2), (1, 5, 13)])
+def test_quantize_maps_and_histograms(T, dev, shape):
+    rng = numpy.random.RandomState(13)
+    y = (rng.laplace(size=shape + (128,))*3).astype(numpy.float32)
+    y[..., 5] = 0.01   # a dead map (after centring by a mean of 0.01 it is exactly 0)
+    y[0, 0, 0, 7] = 2.5
+    y[0, 0, 1, 7] = -2.5
+    y[0, 1, 0, 7] = 3.5   # half-way cases with bw = 1
+    bw = rng.uniform(0.5, 2., size=128).astype(numpy.float32)
+    bw[7] = 1.
+    mean = (rng.standard_normal(size=128)*0.1).astype(numpy.float32)
+    mean[5] = numpy.float32(0.01)
+    mean[7] = 0.
+    res = dev.quantize_maps(_cuda(T, y), _cuda(T, bw), _cuda(T, mean), want_cq=True, want_shifted=True, want_symbols=True,
+                            want_flags=True)
+    # numpy restatement of reconstructing_eae_kodak.py:178-192 + tools.py:927-929 + compression.py:142
+    centered = y - numpy.tile(mean, shape + (1,))
+    tiled = numpy.tile(bw.reshape(1, 1, 1, 128), shape + (1,))
+    cq = tiled*numpy.round(centered/tiled)
+    sym = numpy.round(cq/tiled).astype(numpy.int16)
+    assert numpy.array_equal(res['cq'].cpu().numpy(), cq)
+    assert numpy.array_equal(res['shifted'].cpu().numpy(), cq + numpy.tile(mean, shape + (1,)))
+    planar = numpy.ascontiguousarray(sym.reshape(shape[0], -1, 128).transpose(0, 2, 1))
+    assert numpy.array_equal(res['symbols'].cpu().numpy(), planar)
+    assert int(res['range_error'].item()) == 0
+    dead = numpy.sum(numpy.sum(numpy.absolute(cq), axis=(1, 2)) == 0, axis=1)     # tools.py:318-320
+    assert numpy.array_equal((res['nonzero_flags'].cpu().numpy() == 0).sum(axis=1), dead)
+    assert dead.min() >= 1
+    assert tuple(sym[0, 0, :2, 7]) == (2, -2) and sym[0, 1, 0, 7] == 4            # round half to even
+    for radius in (3, 40, 5000):
+        hist, overflow = dev.symbol_histograms(res['symbols'], radius)
+        hist = hist.cpu().numpy()
+        overflow = overflow.cpu().numpy()
+        flat = planar.reshape(-1, planar.shape[-1]).astype(numpy.int64)
+        for m in range(0, flat.shape[0], 17):
+            inside = flat[m][numpy.absolute(flat[m]) <= radius]
+            assert numpy.array_equal(hist[m], numpy.bincount(inside + radius, minlength=2*radius + 1))
+            assert overflow[m] == flat[m].size - inside.size
+
+
+def test_quantize_range_error(T, dev):
+    y = numpy.zeros((1, 2, 2, 128), dtype=numpy.float32)
+    y[0, 0, 0, 3] = 40000.
+    y[0, 1, 1, 4] = -32768.
+    y[0, 1, 0, 4] = 32767.
+    res = dev.quantize_maps(_cuda(T, y), _cuda(T, numpy.ones(128, dtype=numpy.float32)), None, want_symbols=True)
+    assert int(res['range_error'].item()) == 2
+
+
+def test_cast_bt601_and_sse(T, dev):
+    """tools.py:61-93 incl. the reference's own example (test_tools.py:56-71) and half-way cases."""
+    x = numpy.array([[15.431, -0.001, 0.], [235.678, 143.18, 1.111]], dtype=numpy.float32)
+    assert numpy.array_equal(dev.cast_bt601(_cuda(T, x)).cpu().numpy(), numpy.array([[16, 16, 16], [235, 143, 16]], dtype=numpy.uint8))
+    rng = numpy.random.RandomState(14)
+    big = numpy.concatenate([rng.uniform(-10, 260, size=100000), numpy.arange(16, 236) + 0.5]).astype(numpy.float32)
+    assert numpy.array_equal(dev.cast_bt601(_cuda(T, big)).cpu().numpy(), numpy.round(big.clip(min=16., max=235.)).astype(numpy.uint8))
+    a = rng.randint(0, 256, size=(3, 40, 56)).astype(numpy.uint8)
+    b = rng.randint(0, 256, size=(3, 40, 56)).astype(numpy.uint8)
+    expected = ((a.astype(numpy.int64) - b.astype(numpy.int64))**2).reshape(3, -1).sum(axis=1)
+    assert numpy.array_equal(dev.sse_u8(_cuda(T, a), _cuda(T, b)).cpu().numpy(), expected)
+
+
+@pytest.mark.parametrize('learned', [False, True])
+def test_full_chain_bitwise(T, dev, orc, learned):
+    """encoder -> quantiser -> decoder through the kernels == the oracle composition, exactly (64x96 image)."""
+    v = _vars(20, learned)
+    v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
+    x = _image(numpy.random.RandomState(21), 2, 64, 96)
+    y_ref = orc.encoder(x.astype(numpy.float32)[..., None], v, learned)
+    d = {k: _cuda(T, a) for k, a in v.items()}
+    a1 = dev.conv9x9s4_u8(_cuda(T, x), d['encoder/weights_1'], d['encoder/biases_1'], d['encoder/gamma_1'], d['encoder/beta_1'])
+    a2 = dev.conv5x5s2(a1, d['encoder/weights_2'], d['encoder/biases_2'], 1, d['encoder/gamma_2'], d['encoder/beta_2'])
+    if learned:
+        y = dev.conv5x5s2(a2, d['encoder/weights_3'], d['encoder/biases_3'], 0)
+    else:
+        y = dev.conv5x5s2(a2, d['encoder/weights_3'], d['encoder/biases_3'], 1, d['encoder/gamma_3'], d['encoder/beta_3'])
+    assert numpy.array_equal(y.cpu().numpy(), y_ref)
+    bw = numpy.full(128, 0.5, dtype=numpy.float32)
+    q = dev.quantize_maps(y, _cuda(T, bw), None, want_shifted=True)['shifted']
+    tiled = numpy.tile(bw.reshape(1, 1, 1, 128), y_ref.shape[:3] + (1,))
+    q_ref = tiled*numpy.round(y_ref/tiled)
+    assert numpy.array_equal(q.cpu().numpy(), q_ref)
+    rec_ref = orc.decoder(q_ref, v, learned)[..., 0]
+    t = q if learned else dev.gdn(q, d['decoder/gamma_4'], d['decoder/beta_4'], inverse=True)
+    t = dev.tconv5x5s2(t, dev.pack_tconv_weights(d['decoder/weights_4']), d['decoder/biases_4'], 2, d['decoder/gamma_5'], d['decoder/beta_5'])
+    t = dev.tconv5x5s2(t, dev.pack_tconv_weights(d['decoder/weights_5']), d['decoder/biases_5'], 2, d['decoder/gamma_6'], d['decoder/beta_6'])
+    f32, u8, _ = dev.tconv9x9s4_luma(t, dev.pack_tconv9x9s4_weights(d['decoder/weights_6']), want_f32=True, want_u8=True)
+    assert numpy.array_equal(f32.cpu().numpy(), rec_ref)
+    assert numpy.array_equal(u8.cpu().numpy(), numpy.round(rec_ref.clip(min=16., max=235.)).astype(numpy.uint8))

@@ -15,7 +15,7 @@ constexpr int PIX = 64;   // pixels per block
 __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__ y, const float* __restrict__ map_mean,
                                                        const float* __restrict__ bin_widths, float* __restrict__ cq_out,
                                                        float* __restrict__ shifted_out, int16_t* __restrict__ symbols,
-                                                       unsigned int* __restrict__ nonzero, unsigned int* range_error,
+                                                       unsigned int* __restrict__ nonzero, unsigned int* checks,
                                                        int hw, int chunks) {
     __shared__ int16_t tile[EAE_C][PIX + 2];
     const int tid = threadIdx.x;
@@ -24,19 +24,24 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__
     const float m = map_mean ? map_mean[c] : 0.f;
     const float bw = bin_widths[c];
     bool any_nonzero = false;
-    unsigned int bad = 0;
+    unsigned int bad = 0, not_quantized = 0, altered = 0;
     const int p0 = chunk * PIX + half * (PIX / 2);
 #pragma unroll 4
     for (int i = 0; i < PIX / 2; ++i) {
         const int pix = p0 + i;
         if (pix < hw) {
             const size_t idx = ((size_t)img * hw + pix) * EAE_C + c;
-            const float centered = y[idx] - m;
+            const float yin = y[idx];
+            const float centered = yin - m;
             const float r = round_half_even(centered / bw);
             const float cq = bw * r;
             // compression.py:142: symbols come from cq / bw again (not from r), rounded half to even
             const float rs = round_half_even(cq / bw);
             if (!(fabsf(rs) < 32768.f)) bad++;              // tools.py:130-132 (AssertionError in the reference)
+            // tools.py:372-375 on an input that claims to be quantised already: |bw*round(x/bw) - x| < 1.5e-10
+            if (!(fabs((double)cq - (double)centered) < 1.5e-10)) not_quantized++;
+            // compression.py:149-153: int16 symbol * bw must give the input back exactly
+            if (!((float)(int16_t)(int)rs * bw == centered)) altered++;
             if (cq_out) cq_out[idx] = cq;
             if (shifted_out) shifted_out[idx] = cq + m;
             if (cq != 0.f) any_nonzero = true;              // NaN counts as non-zero, like sum(abs(.)) == 0 failing
@@ -44,7 +49,11 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__
         }
     }
     if (any_nonzero && nonzero) nonzero[img * EAE_C + c] = 1u;   // benign race: every writer stores 1
-    if (bad && range_error) atomicAdd(range_error, bad);
+    if (checks) {
+        if (bad) atomicAdd(&checks[0], bad);
+        if (not_quantized) atomicAdd(&checks[1], not_quantized);
+        if (altered) atomicAdd(&checks[2], altered);
+    }
     if (symbols) {
         __syncthreads();
         // planar write: a wave covers 64 consecutive pixels of one map (128 B)
@@ -53,6 +62,54 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__
             const int pix = chunk * PIX + px;
             if (pix < hw) symbols[((size_t)img * EAE_C + ch) * hw + pix] = tile[ch][px];
         }
+    }
+}
+
+// Any channel count (the tools.* helpers accept arbitrary arrays, e.g. one map with a scalar bin width): one element per
+// thread, same arithmetic as above.
+__global__ void quantize_generic_kernel(const float* __restrict__ y, const float* __restrict__ map_mean,
+                                        const float* __restrict__ bin_widths, float* __restrict__ cq_out,
+                                        float* __restrict__ shifted_out, int16_t* __restrict__ symbols,
+                                        unsigned int* __restrict__ nonzero, unsigned int* checks, long total, int hw,
+                                        int c_count) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c_count);
+        const long pixel = idx / c_count;
+        const long img = pixel / hw;
+        const int pix = (int)(pixel % hw);
+        const float m = map_mean ? map_mean[c] : 0.f;
+        const float bw = bin_widths[c];
+        const float centered = y[idx] - m;
+        const float r = round_half_even(centered / bw);
+        const float cq = bw * r;
+        const float rs = round_half_even(cq / bw);
+        if (checks) {
+            if (!(fabsf(rs) < 32768.f)) atomicAdd(&checks[0], 1u);
+            if (!(fabs((double)cq - (double)centered) < 1.5e-10)) atomicAdd(&checks[1], 1u);
+            if (!((float)(int16_t)(int)rs * bw == centered)) atomicAdd(&checks[2], 1u);
+        }
+        if (cq_out) cq_out[idx] = cq;
+        if (shifted_out) shifted_out[idx] = cq + m;
+        if (nonzero && cq != 0.f) nonzero[img * c_count + c] = 1u;
+        if (symbols) symbols[((size_t)img * c_count + c) * hw + pix] = (int16_t)(int)rs;
+    }
+}
+
+// tls.count_nb_deads (tools.py:318-320) on an arbitrary stack [N][hw][C]: flag (n, c) when some element is non-zero.
+__global__ void nonzero_flags_kernel(const float* __restrict__ x, unsigned int* __restrict__ nonzero, long total, int hw,
+                                     int c_count) {
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        if (x[idx] != 0.f) nonzero[(idx / c_count / hw) * c_count + idx % c_count] = 1u;
+    }
+}
+
+// tls.cast_float_to_int16 (tools.py:126-133): int16(round_half_even(x)); range_error counts |round(x)| >= 32768.
+__global__ void cast_int16_kernel(const float* __restrict__ x, int16_t* __restrict__ out, long count,
+                                  unsigned int* range_error) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float r = round_half_even(x[i]);
+        if (!(fabsf(r) < 32768.f)) atomicAdd(range_error, 1u);
+        out[i] = (int16_t)(int)r;
     }
 }
 
@@ -107,13 +164,41 @@ __global__ __launch_bounds__(256) void sse_kernel(const uint8_t* __restrict__ a,
 }
 }  // namespace
 
+static unsigned grid_for(long total) {
+    const long blocks = (total + 255) / 256;
+    return (unsigned)(blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks));
+}
+
 extern "C" int eae_hip_quantize_maps(const float* y, const float* map_mean, const float* bin_widths, float* cq_out,
                                      float* shifted_out, int16_t* symbols_planar, uint32_t* nonzero_flags,
-                                     uint32_t* range_error, int n, int hw, void* stream) {
-    if (!y || !bin_widths || n <= 0 || hw <= 0) return EAE_HIP_BAD_ARGUMENT;
-    const int chunks = (hw + PIX - 1) / PIX;
-    hipLaunchKernelGGL(quantize_kernel, dim3(n * chunks), dim3(256), 0, (hipStream_t)stream, y, map_mean, bin_widths,
-                       cq_out, shifted_out, symbols_planar, nonzero_flags, range_error, hw, chunks);
+                                     uint32_t* checks, int n, int hw, int c, void* stream) {
+    if (!y || !bin_widths || n <= 0 || hw <= 0 || c <= 0) return EAE_HIP_BAD_ARGUMENT;
+    if (c == EAE_C) {
+        const int chunks = (hw + PIX - 1) / PIX;
+        hipLaunchKernelGGL(quantize_kernel, dim3(n * chunks), dim3(256), 0, (hipStream_t)stream, y, map_mean, bin_widths,
+                           cq_out, shifted_out, symbols_planar, nonzero_flags, checks, hw, chunks);
+    } else {
+        const long total = (long)n * hw * c;
+        hipLaunchKernelGGL(quantize_generic_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y, map_mean,
+                           bin_widths, cq_out, shifted_out, symbols_planar, nonzero_flags, checks, total, hw, c);
+    }
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}
+
+extern "C" int eae_hip_nonzero_flags(const float* x, uint32_t* nonzero_flags, int n, int hw, int c, void* stream) {
+    if (!x || !nonzero_flags || n <= 0 || hw <= 0 || c <= 0) return EAE_HIP_BAD_ARGUMENT;
+    const long total = (long)n * hw * c;
+    hipLaunchKernelGGL(nonzero_flags_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, nonzero_flags, total,
+                       hw, c);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}
+
+extern "C" int eae_hip_cast_int16(const float* x, int16_t* out, int64_t count, uint32_t* range_error, void* stream) {
+    if (!x || !out || !range_error || count <= 0) return EAE_HIP_BAD_ARGUMENT;
+    hipLaunchKernelGGL(cast_int16_kernel, dim3(grid_for((long)count)), dim3(256), 0, (hipStream_t)stream, x, out, (long)count,
+                       range_error);
     EAE_HIP_CHECK_LAUNCH();
     return EAE_HIP_OK;
 }

@@ -110,19 +110,40 @@ def pack_tconv9x9s4_weights(w_tf):
 
 
 def quantize_maps(y, bin_widths, map_mean=None, want_cq=False, want_shifted=False, want_symbols=False, want_flags=False):
-    """One pass over y [N,h,w,128]; see include/eae_hip.h. Returns a dict of the requested device tensors."""
-    (n, h, wd, c) = y.shape
-    dev = y.device
-    res = {}
+    """One pass over y [N,h,w,C] (or [N,hw,C]); see include/eae_hip.h. Returns a dict of the requested device tensors.
+
+    `checks` (int32 [3]) always comes back: [0] int16 range violations, [1] "quantization was omitted" count,
+    [2] "lossless compression altered the data" count.
+    """
+    n = y.shape[0]
+    c = y.shape[-1]
+    hw = y.numel()//(n*c)
+    d = y.device
     cq = torch.empty_like(y) if want_cq else None
     shifted = torch.empty_like(y) if want_shifted else None
-    symbols = torch.empty((n, c, h*wd), dtype=torch.int16, device=dev) if want_symbols else None
-    flags = torch.zeros((n, c), dtype=torch.int32, device=dev) if want_flags else None
-    range_error = torch.zeros(1, dtype=torch.int32, device=dev)
+    symbols = torch.empty((n, c, hw), dtype=torch.int16, device=d) if want_symbols else None
+    flags = torch.zeros((n, c), dtype=torch.int32, device=d) if want_flags else None
+    checks = torch.zeros(3, dtype=torch.int32, device=d)
     _check(_native.hip().eae_hip_quantize_maps(_p(y), _p(map_mean), _p(bin_widths), _p(cq), _p(shifted), _p(symbols), _p(flags),
-                                               _p(range_error), n, h*wd, _stream()), 'eae_hip_quantize_maps')
-    res.update(cq=cq, shifted=shifted, symbols=symbols, nonzero_flags=flags, range_error=range_error)
-    return res
+                                               _p(checks), n, hw, c, _stream()), 'eae_hip_quantize_maps')
+    return {'cq': cq, 'shifted': shifted, 'symbols': symbols, 'nonzero_flags': flags, 'checks': checks}
+
+
+def nonzero_flags(x):
+    """x [N, ..., C] -> int32 [N, C], 1 where map (n, c) has a non-zero element."""
+    n = x.shape[0]
+    c = x.shape[-1]
+    flags = torch.zeros((n, c), dtype=torch.int32, device=x.device)
+    _check(_native.hip().eae_hip_nonzero_flags(_p(x), _p(flags), n, x.numel()//(n*c), c, _stream()), 'eae_hip_nonzero_flags')
+    return flags
+
+
+def cast_int16(x):
+    """int16(round_half_even(x)) and the count of out-of-range elements (int32 [1])."""
+    out = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+    range_error = torch.zeros(1, dtype=torch.int32, device=x.device)
+    _check(_native.hip().eae_hip_cast_int16(_p(x), _p(out), x.numel(), _p(range_error), _stream()), 'eae_hip_cast_int16')
+    return out, range_error
 
 
 def symbol_histograms(symbols_planar, radius):

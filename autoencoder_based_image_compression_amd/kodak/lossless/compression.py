@@ -1,0 +1,144 @@
+"""Per-image lossless coding of the quantized latent variables; mirrors kodak_tensorflow/lossless/compression.py.
+
+`compress_lossless_maps` :11-82 and `rescale_compress_lossless_maps` :84-154, same signatures, return values and
+exceptions. Differences in HOW: the float -> int16 symbol conversion and the exception map's histogram run on the
+MI355X (one kernel, symbols land map-major so that ONE device -> host copy feeds the coder); the 127 coder calls of
+the reference's Python loop (:67-81) become one threaded `eae_coder_compress_maps` call (include/eae_coder.h).
+"""
+import ctypes
+import os
+
+import numpy
+
+from ... import _native
+from ... import device as dev
+from .. import _backend as bk
+from ..tools import tools as tls
+from . import interface_cython
+
+_probabilities_cache = {}
+
+
+def load_binary_probabilities(path_to_binary_probabilities):
+    """`numpy.load` of the binary probabilities (the reference reloads the file on every call, compression.py:60;
+    here the array is cached per (path, mtime, size))."""
+    stat = os.stat(path_to_binary_probabilities)
+    key = (os.path.abspath(path_to_binary_probabilities), stat.st_mtime_ns, stat.st_size)
+    if key not in _probabilities_cache:
+        _probabilities_cache.clear()
+        _probabilities_cache[key] = numpy.load(path_to_binary_probabilities)
+    return _probabilities_cache[key]
+
+
+def code_planar_symbols(symbols_planar, binary_probabilities, idx_map_exception=-1, nb_threads=0, roundtrip=True):
+    """Codes every map of a batch after the single device -> host copy.
+
+    symbols_planar : int16 (nb_images, nb_maps, map_size), C-contiguous (the layout of `eae_hip_quantize_maps`).
+    binary_probabilities : float64 (nb_maps, L).
+    Returns (reconstruction int16 like `symbols_planar` or None, nb_bits uint32 (nb_images, nb_maps)); the entry of
+    the exception map is 0 here -- its cost comes from its histogram (compression.py:68-75).
+    Raises like `compress_lossless_flattened_map` for the first failing map.
+    """
+    (nb_images, nb_maps, map_size) = symbols_planar.shape
+    probabilities = numpy.ascontiguousarray(binary_probabilities, dtype=numpy.float64)
+    truncated_unary_length = probabilities.shape[1]
+    if truncated_unary_length > 255:
+        raise OverflowError('value too large to convert to numpy.uint8_t')   # interface_cython.pyx:49
+    n = nb_images*nb_maps
+    prob_row = numpy.tile(numpy.arange(nb_maps, dtype=numpy.int32), nb_images)
+    if idx_map_exception >= 0:
+        prob_row[idx_map_exception::nb_maps] = -1
+    nb_bits = numpy.zeros(n, dtype=numpy.uint32)
+    status = numpy.zeros(n, dtype=numpy.int32)
+    stage = numpy.zeros(n, dtype=numpy.int32)
+    reconstruction = numpy.empty_like(symbols_planar) if roundtrip else None
+    lib = _native.coder()
+    lib.eae_coder_compress_maps(n, map_size, _native.ptr(symbols_planar, _native.c_i16p),
+                                _native.ptr(reconstruction, _native.c_i16p) if roundtrip else None,
+                                truncated_unary_length, _native.ptr(probabilities, _native.c_f64p),
+                                _native.ptr(prob_row, _native.c_i32p), _native.ptr(nb_bits, _native.c_u32p),
+                                _native.ptr(status, _native.c_i32p), _native.ptr(stage, _native.c_i32p),
+                                0 if roundtrip else 1, nb_threads)
+    bad = numpy.flatnonzero(status)
+    if bad.size:
+        interface_cython.raise_for_status(int(status[bad[0]]), int(stage[bad[0]]))
+    return (reconstruction, nb_bits.reshape(nb_images, nb_maps))
+
+
+def exception_map_nb_bits(hist_row, map_size):
+    """compression.py:73-74: ceil(h*w*discrete_entropy(map, 1.)) from the map's exact symbol histogram."""
+    occupied = numpy.flatnonzero(hist_row)
+    cumulated_entropy = map_size*tls._entropy_from_hist(hist_row[occupied[0]:occupied[-1] + 1])
+    return numpy.ceil(cumulated_entropy).astype(numpy.uint32)
+
+
+# The functions are sorted in alphabetic order.
+
+def compress_lossless_maps(ref_int16, path_to_binary_probabilities, idx_map_exception=-1):
+    """Compresses without loss each map of signed integers separately (compression.py:11-82).
+
+    Returns (reconstruction int16 (h, w, nb_maps), coding costs uint32 (nb_maps,)).
+
+    Raises
+    ------
+    TypeError
+        If `ref_int16.dtype` is not equal to `numpy.int16`.
+    ValueError
+        If `binary_probabilities.ndim` is not equal to 2 or its first dimension is not `ref_int16.shape[2]`.
+    """
+    if ref_int16.dtype != numpy.int16:
+        raise TypeError('`ref_int16.dtype` is not equal to `numpy.int16`.')
+    (height_map, width_map, nb_maps) = ref_int16.shape
+    binary_probabilities = load_binary_probabilities(path_to_binary_probabilities)
+    if binary_probabilities.ndim != 2:
+        raise ValueError('`binary_probabilities.ndim` is not equal to 2.')
+    if binary_probabilities.shape[0] != nb_maps:
+        raise ValueError('`binary_probabilities.shape[0]` is not equal to `ref_int16.shape[2]`.')
+    planar = numpy.ascontiguousarray(ref_int16.reshape(height_map*width_map, nb_maps).T)[None]
+    (rec_planar, nb_bits) = code_planar_symbols(planar, binary_probabilities, idx_map_exception)
+    nb_bits_each_map = nb_bits[0].copy()
+    if 0 <= idx_map_exception < nb_maps:
+        (hist, radius) = tls._symbol_histograms(bk.to_device(planar[0, idx_map_exception:idx_map_exception + 1]))
+        nb_bits_each_map[idx_map_exception] = exception_map_nb_bits(hist[0], height_map*width_map)
+    rec_int16 = numpy.ascontiguousarray(rec_planar[0].T).reshape(height_map, width_map, nb_maps)
+    return (rec_int16, nb_bits_each_map)
+
+
+def rescale_compress_lossless_maps(centered_quantized_data, bin_widths_test, path_to_binary_probabilities, idx_map_exception=-1):
+    """Rescales and compresses without loss each map of centered-quantized data separately (compression.py:84-154).
+
+    Returns the number of bits in the bitstream (int).
+
+    Raises
+    ------
+    ValueError
+        If `bin_widths_test.ndim` is not equal to 1 or its size is not `centered_quantized_data.shape[2]`.
+    AssertionError
+        If the lossless compression has altered the centered quantized data.
+    """
+    if bin_widths_test.ndim != 1:
+        raise ValueError('`bin_widths_test.ndim` is not equal to 1.')
+    (height_map, width_map, nb_maps) = centered_quantized_data.shape
+    if bin_widths_test.size != nb_maps:
+        raise ValueError('`bin_widths_test.size` is not equal to `centered_quantized_data.shape[2]`.')
+    binary_probabilities = load_binary_probabilities(path_to_binary_probabilities)
+    if binary_probabilities.ndim != 2:
+        raise ValueError('`binary_probabilities.ndim` is not equal to 2.')
+    if binary_probabilities.shape[0] != nb_maps:
+        raise ValueError('`binary_probabilities.shape[0]` is not equal to `ref_int16.shape[2]`.')
+    # compression.py:142 on the device: int16(round(cq / bw)), map-major; checks[0] is the int16 assertion of
+    # tools.py:130-132, checks[2] the final `assert_equal` of compression.py:149-153 (symbol*bw must give cq back).
+    res = dev.quantize_maps(bk.to_device(centered_quantized_data[None], numpy.float32), bk.to_device(bin_widths_test, numpy.float32),
+                            None, want_symbols=True)
+    checks = res['checks'].cpu().tolist()
+    if checks[0] != 0:
+        raise AssertionError('The rounded array elements cannot be represented as 16-bit signed integers.')
+    symbols_planar = bk.to_host(res['symbols'])                      # the single device -> host copy
+    (rec_planar, nb_bits) = code_planar_symbols(symbols_planar, binary_probabilities, idx_map_exception)
+    nb_bits_each_map = nb_bits[0]
+    if 0 <= idx_map_exception < nb_maps:
+        (hist, radius) = tls._symbol_histograms(res['symbols'][:, idx_map_exception:idx_map_exception + 1].contiguous())
+        nb_bits_each_map[idx_map_exception] = exception_map_nb_bits(hist[0], height_map*width_map)
+    if checks[2] != 0 or not numpy.array_equal(rec_planar, symbols_planar):
+        raise AssertionError('\nArrays are not equal\nThe lossless compression has altered the centered quantized data.')
+    return numpy.sum(nb_bits_each_map).item()

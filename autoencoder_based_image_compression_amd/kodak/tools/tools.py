@@ -1,0 +1,208 @@
+"""Hot-path subset of the reference's `tools/tools.py`, same names / arguments / exceptions, computed on the MI355X.
+
+Reference: kodak_tensorflow/tools/tools.py -- `average_entropies` :25-59, `cast_bt601` :61-93,
+`cast_float_to_int16` :95-133, `count_nb_deads` :294-320, `count_symbols` :322-388, `discrete_entropy` :486-537,
+`float_to_str` :570-593, `psnr_2d` :831-881, `quantize_per_map` :883-929, `rate_3d` :931-989, `subdivide_set`
+:1108-1132. Arrays come in and go out as numpy (the reference's contract); the element-wise and counting work runs in
+the kernels of include/eae_hip.h; the few float64 scalars at the end (`-sum f log2 f`, `10 log10(255^2/mse)`) are
+formed on the host from EXACT integer counts with the reference's own numpy expressions, so they are bit-identical.
+Plotting, image I/O, Bjontegaard and dataset helpers of the reference file are out of scope.
+"""
+import numpy
+
+from ... import device as dev
+from .. import _backend as bk
+
+# Histogram radius tried first; symbols outside trigger a re-run with the int16-covering radius (exact either way).
+_FIRST_RADIUS = 255
+_FULL_RADIUS = 32768
+
+
+def _is_floating(array):
+    return numpy.issubdtype(array.dtype, numpy.floating)
+
+
+# The functions are sorted in alphabetic order, like the reference.
+
+def average_entropies(data, bin_widths):
+    """Quantizes the data and computes the mean entropy of the quantized data (tools.py:25-59)."""
+    quantized_data = quantize_per_map(data, bin_widths)
+    nb_maps = data.shape[3]
+    entropies = _map_entropies(numpy.moveaxis(quantized_data, 3, 0).reshape(1, nb_maps, -1), bin_widths, planar=True)
+    cumulated_entropy = 0.
+    for i in range(nb_maps):
+        cumulated_entropy += entropies[0, i]
+    return cumulated_entropy/nb_maps
+
+
+def cast_bt601(array_float):
+    """Clips to [16., 235.], rounds half to even and casts to `numpy.uint8` (tools.py:61-93)."""
+    if not _is_floating(array_float):
+        raise TypeError('`array_float.dtype` is not smaller than `numpy.float` in type hierarchy.')
+    if array_float.size == 0:
+        return numpy.zeros(array_float.shape, dtype=numpy.uint8)
+    return bk.to_host(dev.cast_bt601(bk.to_device(array_float, numpy.float32))).reshape(array_float.shape)
+
+
+def cast_float_to_int16(array_float):
+    """Rounds half to even and casts to `numpy.int16`; AssertionError outside [-32767, 32767] (tools.py:95-133)."""
+    if not _is_floating(array_float):
+        raise TypeError('`array_float.dtype` is not smaller than `numpy.float` in type hierarchy.')
+    if array_float.size == 0:
+        return numpy.zeros(array_float.shape, dtype=numpy.int16)
+    (out, range_error) = dev.cast_int16(bk.to_device(array_float, numpy.float32))
+    if int(range_error.item()) != 0:
+        raise AssertionError('The rounded array elements cannot be represented as 16-bit signed integers.')
+    return bk.to_host(out).reshape(array_float.shape)
+
+
+def count_nb_deads(array_4d):
+    """Number of dead feature maps (sum of absolute values exactly 0) per first-axis component (tools.py:294-320)."""
+    if array_4d.ndim != 4:
+        raise ValueError('`array_4d.ndim` is not equal to 4.')
+    flags = bk.to_host(dev.nonzero_flags(bk.to_device(array_4d, numpy.float32)))
+    return numpy.sum(flags == 0, axis=1)
+
+
+def _symbol_histograms(symbols_planar_device):
+    """Exact per-map histograms of int16 symbols: (hist int64 [n_maps, 2R+1], R)."""
+    radius = _FIRST_RADIUS
+    (hist, overflow) = dev.symbol_histograms(symbols_planar_device, radius)
+    if int(overflow.sum().item()) != 0:
+        radius = _FULL_RADIUS
+        (hist, overflow) = dev.symbol_histograms(symbols_planar_device, radius)
+    return (bk.to_host(hist).astype(numpy.int64), radius)
+
+
+def _quantized_to_symbols(quantized_planar_or_nhwc, bin_widths_float32, check_quantized=True):
+    """float quantised samples [N, hw, C] -> int16 symbols [N, C, hw] on the device (+ the tools.py:372-375 check)."""
+    res = dev.quantize_maps(bk.to_device(quantized_planar_or_nhwc, numpy.float32), bk.to_device(bin_widths_float32, numpy.float32),
+                            None, want_symbols=True)
+    checks = res['checks'].cpu().tolist()
+    if check_quantized and checks[1] != 0:
+        raise AssertionError('\nArrays are not almost equal to 10 decimals\nThe quantization was omitted.')
+    if checks[0] != 0:
+        raise ValueError('A symbol does not fit in 16 bits: outside the domain of this build (lossless/compression.py:142 '
+                         'casts the symbols to int16).')
+    return res['symbols']
+
+
+def count_symbols(quantized_samples, bin_width):
+    """Number of occurrences of each symbol from the smallest to the largest quantized sample (tools.py:322-388)."""
+    if bin_width <= 0.:
+        raise ValueError('The quantization bin width is not strictly positive.')
+    if numpy.size(quantized_samples) == 0:   # numpy.amin of the reference (tools.py:376)
+        raise ValueError('zero-size array to reduction operation minimum which has no identity')
+    flat = numpy.ascontiguousarray(quantized_samples, dtype=numpy.float32).reshape(1, -1, 1)
+    symbols = _quantized_to_symbols(flat, numpy.array([bin_width], dtype=numpy.float32))
+    (hist, radius) = _symbol_histograms(symbols)
+    occupied = numpy.flatnonzero(hist[0])
+    return hist[0, occupied[0]:occupied[-1] + 1]
+
+
+def _entropy_from_hist(hist):
+    """tools.py:523-537 verbatim, from the integer histogram."""
+    hist_non_zero = numpy.extract(hist != 0, hist)
+    frequency = hist_non_zero.astype(numpy.float64)/numpy.sum(hist_non_zero)
+    disc_entropy = -numpy.sum(frequency*numpy.log2(frequency))
+    if disc_entropy < 0.:
+        raise ValueError('The entropy is not positive.')
+    if disc_entropy > numpy.log2(hist_non_zero.size):
+        raise ValueError('The entropy is not smaller than its upper bound.')
+    return disc_entropy
+
+
+def discrete_entropy(quantized_samples, bin_width):
+    """Entropy of the quantized samples (tools.py:486-537)."""
+    return _entropy_from_hist(count_symbols(quantized_samples, bin_width))
+
+
+def _map_entropies(quantized, bin_widths, planar=False):
+    """Entropy of every map: `quantized` is [N, hw, C] (or [N, C, hw] if planar) -> float64 [N, C]."""
+    if planar:
+        quantized = numpy.ascontiguousarray(numpy.swapaxes(quantized, 1, 2))
+    if numpy.any(bin_widths <= 0.):
+        raise ValueError('The quantization bin width is not strictly positive.')
+    symbols = _quantized_to_symbols(quantized, bin_widths)
+    (hist, radius) = _symbol_histograms(symbols)
+    (n, c) = (quantized.shape[0], quantized.shape[2])
+    entropies = numpy.zeros((n, c))
+    for i in range(n*c):
+        row = hist[i]
+        occupied = numpy.flatnonzero(row)
+        entropies[i//c, i % c] = _entropy_from_hist(row[occupied[0]:occupied[-1] + 1])
+    return entropies
+
+
+def float_to_str(float_in):
+    """Converts the float into a string, "." -> "dot", "-" -> "minus" (tools.py:570-593)."""
+    if float_in.is_integer():
+        str_in = str(int(float_in))
+    else:
+        str_in = str(float_in).replace('.', 'dot')
+    return str_in.replace('-', 'minus')
+
+
+def psnr_2d(reference_uint8, reconstruction_uint8):
+    """PSNR between the luminance image and its reconstruction (tools.py:831-881)."""
+    if reference_uint8.dtype != numpy.uint8:
+        raise TypeError('`reference_uint8.dtype` is not equal to `numpy.uint8`.')
+    if reconstruction_uint8.dtype != numpy.uint8:
+        raise TypeError('`reconstruction_uint8.dtype` is not equal to `numpy.uint8`.')
+    if reference_uint8.ndim != 2:
+        raise ValueError('`reference_uint8.ndim` is not equal to 2.')
+    if reference_uint8.shape != reconstruction_uint8.shape:
+        raise ValueError('`reference_uint8.shape` is not equal to `reconstruction_uint8.shape`.')
+    sse = dev.sse_u8(bk.to_device(reference_uint8[None]), bk.to_device(reconstruction_uint8[None]))
+    return psnr_from_sse(int(sse.item()), reference_uint8.size)
+
+
+def psnr_from_sse(sse, nb_pixels):
+    """tools.py:875-881 from the exact integer sum of squared errors (a sum of integers < 2^53 is exact in float64,
+    so `numpy.mean((a - b)**2)` == sse/nb_pixels bit for bit)."""
+    mse = numpy.float64(sse)/nb_pixels
+    if mse == 0.:
+        raise ValueError('The mean squared error between the luminance image and its reconstruction is 0.')
+    return 10.*numpy.log10((255.**2)/mse)
+
+
+def quantize_per_map(data, bin_widths):
+    """Uniform scalar quantization of each map with its own bin width (tools.py:883-929)."""
+    if bin_widths.ndim != 1:
+        raise ValueError('`bin_widths.ndim` is not equal to 1.')
+    (nb_examples, height_map, width_map, nb_maps) = data.shape
+    if bin_widths.size != nb_maps:
+        raise ValueError('`bin_widths.size` is not equal to `data.shape[3]`.')
+    if numpy.any(bin_widths <= 0.):
+        raise ValueError('A quantization bin width is not strictly positive.')
+    if data.size == 0:
+        return numpy.zeros(data.shape, dtype=numpy.float32)
+    res = dev.quantize_maps(bk.to_device(data, numpy.float32), bk.to_device(bin_widths, numpy.float32), None, want_cq=True)
+    return bk.to_host(res['cq'])
+
+
+def rate_3d(quantized_latent_float32, bin_widths, h_in, w_in):
+    """Rate (bits per pixel) of the quantized latent variables of one luminance image (tools.py:931-989)."""
+    if bin_widths.ndim != 1:
+        raise ValueError('`bin_widths.ndim` is not equal to 1.')
+    (height_map, width_map, nb_maps) = quantized_latent_float32.shape
+    if bin_widths.size != nb_maps:
+        raise ValueError('`bin_widths.size` is not equal to `quantized_latent_float32.shape[2]`.')
+    entropies = _map_entropies(numpy.ascontiguousarray(quantized_latent_float32, dtype=numpy.float32).reshape(1, -1, nb_maps),
+                               numpy.asarray(bin_widths, dtype=numpy.float32))
+    return rate_from_entropies(entropies[0], height_map, width_map, h_in, w_in)
+
+
+def rate_from_entropies(entropies, height_map, width_map, h_in, w_in):
+    """tools.py:977-989 given the per-map entropies (same accumulation order)."""
+    cumulated_rate = 0.
+    for i in range(entropies.size):
+        cumulated_rate += entropies[i]*height_map*width_map
+    return cumulated_rate/(h_in*w_in)
+
+
+def subdivide_set(nb_examples, batch_size):
+    """Number of mini-batches in the set of examples (tools.py:1108-1132)."""
+    if nb_examples % batch_size != 0:
+        raise ValueError('`nb_examples` is not divisible by `batch_size`.')
+    return nb_examples//batch_size

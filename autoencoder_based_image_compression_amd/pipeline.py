@@ -1,0 +1,87 @@
+"""Device-resident analysis / synthesis transforms: the arithmetic behind `sess.run(entropy_ae.node_y)` and
+`sess.run(isolated_decoder.node_reconstruction)` of the reference (kodak_tensorflow/eae/batching.py:96-99, 49-52).
+
+`DeviceEncoder` / `DeviceDecoder` keep the variables of one trained model in HBM (7 MB) and chain the kernels of
+include/eae_hip.h on torch's current stream; activations never leave the device. Both are the hot path of
+`bench.py` and the engine under the reference-shaped classes in `kodak/eae/graph/`.
+"""
+import numpy
+import torch
+
+from . import device as dev
+from .kodak.eae.graph import constants as csts
+from .kodak.eae.graph import variables as var
+
+
+def _to_device(array, device):
+    return torch.from_numpy(numpy.ascontiguousarray(array, dtype=numpy.float32)).to(device)
+
+
+class DeviceEncoder(object):
+    """components.encoder (kodak_tensorflow/eae/graph/components.py:86-142) on the GPU."""
+
+    def __init__(self, variables, are_bin_widths_learned, device='cuda'):
+        names = var.ENCODER_NAMES + (() if are_bin_widths_learned else var.ENCODER_NAMES_FIXED_BW)
+        var.check_variables(variables, names)
+        self.are_bin_widths_learned = are_bin_widths_learned
+        self.device = torch.device(device)
+        self.v = {name: _to_device(variables[name], self.device) for name in names}
+
+    def __call__(self, luminances_uint8):
+        """uint8 [N,H,W] or [N,H,W,1] (device) -> float32 latents [N,H/16,W/16,128] (device)."""
+        if luminances_uint8.dtype != torch.uint8:
+            raise TypeError('`luminances_uint8.dtype` is not equal to `torch.uint8`.')
+        (h_in, w_in) = (luminances_uint8.shape[1], luminances_uint8.shape[2])
+        if h_in % csts.STRIDE_PROD != 0:
+            raise ValueError('The height of the input images is not divisible by the product of the three strides.')
+        if w_in % csts.STRIDE_PROD != 0:
+            raise ValueError('The width of the input images is not divisible by the product of the three strides.')
+        v = self.v
+        gdn_1 = dev.conv9x9s4_u8(luminances_uint8, v['encoder/weights_1'], v['encoder/biases_1'],
+                                 v['encoder/gamma_1'], v['encoder/beta_1'])
+        gdn_2 = dev.conv5x5s2(gdn_1, v['encoder/weights_2'], v['encoder/biases_2'], dev.NORM_GDN,
+                              v['encoder/gamma_2'], v['encoder/beta_2'])
+        if self.are_bin_widths_learned:
+            return dev.conv5x5s2(gdn_2, v['encoder/weights_3'], v['encoder/biases_3'], dev.NORM_NONE)
+        return dev.conv5x5s2(gdn_2, v['encoder/weights_3'], v['encoder/biases_3'], dev.NORM_GDN,
+                             v['encoder/gamma_3'], v['encoder/beta_3'])
+
+
+class DeviceDecoder(object):
+    """components.decoder (components.py:11-84) + tls.cast_bt601 (batching.py:53) on the GPU."""
+
+    def __init__(self, variables, are_bin_widths_learned, device='cuda'):
+        names = var.DECODER_NAMES + (() if are_bin_widths_learned else var.DECODER_NAMES_FIXED_BW)
+        var.check_variables(variables, names)
+        self.are_bin_widths_learned = are_bin_widths_learned
+        self.device = torch.device(device)
+        self.v = {name: _to_device(variables[name], self.device) for name in names}
+        # kernel-side weight layouts, packed once on the device
+        self.w4 = dev.pack_tconv_weights(self.v['decoder/weights_4'])
+        self.w5 = dev.pack_tconv_weights(self.v['decoder/weights_5'])
+        self.w6 = dev.pack_tconv9x9s4_weights(self.v['decoder/weights_6'])
+
+    def __call__(self, quantized_y, want_float=False, want_uint8=True, reference_uint8=None, sse=None):
+        """float32 [N,h,w,128] (device) -> (float32 [N,16h,16w] or None, uint8 [N,16h,16w] or None, sse or None)."""
+        v = self.v
+        t = quantized_y
+        if not self.are_bin_widths_learned:
+            t = dev.gdn(t, v['decoder/gamma_4'], v['decoder/beta_4'], inverse=True)
+        t = dev.tconv5x5s2(t, self.w4, v['decoder/biases_4'], dev.NORM_IGDN, v['decoder/gamma_5'], v['decoder/beta_5'])
+        t = dev.tconv5x5s2(t, self.w5, v['decoder/biases_5'], dev.NORM_IGDN, v['decoder/gamma_6'], v['decoder/beta_6'])
+        return dev.tconv9x9s4_luma(t, self.w6, want_f32=want_float, want_u8=want_uint8, ref_u8=reference_uint8, sse=sse)
+
+
+# Algorithmic work per INPUT pixel of each launch, fixed-bin-width model.
+# MACs: conv1 648 + GDN1 1024; conv2 6400 + GDN2 256; conv3 1600 + GDN3 64; IGDN4 64; tconv1 1600 + IGDN5 256;
+# tconv2 6400 + IGDN6 1024; tconv3 648.
+FLOP_PER_PIXEL = {
+    'conv1_gdn1': 2*(648 + 1024),
+    'conv2_gdn2': 2*(6400 + 256),
+    'conv3_gdn3': 2*(1600 + 64),
+    'igdn4': 2*64,
+    'tconv1_igdn5': 2*(1600 + 256),
+    'tconv2_igdn6': 2*(6400 + 1024),
+    'tconv3': 2*648,
+}
+FLOP_PER_PIXEL_TOTAL = sum(FLOP_PER_PIXEL.values())   # 39,968

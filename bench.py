@@ -1,0 +1,321 @@
+#!/usr/bin/env python
+"""bench.py -- Mpixels/s of the compression inference path (encode -> quantise -> entropy-code -> decode) on MI355X.
+
+One STEP = one pass of the whole hot path over one batch of Kodak-sized (512x768) synthetic luminance images that
+are already resident in HBM:
+    conv1+GDN1 -> conv2+GDN2 -> conv3+GDN3 -> centre/quantise/int16 symbols (+dead-map flags, exception-map histogram)
+    -> ONE device->host copy of the symbols -> host coder (UEG0 + binary arithmetic coder, encode + decode + verify,
+       threaded over maps, overlapped with the GPU decode)
+    -> IGDN4 -> tconv1+IGDN5 -> tconv2+IGDN6 -> tconv3 + BT.601 cast + squared error vs the input (PSNR).
+Nothing is skipped or cached between steps. Multi-GPU: one process per GPU, each rank codes its own batch (weak
+scaling, no data-path collective); one RCCL all-reduce sums the rate / PSNR statistics at the end of the timed region.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md section 6 for the fields).
+"""
+import argparse
+import json
+import os
+import queue
+import sys
+import threading
+import time
+
+import numpy
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from autoencoder_based_image_compression_amd import device as dev            # noqa: E402
+from autoencoder_based_image_compression_amd import pipeline                 # noqa: E402
+from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var   # noqa: E402
+from autoencoder_based_image_compression_amd.kodak.lossless import compression as lossless_compression   # noqa: E402
+from autoencoder_based_image_compression_amd.kodak.lossless import stats as lossless_stats   # noqa: E402
+from autoencoder_based_image_compression_amd.kodak.tools import tools as tls   # noqa: E402
+
+H_IN, W_IN = 512, 768          # Kodak luminance (datasets/kodak/kodak.py:10-83: uint8 (24, 512, 768))
+IDX_MAP_EXCEPTION = 67         # lossless/results/1_10000/training_index_10/idx_map_exception.pkl
+TRUNCATED_UNARY_LENGTH = 10    # collecting_stats_eae_extra.py:44
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+
+
+def synthetic_images(seed, n, h, w):
+    """RandomState(seed).randint(16, 236) low-pass filtered (3x box blur), uint8."""
+    rng = numpy.random.RandomState(seed)
+    x = rng.randint(16, 236, size=(n, h, w)).astype(numpy.float32)
+    for _ in range(3):
+        x = (x + numpy.roll(x, 1, 1) + numpy.roll(x, -1, 1) + numpy.roll(x, 1, 2) + numpy.roll(x, -1, 2))/numpy.float32(5.)
+    return numpy.round(x).astype(numpy.uint8)
+
+
+def synthetic_model(bin_width=1.):
+    """Random-init weights of the fixed-bin-width architecture (no trained checkpoint exists in the reference mount)."""
+    v = var.random_variables(bin_width, False, seed=0, bias_std=0.01)
+    v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)   # leave the clip floor
+    return v
+
+
+class CoderWorker(threading.Thread):
+    """Host entropy coding off the launch thread: waits for a batch's D2H copy, codes every map (encode + decode +
+    verify, like compress_lossless), and leaves the bit counts. ctypes releases the GIL inside the coder."""
+
+    def __init__(self, probabilities, nb_threads):
+        super(CoderWorker, self).__init__(daemon=True)
+        self.probabilities = probabilities
+        self.nb_threads = nb_threads
+        self.jobs = queue.Queue()
+        self.results = []
+        self.error = None
+        self.busy_s = 0.
+
+    def run(self):
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            (event, symbols_host, slot_free) = job
+            try:
+                event.synchronize()
+                t0 = time.perf_counter()
+                sym = symbols_host.numpy()
+                (rec, nb_bits) = lossless_compression.code_planar_symbols(sym, self.probabilities, IDX_MAP_EXCEPTION,
+                                                                         nb_threads=self.nb_threads, roundtrip=True)
+                if not numpy.array_equal(rec, sym):
+                    raise AssertionError('The lossless compression has altered the centered quantized data.')
+                self.busy_s += time.perf_counter() - t0
+                self.results.append(nb_bits)
+            except Exception as exc:   # surfaced by the main thread
+                self.error = exc
+            finally:
+                slot_free.set()
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--gpus', type=int, default=1)
+    parser.add_argument('--steps', type=int, default=10)
+    parser.add_argument('--warmup', type=int, default=2)
+    parser.add_argument('--batch', type=int, default=24, help='Kodak-sized images per GPU per step')
+    parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--coder-threads', type=int, default=0)
+    args = parser.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the product path.')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world)
+    device = torch.device('cuda', local_rank)
+    cores = os.cpu_count() or 1
+    coder_threads = args.coder_threads if args.coder_threads > 0 else max(1, cores//max(world, 1) - 2)
+
+    # ---- model, inputs, coder tables (outside the timed region) ---------------------------------------------------
+    variables = synthetic_model(1.)
+    encoder = pipeline.DeviceEncoder(variables, False, device)
+    decoder = pipeline.DeviceDecoder(variables, False, device)
+    bin_widths = torch.from_numpy(variables[var.BIN_WIDTHS_NAME]).to(device)
+    images = torch.from_numpy(synthetic_images(1000 + rank, args.batch, H_IN, W_IN)).to(device)
+    (h_map, w_map) = (H_IN//16, W_IN//16)
+    map_size = h_map*w_map
+    # statistics that feed the coder, from this build's own a26/a27 path on the first batch (lossless/stats.py:306, :13-68)
+    y0 = encoder(images)
+    map_mean_host = y0.mean(dim=(0, 1, 2)).cpu().numpy().astype(numpy.float32)
+    probabilities = lossless_stats.compute_binary_probabilities(y0.cpu().numpy(), variables[var.BIN_WIDTHS_NAME], map_mean_host,
+                                                                TRUNCATED_UNARY_LENGTH)
+    map_mean = torch.from_numpy(map_mean_host).to(device)
+    del y0
+    nb_slots = 3
+    pinned = [torch.empty((args.batch, 128, map_size), dtype=torch.int16).pin_memory() for _ in range(nb_slots)]
+    slot_free = [threading.Event() for _ in range(nb_slots)]
+    for e in slot_free:
+        e.set()
+    worker = CoderWorker(probabilities, coder_threads)
+    worker.start()
+    sse_total = torch.zeros(args.batch, dtype=torch.int64, device=device)
+    dead_total = torch.zeros(1, dtype=torch.int64, device=device)
+    exc_hists = []
+    gemm_events = []            # (start, stop, launch name) around every conv_gemm launch of the timed region
+
+    def timed_launch(name, fn, record):
+        if not record:
+            return fn()
+        (a, b) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        a.record()
+        out = fn()
+        b.record()
+        gemm_events.append((a, b, name))
+        return out
+
+    def step(index, record):
+        v = encoder.v
+        gdn_1 = dev.conv9x9s4_u8(images, v['encoder/weights_1'], v['encoder/biases_1'], v['encoder/gamma_1'], v['encoder/beta_1'])
+        gdn_2 = timed_launch('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, v['encoder/weights_2'], v['encoder/biases_2'], dev.NORM_GDN,
+                                                                 v['encoder/gamma_2'], v['encoder/beta_2']), record)
+        y = timed_launch('conv3_gdn3', lambda: dev.conv5x5s2(gdn_2, v['encoder/weights_3'], v['encoder/biases_3'], dev.NORM_GDN,
+                                                             v['encoder/gamma_3'], v['encoder/beta_3']), record)
+        q = dev.quantize_maps(y, bin_widths, map_mean, want_shifted=True, want_symbols=True, want_flags=True)
+        slot = index % nb_slots
+        slot_free[slot].wait()
+        slot_free[slot].clear()
+        pinned[slot].copy_(q['symbols'], non_blocking=True)          # the single device -> host copy
+        copied = torch.cuda.Event()
+        copied.record()
+        worker.jobs.put((copied, pinned[slot], slot_free[slot]))
+        # exception map: exact histogram on the device, entropy on the host after the timed region's sync
+        exc_hists.append(dev.symbol_histograms(q['symbols'][:, IDX_MAP_EXCEPTION:IDX_MAP_EXCEPTION + 1].contiguous(), 255))
+        dead_total.add_((q['nonzero_flags'] == 0).sum())
+        d = decoder.v
+        t = dev.gdn(q['shifted'], d['decoder/gamma_4'], d['decoder/beta_4'], inverse=True)
+        t = timed_launch('tconv1_igdn5', lambda: dev.tconv5x5s2(t, decoder.w4, d['decoder/biases_4'], dev.NORM_IGDN,
+                                                                d['decoder/gamma_5'], d['decoder/beta_5']), record)
+        t = timed_launch('tconv2_igdn6', lambda: dev.tconv5x5s2(t, decoder.w5, d['decoder/biases_5'], dev.NORM_IGDN,
+                                                                d['decoder/gamma_6'], d['decoder/beta_6']), record)
+        dev.tconv9x9s4_luma(t, decoder.w6, want_f32=False, want_u8=True, ref_u8=images, sse=sse_total)
+
+    def drain():
+        for e in slot_free:
+            e.wait()
+        torch.cuda.synchronize()
+        if worker.error is not None:
+            raise worker.error
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i, False)
+    drain()
+    worker.results.clear()
+    del exc_hists[:]
+    sse_total.zero_()
+    dead_total.zero_()
+    worker.busy_s = 0.
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    drain()
+    # exception map (compression.py:68-75): ceil(h*w*entropy) from the exact device histogram
+    exception_bits = 0
+    for (hist, overflow) in exc_hists:
+        if int(overflow.sum().item()) != 0:
+            raise RuntimeError('exception-map symbols outside the histogram radius')
+        for row in hist.cpu().numpy().astype(numpy.int64):
+            exception_bits += int(lossless_compression.exception_map_nb_bits(row, map_size))
+    # the path's only exchange step: sum the rate / PSNR accumulators over ranks
+    coder_bits = float(sum(int(r.sum()) for r in worker.results)) + float(exception_bits)
+    stats = torch.tensor([coder_bits, float(sse_total.sum().item()), float(dead_total.item()), float(args.steps*args.batch)],
+                         dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    # ---- derived figures (outside the timed region) ------------------------------------------------------------------
+    pixels_per_step = args.batch*H_IN*W_IN
+    total_pixels = pixels_per_step*args.steps*world
+    value = total_pixels/elapsed/1e6
+    nb_images_total = stats[3].item()
+    bpp = stats[0].item()/(nb_images_total*H_IN*W_IN)
+    mean_psnr = float(tls.psnr_from_sse(stats[1].item(), nb_images_total*H_IN*W_IN))   # PSNR of the pooled MSE
+    flops = {'conv2_gdn2': pipeline.FLOP_PER_PIXEL['conv2_gdn2'], 'conv3_gdn3': pipeline.FLOP_PER_PIXEL['conv3_gdn3'],
+             'tconv1_igdn5': pipeline.FLOP_PER_PIXEL['tconv1_igdn5'], 'tconv2_igdn6': pipeline.FLOP_PER_PIXEL['tconv2_igdn6']}
+    per_launch_ms = {}
+    for (a, b, name) in gemm_events:
+        per_launch_ms.setdefault(name, []).append(a.elapsed_time(b))
+    gemm_ms = sum(sum(v) for v in per_launch_ms.values())
+    gemm_launches = sum(len(v) for v in per_launch_ms.values())
+    gemm_flop = sum(flops[name]*pixels_per_step*len(v) for (name, v) in per_launch_ms.items())
+    achieved = gemm_flop/(gemm_ms*1e-3)/1e12 if gemm_ms > 0 else 0.
+    traffic = None
+    traffic_file = os.path.join(ROOT, 'profiles', 'traffic_conv_gemm.json')
+    if os.path.isfile(traffic_file):
+        with open(traffic_file) as f:
+            traffic = json.load(f).get('hbm_bytes_per_launch')
+    line = {
+        'metric': 'Mpixels/s encode+decode (Kodak 768x512 luma), bitstream bit-exact',
+        'value': round(value, 3), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed/args.steps*1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'kodak_512x768_luma_batch{}_per_gpu_bin_width_1.0_lossless_roundtrip'.format(args.batch),
+                   'images_per_gpu_per_step': args.batch, 'height': H_IN, 'width': W_IN, 'bin_width_multiplier': 1.0,
+                   'truncated_unary_length': TRUNCATED_UNARY_LENGTH, 'idx_map_exception': IDX_MAP_EXCEPTION,
+                   'weights': 'random-init fixed-bin-width architecture (trained checkpoints absent from the reference)',
+                   'parallelism': 'image shards, one process per GPU' if world > 1 else 'single GPU',
+                   'coder_threads_per_rank': coder_threads},
+        'images_per_s': round(nb_images_total/elapsed, 2),
+        'rate_bpp': round(bpp, 5), 'psnr_db_pooled': round(mean_psnr, 4), 'dead_maps_per_image': round(stats[2].item()/nb_images_total, 3),
+        'coder_busy_fraction': round(worker.busy_s/elapsed, 3),
+        'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_kernel<128> (conv2+GDN2, conv3+GDN3, tconv1+IGDN5, tconv2+IGDN6)',
+                     'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': round(achieved/PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                     'avg_launch_ms': round(gemm_ms/max(gemm_launches, 1), 4),
+                     'per_launch_ms': {k: round(sum(v)/len(v), 4) for (k, v) in per_launch_ms.items()},
+                     'algorithmic_flop_per_launch': {k: flops[k]*pixels_per_step for k in flops}},
+    }
+    worker.jobs.put(None)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(variables, probabilities, map_mean_host, cores)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(variables, probabilities, map_mean, cores):
+    """The same path on the host cores, on a BOUNDED sample (checker code, timed only here, never shipped):
+    transforms = oracle/transforms_oracle.c (plain-C restatement, OpenMP over all cores);
+    coder = the reference's own C++ coder compiled into oracle/_ref (single thread, as the reference runs it),
+    falling back to the oracle's C restatement when the reference build is absent; numpy quantiser / PSNR."""
+    from oracle import coder as oracle_coder
+    from oracle import transforms as oracle_transforms
+    n_img = 1
+    x = synthetic_images(999, n_img, H_IN, W_IN)
+    bw = variables[var.BIN_WIDTHS_NAME]
+    kind_coder = 'ref' if oracle_coder.available('ref') else 'oracle'
+    lib = oracle_coder.CoderLib(kind_coder)
+    t0 = time.perf_counter()
+    y = oracle_transforms.encoder(x.astype(numpy.float32)[..., None], variables, False)
+    t_enc = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    tiled = numpy.tile(bw.reshape(1, 1, 1, 128), y.shape[:3] + (1,))
+    cq = tiled*numpy.round((y - map_mean)/tiled)
+    sym = numpy.round(cq/tiled).astype(numpy.int16)
+    t_quant = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    bits = 0
+    for j in range(n_img):
+        for c in range(128):
+            if c == IDX_MAP_EXCEPTION:
+                continue
+            (rec, nb) = lib.compress_lossless(numpy.ascontiguousarray(sym[j, :, :, c]).reshape(-1), probabilities[c])
+            bits += nb
+    t_coder = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rec = oracle_transforms.decoder(cq + map_mean, variables, False)[..., 0]
+    rec_u8 = numpy.round(rec.clip(min=16., max=235.)).astype(numpy.uint8)
+    mse = numpy.mean((x.astype(numpy.float64) - rec_u8.astype(numpy.float64))**2)
+    t_dec = time.perf_counter() - t0
+    total = t_enc + t_quant + t_coder + t_dec
+    return {'value': round(n_img*H_IN*W_IN/total/1e6, 4), 'unit': 'Mpixels/s', 'cores': cores, 'kind': 'port',
+            'sample': '{} synthetic 512x768 image(s), encode+quantise+code(enc+dec)+decode+PSNR'.format(n_img),
+            'seconds': {'encoder_oracle_c_openmp': round(t_enc, 3), 'quantiser_numpy': round(t_quant, 3),
+                        'coder_{}_single_thread'.format('reference_cpp' if kind_coder == 'ref' else 'oracle_c'): round(t_coder, 3),
+                        'decoder_oracle_c_openmp_plus_psnr': round(t_dec, 3)},
+            'bits': int(bits), 'mse': round(float(mse), 4)}
+
+
+if __name__ == '__main__':
+    main()

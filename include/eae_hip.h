@@ -95,11 +95,23 @@ int eae_hip_pack_tconv_weights(const float* w_tf, float* w_packed, int taps, int
  *                         compression.py:77 for image i; this is the buffer the single device->host copy moves
  *   nonzero_flags       : uint32 [N][C], set to 1 when some cq of the map is != 0 (so `count_nb_deads`,
  *                         tools.py:318-320, is the number of zero flags); caller zeroes
- *   range_error         : uint32 [1], += number of elements with |round(cq/bw)| >= 32768 (the AssertionError of
- *                         tools.py:130-132); caller zeroes */
+ *   checks              : uint32 [3], caller zeroes; each += a count of offending elements:
+ *       [0] |round(cq/bw)| >= 32768                      -> AssertionError of tools.py:130-132
+ *       [1] |bw*round(x/bw) - x| >= 1.5e-10, x = y - m   -> AssertionError "The quantization was omitted."
+ *                                                           (tools.py:372-375) when y is passed as already quantised
+ *       [2] float(symbol)*bw != x                        -> AssertionError of lossless/compression.py:149-153
+ * c = number of maps (last axis). c == 128 takes the tiled kernel; any other c a generic one (same arithmetic). */
 int eae_hip_quantize_maps(const float* y, const float* map_mean, const float* bin_widths,
                           float* cq_out, float* shifted_out, int16_t* symbols_planar,
-                          uint32_t* nonzero_flags, uint32_t* range_error, int n, int hw, void* stream);
+                          uint32_t* nonzero_flags, uint32_t* checks, int n, int hw, int c, void* stream);
+
+/* tls.count_nb_deads (tools.py:294-320) for an arbitrary stack x [N][hw][C]: nonzero_flags[n][c] = 1 when some
+ * element of map (n, c) is != 0 (caller zeroes); the number of dead maps of image n is the number of zero flags. */
+int eae_hip_nonzero_flags(const float* x, uint32_t* nonzero_flags, int n, int hw, int c, void* stream);
+
+/* tls.cast_float_to_int16 (tools.py:95-133): out = int16(round_half_even(x)); *range_error += number of elements
+ * with |round(x)| >= 32768 (the reference raises AssertionError); caller zeroes. */
+int eae_hip_cast_int16(const float* x, int16_t* out, int64_t count, uint32_t* range_error, void* stream);
 
 /* Per-map symbol histograms (tls.count_symbols, tools.py:376-388, is this histogram restricted to [min, max]; it feeds
  * discrete_entropy :523-537, rate_3d :977-989 and stats.count_binary_decisions, lossless/stats.py:179-195).

@@ -1,0 +1,123 @@
+"""The rate-distortion harness of the reference (kodak_tensorflow/reconstructing_eae_kodak.py) on the mirrored surface.
+
+`fix_gamma` :31-243 and `vary_gamma_fix_bin_widths` :401-556 with the reference's arguments, written against exactly
+the calls the reference makes (`EntropyAutoencoder`, `IsolatedDecoder`, `tf.Session`, `eae.batching.*`, `tls.*`,
+`lossless.compression.rescale_compress_lossless_maps`), so it doubles as the proof that the reference's own script
+drops onto this package. Out of scope here: PNG dumps, plots, JPEG2000 / HEVC baselines and
+Bjontegaard metrics of the reference's `__main__` (SURVEY.md 8(f) "next").
+"""
+import os
+import pickle
+
+import numpy
+
+from . import tf_shim as tf
+from .eae import batching
+from .eae.graph.EntropyAutoencoder import EntropyAutoencoder
+from .eae.graph.IsolatedDecoder import IsolatedDecoder
+from .lossless import compression
+from .tools import tools as tls
+
+
+def fix_gamma(reference_uint8, bin_width_init, multipliers, idx_training, gamma_scaling, batch_size,
+              are_bin_widths_learned, is_lossless, path_to_checking_r=None, list_rotation=None, positions_top_left=None,
+              root='.', return_nb_deads=False):
+    """Rate and PSNR of one trained entropy autoencoder at several multiples of its bin widths (:31-243).
+
+    reference_uint8 : uint8 (nb_images, h_in, w_in). multipliers : float32 (nb_points,).
+    Files are looked up like the reference does, relative to `root`:
+      eae/results/<suffix>/nb_itvs_per_side_<idx>.pkl, eae/results/<suffix>/model_<idx>.ckpt (here: .npz),
+      lossless/results/<suffix>/training_index_<idx>/{map_mean.npy, idx_map_exception.pkl, binary_probabilities_<m>.npy}.
+    Returns (rate, psnr) float64 (nb_points, nb_images) [+ array_nb_deads int32 when `return_nb_deads`].
+    """
+    nb_points = multipliers.size
+    (nb_images, h_in, w_in) = reference_uint8.shape
+    rate = numpy.zeros((nb_points, nb_images))
+    psnr = numpy.zeros((nb_points, nb_images))
+    if are_bin_widths_learned:
+        suffix = 'learning_bw_{0}_{1}'.format(tls.float_to_str(bin_width_init), tls.float_to_str(gamma_scaling))
+    else:
+        suffix = '{0}_{1}'.format(tls.float_to_str(bin_width_init), tls.float_to_str(gamma_scaling))
+    path_to_nb_itvs_per_side_load = os.path.join(root, 'eae/results/{0}/nb_itvs_per_side_{1}.pkl'.format(suffix, idx_training))
+    path_to_restore = os.path.join(root, 'eae/results/{0}/model_{1}.ckpt'.format(suffix, idx_training))
+    path_to_stats = os.path.join(root, 'lossless/results/{0}/training_index_{1}/'.format(suffix, idx_training))
+    path_to_map_mean = os.path.join(path_to_stats, 'map_mean.npy')
+
+    entropy_ae = EntropyAutoencoder(batch_size, h_in, w_in, bin_width_init, gamma_scaling, path_to_nb_itvs_per_side_load,
+                                    are_bin_widths_learned)
+    with tf.Session() as sess:
+        entropy_ae.initialization(sess, path_to_restore)
+        y_float32 = batching.encode_mini_batches(numpy.expand_dims(reference_uint8, axis=3), sess, entropy_ae, batch_size)
+        bin_widths = entropy_ae.get_bin_widths()
+    tf.reset_default_graph()
+
+    isolated_decoder = IsolatedDecoder(batch_size, h_in, w_in, are_bin_widths_learned)
+    array_nb_deads = numpy.zeros((nb_points, nb_images), dtype=numpy.int32)
+    map_mean = numpy.load(path_to_map_mean)
+    tiled_map_mean = numpy.tile(map_mean, (nb_images, y_float32.shape[1], y_float32.shape[2], 1))
+    if is_lossless:
+        with open(os.path.join(path_to_stats, 'idx_map_exception.pkl'), 'rb') as file:
+            idx_map_exception = pickle.load(file)
+    centered_y_float32 = y_float32 - tiled_map_mean
+    with tf.Session() as sess:
+        isolated_decoder.initialization(sess, path_to_restore)
+        for i in range(nb_points):
+            multiplier = multipliers[i].item()
+            str_multiplier = tls.float_to_str(multiplier)
+            bin_widths_test = multiplier*bin_widths
+            centered_quantized_y_float32 = tls.quantize_per_map(centered_y_float32, bin_widths_test)
+            array_nb_deads[i, :] = tls.count_nb_deads(centered_quantized_y_float32)
+            off_centered_quantized_y_float32 = centered_quantized_y_float32 + tiled_map_mean
+            expanded_reconstruction_uint8 = batching.decode_mini_batches(off_centered_quantized_y_float32, sess,
+                                                                         isolated_decoder, batch_size)
+            reconstruction_uint8 = numpy.squeeze(expanded_reconstruction_uint8, axis=3)
+            if is_lossless:
+                path_to_binary_probabilities = os.path.join(path_to_stats, 'binary_probabilities_{}.npy'.format(str_multiplier))
+            for j in range(nb_images):
+                if is_lossless:
+                    nb_bits = compression.rescale_compress_lossless_maps(centered_quantized_y_float32[j, :, :, :],
+                                                                         bin_widths_test,
+                                                                         path_to_binary_probabilities,
+                                                                         idx_map_exception=idx_map_exception)
+                    rate[i, j] = float(nb_bits)/(h_in*w_in)
+                else:
+                    rate[i, j] = tls.rate_3d(centered_quantized_y_float32[j, :, :, :], bin_widths_test, h_in, w_in)
+                psnr[i, j] = tls.psnr_2d(reference_uint8[j, :, :], reconstruction_uint8[j, :, :])
+    tf.reset_default_graph()
+    if return_nb_deads:
+        return (rate, psnr, array_nb_deads)
+    return (rate, psnr)
+
+
+def vary_gamma_fix_bin_widths(reference_uint8, bin_width_init, idxs_training, gammas_scaling, batch_size,
+                              path_to_checking_r=None, list_rotation=None, positions_top_left=None, root='.'):
+    """Rate and PSNR of several entropy autoencoders, each trained with a different scaling coefficient (:401-556)."""
+    nb_points = gammas_scaling.size
+    if idxs_training.size != nb_points:
+        raise ValueError('`gammas_scaling.size` is not equal to `idxs_training.size`.')
+    (nb_images, h_in, w_in) = reference_uint8.shape
+    rate = numpy.zeros((nb_points, nb_images))
+    psnr = numpy.zeros((nb_points, nb_images))
+    for i in range(nb_points):
+        gamma_scaling = gammas_scaling[i].item()
+        idx_training = idxs_training[i].item()
+        suffix = '{0}_{1}'.format(tls.float_to_str(bin_width_init), tls.float_to_str(gamma_scaling))
+        path_to_nb_itvs_per_side_load = os.path.join(root, 'eae/results/{0}/nb_itvs_per_side_{1}.pkl'.format(suffix, idx_training))
+        path_to_restore = os.path.join(root, 'eae/results/{0}/model_{1}.ckpt'.format(suffix, idx_training))
+        entropy_ae = EntropyAutoencoder(batch_size, h_in, w_in, bin_width_init, gamma_scaling, path_to_nb_itvs_per_side_load, False)
+        with tf.Session() as sess:
+            entropy_ae.initialization(sess, path_to_restore)
+            y_float32 = batching.encode_mini_batches(numpy.expand_dims(reference_uint8, axis=3), sess, entropy_ae, batch_size)
+            bin_widths = entropy_ae.get_bin_widths()
+        tf.reset_default_graph()
+        isolated_decoder = IsolatedDecoder(batch_size, h_in, w_in, False)
+        quantized_y_float32 = tls.quantize_per_map(y_float32, bin_widths)
+        with tf.Session() as sess:
+            isolated_decoder.initialization(sess, path_to_restore)
+            expanded_reconstruction_uint8 = batching.decode_mini_batches(quantized_y_float32, sess, isolated_decoder, batch_size)
+        reconstruction_uint8 = numpy.squeeze(expanded_reconstruction_uint8, axis=3)
+        tf.reset_default_graph()
+        for j in range(nb_images):
+            rate[i, j] = tls.rate_3d(quantized_y_float32[j, :, :, :], bin_widths, h_in, w_in)
+            psnr[i, j] = tls.psnr_2d(reference_uint8[j, :, :], reconstruction_uint8[j, :, :])
+    return (rate, psnr)

@@ -1,0 +1,63 @@
+"""The two C-ABI libraries load WITHOUT a GPU and export every symbol the headers declare (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from autoencoder_based_image_compression_amd import _native
+from autoencoder_based_image_compression_amd import _native_hip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    text = open(os.path.join(ROOT, 'include', header)).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(eae_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_coder_library_exports_every_declared_symbol():
+    names = declared('eae_coder.h')
+    assert len(names) >= 30
+    lib = ctypes.CDLL(os.path.join(_native.LIB_DIR, 'libeae_coder.so'))
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(_native.CODER_SYMBOLS) == names   # the Python prototypes cover the header exactly
+    assert b'bit-exact' in _native.coder().eae_coder_version()
+
+
+def test_hip_library_exports_every_declared_symbol():
+    names = declared('eae_hip.h')
+    assert len(names) >= 14
+    lib = ctypes.CDLL(os.path.join(_native.LIB_DIR, 'libeae_hip.so'))
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(_native_hip.HIP_SYMBOLS) == names
+    assert b'gfx950' in _native.hip().eae_hip_version()
+
+
+def test_hip_library_contains_gfx950_code_objects():
+    blob = open(os.path.join(_native.LIB_DIR, 'libeae_hip.so'), 'rb').read()
+    assert b'gfx950' in blob
+    assert b'conv_gemm_kernel' in blob and b'v_mfma' not in blob[:0]   # kernels are embedded (names in the fat binary)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_native, 'LIB_DIR', str(tmp_path))
+    monkeypatch.setattr(_native, '_hip', None)
+    monkeypatch.setattr(_native, '_coder', None)
+    with pytest.raises(_native.NativeLibraryMissing):
+        _native.hip()
+    with pytest.raises(ImportError):
+        _native.coder()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'autoencoder_based_image_compression_amd')
+    for (dirpath, _, files) in os.walk(pkg):
+        for name in files:
+            if name.endswith(('.py', '.cpp', '.hip', '.h')):
+                text = open(os.path.join(dirpath, name)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), os.path.join(dirpath, name)
+                assert 'liboracle' not in text and '_ref/' not in text, os.path.join(dirpath, name)

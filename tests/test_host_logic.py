@@ -1,0 +1,177 @@
+"""Host-side logic of the reference-shaped surface that needs no GPU: argument validation, naming helpers, the float64
+tails (entropy, PSNR) fed with exact integer counts, the TF shim, sharding arithmetic. Expected values come from the
+reference's own Python (tests/golden/tools_golden.npz, oracle/gen_golden.py)."""
+import os
+
+import numpy
+import pytest
+
+from autoencoder_based_image_compression_amd import sharding
+from autoencoder_based_image_compression_amd.kodak import tf_shim
+from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+from autoencoder_based_image_compression_amd.kodak.eae.graph.EntropyAutoencoder import EntropyAutoencoder
+from autoencoder_based_image_compression_amd.kodak.eae.graph.IsolatedDecoder import IsolatedDecoder
+from autoencoder_based_image_compression_amd.kodak.lossless import compression
+from autoencoder_based_image_compression_amd.kodak.lossless import stats
+from autoencoder_based_image_compression_amd.kodak.tools import tools as tls
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tools_golden.npz')
+
+
+@pytest.fixture(scope='module')
+def gold():
+    with numpy.load(GOLD) as data:
+        return {k: data[k] for k in data.files}
+
+
+def test_float_to_str(gold):
+    got = [tls.float_to_str(v) for v in (1., 0.5, 1.25, -2., 10000., -0.75)]
+    assert got == list(gold['float_to_str']) == ['1', '0dot5', '1dot25', 'minus2', '10000', 'minus0dot75']
+
+
+def test_subdivide_set():
+    assert tls.subdivide_set(24, 4) == 6
+    with pytest.raises(ValueError):
+        tls.subdivide_set(25, 4)
+
+
+def test_entropy_tail_matches_reference(gold):
+    """tools.py:523-537 from integer histograms: the reference example -5*0.1*log2(0.1) - 0.2*log2(0.2) - 0.3*log2(0.3)."""
+    hist = numpy.array([3, 2, 1, 1, 1, 1, 1], dtype=numpy.int64)
+    expected = -5*0.1*numpy.log2(0.1) - 0.2*numpy.log2(0.2) - 0.3*numpy.log2(0.3)
+    assert tls._entropy_from_hist(hist) == gold['ent_out']
+    assert abs(tls._entropy_from_hist(hist) - expected) < 1e-15
+    assert tls._entropy_from_hist(gold['lat_count_symbols_3']) == gold['lat_entropy'][3]
+
+
+def test_psnr_tail_matches_reference(gold):
+    """tools.py:873-881: psnr_2d(12s, 15s) = 38.5883785143 (test_tools.py:494-509)."""
+    assert tls.psnr_from_sse(9*24, 24) == gold['psnr_known']
+    assert round(float(tls.psnr_from_sse(9*24, 24)), 10) == 38.5883785143
+    sse = int(((gold['psnr_a'].astype(numpy.int64) - gold['psnr_b'].astype(numpy.int64))**2).sum())
+    assert tls.psnr_from_sse(sse, gold['psnr_a'].size) == gold['psnr_ab']
+    with pytest.raises(ValueError):
+        tls.psnr_from_sse(0, 24)
+
+
+def test_rate_tail_matches_reference(gold):
+    entropies = gold['lat_entropy']
+    rate = tls.rate_from_entropies(entropies, 8, 12, 128, 192)
+    assert rate == gold['lat_rate'][0]
+
+
+def test_argument_validation_without_gpu():
+    data = numpy.zeros((1, 2, 2, 4), dtype=numpy.float32)
+    with pytest.raises(ValueError):
+        tls.quantize_per_map(data, numpy.ones((2, 2), dtype=numpy.float32))
+    with pytest.raises(ValueError):
+        tls.quantize_per_map(data, numpy.ones(3, dtype=numpy.float32))
+    with pytest.raises(ValueError):
+        tls.quantize_per_map(data, numpy.array([1., 0., 1., 1.], dtype=numpy.float32))
+    with pytest.raises(ValueError):
+        tls.quantize_per_map(data[0], numpy.ones(4, dtype=numpy.float32))   # ndim != 4 -> unpacking error
+    with pytest.raises(TypeError):
+        tls.cast_bt601(numpy.zeros(3, dtype=numpy.int32))
+    with pytest.raises(TypeError):
+        tls.cast_float_to_int16(numpy.zeros(3, dtype=numpy.uint8))
+    with pytest.raises(ValueError):
+        tls.count_nb_deads(numpy.zeros((2, 2, 2)))
+    with pytest.raises(ValueError):
+        tls.count_symbols(numpy.zeros(3, dtype=numpy.float32), 0.)
+    with pytest.raises(ValueError):
+        tls.rate_3d(numpy.zeros((2, 2, 4), dtype=numpy.float32), numpy.ones((1, 4), dtype=numpy.float32), 32, 32)
+    with pytest.raises(ValueError):
+        tls.rate_3d(numpy.zeros((2, 2, 4), dtype=numpy.float32), numpy.ones(5, dtype=numpy.float32), 32, 32)
+    a = numpy.zeros((4, 4), dtype=numpy.uint8)
+    with pytest.raises(TypeError):
+        tls.psnr_2d(a.astype(numpy.float32), a)
+    with pytest.raises(TypeError):
+        tls.psnr_2d(a, a.astype(numpy.int16))
+    with pytest.raises(ValueError):
+        tls.psnr_2d(a[None], a[None])
+    with pytest.raises(ValueError):
+        tls.psnr_2d(a, a[:2])
+    with pytest.raises(ValueError):
+        stats.count_binary_decisions(numpy.array([-1.], dtype=numpy.float32), 1., 4)
+    with pytest.raises(ValueError):
+        compression.rescale_compress_lossless_maps(numpy.zeros((2, 2, 3), dtype=numpy.float32), numpy.ones((1, 3), dtype=numpy.float32), 'x.npy')
+    with pytest.raises(ValueError):
+        compression.rescale_compress_lossless_maps(numpy.zeros((2, 2, 3), dtype=numpy.float32), numpy.ones(4, dtype=numpy.float32), 'x.npy')
+    with pytest.raises(TypeError):
+        compression.compress_lossless_maps(numpy.zeros((2, 2, 3), dtype=numpy.int32), 'x.npy')
+
+
+def test_graph_constructors_check_shapes_like_the_reference():
+    """EntropyAutoencoder.py:77-80."""
+    with pytest.raises(ValueError) as info:
+        EntropyAutoencoder(4, 500, 768, 1., 10000., '', False)
+    assert 'height' in str(info.value)
+    with pytest.raises(ValueError) as info:
+        EntropyAutoencoder(4, 512, 770, 1., 10000., '', False)
+    assert 'width' in str(info.value)
+    ae = EntropyAutoencoder(4, 512, 768, 1., 10000., '', False)
+    assert ae.node_visible_units.shape == (4, 512, 768, 1)
+    dec = IsolatedDecoder(4, 512, 768, True)
+    assert dec.node_quantized_y.shape == (4, 32, 48, 128)
+    with pytest.raises(RuntimeError):
+        ae.get_bin_widths()
+
+
+def test_session_shim():
+    ph = tf_shim.Placeholder((2, 3), 'x')
+    node = tf_shim.Node(lambda v: v*2, ph, 'twice')
+    with tf_shim.Session() as sess:
+        out = sess.run(node, feed_dict={ph: numpy.ones((2, 3))})
+        assert numpy.array_equal(out, 2*numpy.ones((2, 3)))
+        with pytest.raises(ValueError):
+            sess.run(node, feed_dict={ph: numpy.ones((3, 3))})
+        with pytest.raises(ValueError):
+            sess.run(node)
+    tf_shim.reset_default_graph()
+
+
+def test_random_variables_follow_the_reference_initialiser(tmp_path):
+    """EntropyAutoencoder.py:130-224, tfutils.py:445-478: shapes, symmetric gamma in [2e-5, 0.01], beta = 1, bw."""
+    v = var.random_variables(0.5, False, seed=3)
+    assert set(v) == set(var.ENCODER_NAMES + var.ENCODER_NAMES_FIXED_BW + var.DECODER_NAMES + var.DECODER_NAMES_FIXED_BW + (var.BIN_WIDTHS_NAME,))
+    for (name, array) in v.items():
+        assert array.dtype == numpy.float32 and tuple(array.shape) == var.SHAPES[name]
+    g = v['encoder/gamma_2']
+    assert numpy.array_equal(g, g.T) and g.min() >= 2e-5 and g.max() <= 0.01
+    assert numpy.all(v['decoder/beta_5'] == 1.) and numpy.all(v['encoder/biases_1'] == 0.)
+    assert numpy.all(v[var.BIN_WIDTHS_NAME] == numpy.float32(0.5))
+    assert abs(float(v['encoder/weights_3'].std()) - 0.05) < 0.002 and abs(float(v['decoder/weights_6'].std()) - 0.01) < 0.001
+    learned = var.random_variables(0.5, True, seed=3)
+    assert 'encoder/gamma_3' not in learned and 'decoder/gamma_4' not in learned
+    path = str(tmp_path/'model_10.npz')
+    var.save_variables(path, v)
+    back = var.load_variables(path)
+    assert all(numpy.array_equal(back[k], v[k]) for k in v)
+    with pytest.raises(ValueError):
+        var.initialize_weights_gdn(128, 0.02, numpy.random.RandomState(0))
+
+
+def test_shard_bounds():
+    assert [sharding.shard_bounds(512, r, 8) for r in range(8)] == [(64*r, 64*r + 64) for r in range(8)]
+    assert [sharding.shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [sharding.shard_bounds(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    assert sharding.shard_bounds(0, 0, 2) == (0, 0)
+    with pytest.raises(ValueError):
+        sharding.shard_bounds(4, 4, 4)
+    assert numpy.array_equal(sharding.reduce_statistics([1., 2.]), [1., 2.])
+
+
+def test_decisions_from_hist_is_stats_py_181_195(gold):
+    hist_abs = numpy.zeros(16, dtype=numpy.int64)
+    for s in numpy.round(gold['cbd1_in']/numpy.float32(0.05)).astype(int):
+        hist_abs[s] += 1
+    (z, o) = stats._decisions_from_hist(hist_abs, 7)
+    assert numpy.array_equal(z, gold['cbd1_zeros']) and numpy.array_equal(o, gold['cbd1_ones'])
+    assert list(z) == [0, 1, 1, 1, 2, 0, 0] and list(o) == [6, 5, 4, 3, 1, 1, 1]
+
+
+def test_exception_map_bits(gold):
+    """compression.py:73-74 from a histogram."""
+    sym = gold['lossless_symbols'][:, :, 67].astype(numpy.int64)
+    hist = numpy.bincount(sym.reshape(-1) + 255, minlength=511)
+    assert int(compression.exception_map_nb_bits(hist, sym.size)) == int(gold['lossless_bits_each_map'][67])

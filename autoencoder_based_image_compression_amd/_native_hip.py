@@ -14,11 +14,14 @@ HIP_SYMBOLS = {
     'eae_hip_tconv5x5s2': (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'eae_hip_tconv9x9s4_luma': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'eae_hip_pack_tconv9x9s4_weights': (_i, [_vp, _vp, _vp]),
-    'eae_hip_pack_tconv_weights': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'eae_hip_pack_conv_weights': (_i, [_vp, _vp, _i, _vp]),
+    'eae_hip_pack_tconv_weights': (_i, [_vp, _vp, _i, _vp]),
+    'eae_hip_pack_gamma': (_i, [_vp, _vp, _vp]),
     'eae_hip_quantize_maps': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'eae_hip_nonzero_flags': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'eae_hip_cast_int16': (_i, [_vp, _vp, _i64, _vp, _vp]),
     'eae_hip_symbol_histograms': (_i, [_vp, _vp, _i, _vp, _i, _i, _vp]),
+    'eae_hip_debug_set_stamp_buffer': (_i, [_vp]),
     'eae_hip_cast_bt601': (_i, [_vp, _vp, _i64, _vp]),
     'eae_hip_sse_u8': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
 }

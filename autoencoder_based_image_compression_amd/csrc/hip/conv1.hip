@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const uint8_t* __restrict
         for (int r = 0; r < 16; ++r) Xs[(wm * 32 + acc_row32(r, lane)) * EAE_XS_STRIDE + col0 + 32 * t] = acc[t][r];
     __syncthreads();
     f32x16 d[4];
-    gdn_denominator<4>(Xs, wm, lane, gamma, col0, d);
+    gdn_denominator<4>(Xs, wm, lane, gamma, 0, d);   // gamma is packed (eae_hip_pack_gamma)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const float bt = beta[col0 + 32 * t];

@@ -7,13 +7,20 @@
 // Formulation. A "position" is an output pixel (conv) or an input-grid site (transposed conv, one of the 4 output
 // phases (I mod 2, J mod 2)). For one tile of TM positions the kernel computes
 //     Y[TM][128] = sum over taps t, input channels ci of  X[pos + offset(t)][ci] * Wp[t][ci][:]
-// as a GEMM with K = taps * 128: per K-step a [TM x 32] slab of activations (gathered rows, zero outside the image)
-// and a [32 x 128] slab of weights are staged in LDS and consumed by v_mfma_f32_32x32x2_f32.
-// Accumulation order per output element: taps in table order, ci ascending, ONE accumulator -- exactly the f32 FMA
-// chain oracle/transforms_oracle.c runs, so results are bit-identical to the CPU oracle.
+// as a GEMM with K = taps * 128. Per K-step (32 input channels of one tap) a [TM x 32] slab of activations (gathered
+// rows, zero outside the image) and a [32 x 128] slab of weights are staged in LDS and consumed by
+// v_mfma_f32_32x32x2_f32. Accumulation order per output element: taps in table order, ci ascending, ONE accumulator
+// -- exactly the f32 FMA chain oracle/transforms_oracle.c runs, so results are bit-identical to the CPU oracle.
 //
-// Roofline: MFMA-bound (f32 MFMA 157.3 TFLOP/s). Per tile of 128 positions and 25 taps: 105 MFLOP against 1.6 MB of
-// weights (L2-resident, shared by every block) and ~0.34 MB of activations.
+// Data movement (what makes it MFMA-bound rather than LDS/issue-bound):
+//  * weights arrive pre-packed (eae_hip_pack_*): output channels permuted so that the 4 values a lane needs for its 4
+//    column tiles are contiguous -> the weight slab is a straight 16-byte copy global->LDS and ONE ds_read_b128 per k;
+//  * the activation slab is stored [row][k parity][k/2] (+4 floats pad): the 16 k-values a lane needs in a K-step are
+//    contiguous -> 4 ds_read_b128, conflict-free (row stride 144 B = 9 x 16 B);
+//  * LDS is double-buffered: the next slab is fetched global->registers during the MFMAs, written to the other buffer
+//    after them, ONE barrier per K-step; two blocks per CU overlap each other's staging.
+// Roofline: f32 MFMA 157.3 TFLOP/s. Per 128-position tile and 25 taps: 105 MFLOP against 1.6 MB of weights
+// (L2-resident, shared by every block) and ~0.34 MB of activations.
 #include "common.h"
 
 #include <cstdlib>
@@ -21,7 +28,7 @@
 namespace {
 
 constexpr int KC = 32;           // K-step (input channels per LDS slab)
-constexpr int AS_STRIDE = 33;    // +1 float: 32 rows read the same k -> conflict-free ds_read_b32
+constexpr int AS_STRIDE = 36;    // floats per position: [2 parities][16] + 4 pad (16-byte aligned, conflict-free b128)
 constexpr int XS_STRIDE = EAE_XS_STRIDE;   // epilogue tile [TM][128] (+1)
 constexpr int MAX_TAPS = 25;
 constexpr int TILE_H = 8;
@@ -39,16 +46,18 @@ inline int pack_tap(int off_r, int off_c, int widx) { return (off_r + 8) | ((off
 struct ConvGemmParams {
     const float* in;     // [N][Hin][Win][128]
     float* out;          // [N][Hout][Wout][128]
-    const float* w;      // [T][128 ci][128 co]
+    const float* w;      // packed [T][128 ci][128 co permuted]
     const float* bias;   // [128] or nullptr
-    const float* gamma;  // [128][128] (k, c) or nullptr
+    const float* gamma;  // packed [128 k][128 c permuted] or nullptr
     const float* beta;   // [128]
     int norm;            // EAE_NORM_*
     int n, hin, win, hp, wp, hout, wout;
     int in_stride, out_stride;
     int tiles_r, tiles_c, n_phases;
+    unsigned long long* stamps;   // diagnostic only (eae_hip_debug_set_stamp_buffer): 8 x u64 per wave, else nullptr
     PhaseDesc phase[4];
 };
+unsigned long long* g_stamp_buffer = nullptr;
 
 template <int TM>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p) {
@@ -57,12 +66,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     constexpr int WAVES_N = 4 / WAVES_M;   // waves along output channels
     constexpr int NT = 4 / WAVES_N;        // 32-wide channel tiles per wave
     constexpr int A_PASSES = TM / 32;      // float4 loads per thread per K-step for the activation slab
-    constexpr int LDS_MAIN = TM * AS_STRIDE + KC * EAE_C;
+    constexpr int BUF = TM * AS_STRIDE + KC * EAE_C;   // floats per LDS buffer
+    constexpr int LDS_MAIN = 2 * BUF;
     constexpr int LDS_EPI = TM * XS_STRIDE;
     constexpr int LDS_FLOATS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
-    float* As = lds;                      // [TM][33]
-    float* Bs = lds + TM * AS_STRIDE;     // [32][128]   (TM*33*4 bytes is a multiple of 16 for TM in {64,128})
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -77,23 +85,28 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     const int img = b / p.tiles_r;
     const PhaseDesc& pd = p.phase[ph];
 
-    // activation-slab loader: thread -> (position a_m[i], channel quad a_q)
+    // activation-slab loader: thread -> (position (tid>>3) + 32 i, channel quad a_q)
     const int a_q = tid & 7;
     int a_pr[A_PASSES], a_pc[A_PASSES];
-    bool a_ok[A_PASSES];
+    int a_ok[A_PASSES];
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
         const int m = (tid >> 3) + 32 * i;
         a_pr[i] = tr * TILE_H + m / TILE_W;
         a_pc[i] = tc * TILE_W + m % TILE_W;
-        a_ok[i] = a_pr[i] < p.hp && a_pc[i] < p.wp;
+        a_ok[i] = (a_pr[i] < p.hp) & (a_pc[i] < p.wp);
     }
     const float* in_img = p.in + (size_t)img * p.hin * p.win * EAE_C;
 
     // Staging registers for the next K-step (plain named registers + macros: lambdas capturing these arrays by
-    // reference made hipcc demote them to scratch).
+    // reference made hipcc demote them to scratch). Activation rows are fetched with BUFFER loads whose descriptor
+    // covers exactly this image: positions outside the image (SAME zero padding, ragged tiles) get an offset beyond
+    // the descriptor and the hardware returns 0 -- no branches, no selects.
     float4 a_reg[A_PASSES];
     float4 b_reg0, b_reg1, b_reg2, b_reg3;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(in_img), 0, (int)((size_t)p.hin * p.win * EAE_C * sizeof(float)), 0x00020000);
+    const int w_lane_off = tid * 16;
 #define EAE_PREFETCH(step_)                                                                                          \
     {                                                                                                                \
         const int packed_ = pd.tap[(step_) >> 2];                                                                    \
@@ -102,22 +115,27 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
             const int r_ = a_pr[i] * p.in_stride + dr_;                                                              \
             const int c_ = a_pc[i] * p.in_stride + dc_;                                                              \
-            const bool ok_ = a_ok[i] && r_ >= 0 && r_ < p.hin && c_ >= 0 && c_ < p.win;                              \
-            const float4* src_ = reinterpret_cast<const float4*>(                                                    \
-                in_img + ((size_t)(ok_ ? r_ : 0) * p.win + (ok_ ? c_ : 0)) * EAE_C + ci0_ + 4 * a_q);                \
-            const float4 v_ = *src_;                                                                                 \
-            a_reg[i] = ok_ ? v_ : make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+            const int ok_ = a_ok[i] & ((unsigned)r_ < (unsigned)p.hin) & ((unsigned)c_ < (unsigned)p.win);           \
+            const int lin_ = ((r_ * p.win + c_) * EAE_C + ci0_ + 4 * a_q) * 4;                                       \
+            const int off_ = ok_ ? lin_ : -1;   /* beyond num_records -> the load returns 0 */                      \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off_, 0, 0);                             \
+            a_reg[i] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z),              \
+                                   __uint_as_float(v_.w));                                                           \
         }                                                                                                            \
-        const float4* wslab_ = reinterpret_cast<const float4*>(p.w + ((size_t)widx_ * EAE_C + ci0_) * EAE_C) + tid; \
+        const float4* wslab_ = reinterpret_cast<const float4*>(                                                      \
+            reinterpret_cast<const char*>(p.w + ((size_t)widx_ * EAE_C + ci0_) * EAE_C) + w_lane_off);               \
         b_reg0 = wslab_[0]; b_reg1 = wslab_[256]; b_reg2 = wslab_[512]; b_reg3 = wslab_[768];                        \
     }
-#define EAE_STAGE()                                                                                                  \
+    // activation row layout: [parity of k][k >> 1]; channels 4q..4q+3 = k 4q (even), 4q+1 (odd), 4q+2 (even), 4q+3 (odd)
+#define EAE_STAGE(buf_)                                                                                              \
     {                                                                                                                \
+        float* As_ = lds + (buf_) * BUF;                                                                             \
         _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
-            float* dst_ = As + ((tid >> 3) + 32 * i) * AS_STRIDE + 4 * a_q;                                          \
-            dst_[0] = a_reg[i].x; dst_[1] = a_reg[i].y; dst_[2] = a_reg[i].z; dst_[3] = a_reg[i].w;                  \
+            float* dst_ = As_ + ((tid >> 3) + 32 * i) * AS_STRIDE + 2 * a_q;                                         \
+            *reinterpret_cast<float2*>(dst_) = make_float2(a_reg[i].x, a_reg[i].z);                                  \
+            *reinterpret_cast<float2*>(dst_ + 16) = make_float2(a_reg[i].y, a_reg[i].w);                             \
         }                                                                                                            \
-        float4* bdst_ = reinterpret_cast<float4*>(Bs) + tid;                                                         \
+        float4* bdst_ = reinterpret_cast<float4*>(As_ + TM * AS_STRIDE) + tid;                                       \
         bdst_[0] = b_reg0; bdst_[256] = b_reg1; bdst_[512] = b_reg2; bdst_[768] = b_reg3;                            \
     }
 
@@ -128,32 +146,61 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int nsteps = pd.ntaps * (EAE_C / KC);
+    const int hi = lane >> 5, lj = lane & 31;
+    const int a_off = (wm * 32 + lj) * AS_STRIDE + hi * 16;
+    const int b_off = TM * AS_STRIDE + hi * EAE_C + lj * 4 + wn * NT;
+
     EAE_PREFETCH(0)
-    const float* a_rd = As + (wm * 32 + (lane & 31)) * AS_STRIDE + (lane >> 5);
-    const float* b_rd = Bs + (lane >> 5) * EAE_C + wn * NT * 32 + (lane & 31);
+    EAE_STAGE(0)
+    __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
-        __syncthreads();           // previous step's LDS reads are done
-        EAE_STAGE()
-        __syncthreads();
-        {   // next slab's global loads stay in flight during the MFMAs below (the last step re-loads itself: harmless,
+        {   // next slab: global -> registers, in flight during the MFMAs below (the last step re-loads itself: harmless,
             // and keeps the loads unconditional so the staging registers are not demoted to scratch)
             const int nxt = step + 1 < nsteps ? step + 1 : step;
             EAE_PREFETCH(nxt)
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the global loads up here: hipcc otherwise sinks them below the MFMAs
+        const float* base = lds + (step & 1) * BUF;
+        const float4* a_rd = reinterpret_cast<const float4*>(base + a_off);
+        const float4 a0 = a_rd[0], a1 = a_rd[1], a2 = a_rd[2], a3 = a_rd[3];
+        const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+        const float* b_rd = base + b_off;
+        // weight fragments: register double buffer, the read for k+1 is issued before the MFMAs of k
+        float bv[2][NT];
+#define EAE_LOAD_B(dst_, kk_)                                                                                        \
+        if constexpr (NT == 4) {                                                                                     \
+            const float4 v_ = *reinterpret_cast<const float4*>(b_rd + 2 * (kk_) * EAE_C);                            \
+            dst_[0] = v_.x; dst_[1] = v_.y; dst_[2] = v_.z; dst_[3] = v_.w;                                          \
+        } else {                                                                                                     \
+            const float2 v_ = *reinterpret_cast<const float2*>(b_rd + 2 * (kk_) * EAE_C);                            \
+            dst_[0] = v_.x; dst_[1] = v_.y;                                                                          \
+        }
+        // software pipeline, pinned with sched_group_barrier: reads run TWO k ahead of the MFMAs that consume them,
+        //   [4 A reads, B(0), B(1)]  { [NT MFMAs of k]  [B(k+2)] } x 16
+        // so each read has NT*64 cycles (one MFMA group) to land before the wave needs it.
+        EAE_LOAD_B(bv[0], 0)
+        EAE_LOAD_B(bv[1], 1)
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
         for (int kk = 0; kk < KC / 2; ++kk) {
-            const float a = a_rd[2 * kk];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = mfma32(a, b_rd[2 * kk * EAE_C + t * 32], acc[t]);
+            for (int t = 0; t < NT; ++t) acc[t] = mfma32(av[kk], bv[kk & 1][t], acc[t]);
+            if (kk + 2 < KC / 2) { EAE_LOAD_B(bv[kk & 1], kk + 2) }
+            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // the other buffer was last read in step-1, and every wave passed the barrier that ended step-1
+        EAE_STAGE((step + 1) & 1)
+        __syncthreads();
     }
 
     // ---- epilogue: bias_add, then (I)GDN over the 128 channels of each position ------------------------------------
-    const int col0 = wn * NT * 32 + (lane & 31);
+    const int t0 = wn * NT;
     if (p.bias) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float bv = p.bias[col0 + t * 32];
+            const float bv = p.bias[(t0 + t) * 32 + lj];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = acc[t][r] + bv;
         }
@@ -167,77 +214,344 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             if (pr < p.hp && pc < p.wp) {
                 float* o = out_img + ((size_t)(pr * p.out_stride + pd.out_a) * p.wout + (pc * p.out_stride + pd.out_b)) * EAE_C;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) o[col0 + t * 32] = acc[t][r];
+                for (int t = 0; t < NT; ++t) o[(t0 + t) * 32 + lj] = acc[t][r];
             }
         }
         return;
     }
-    __syncthreads();               // everyone is done with As/Bs
+    // (the loop's last barrier guarantees every wave is done with both buffers)
     float* Xs = lds;               // [TM][129]
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Xs[(wm * 32 + acc_row32(r, lane)) * XS_STRIDE + col0 + t * 32] = acc[t][r];
+        for (int r = 0; r < 16; ++r) Xs[(wm * 32 + acc_row32(r, lane)) * XS_STRIDE + (t0 + t) * 32 + lj] = acc[t][r];
     __syncthreads();
     f32x16 d[NT];
-    gdn_denominator<NT>(Xs, wm, lane, p.gamma, col0, d);
+    gdn_denominator<NT>(Xs, wm, lane, p.gamma, t0, d);
     const bool inverse = p.norm == EAE_NORM_IGDN;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const float bt = p.beta[col0 + t * 32];
+        const float bt = p.beta[(t0 + t) * 32 + lj];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = wm * 32 + acc_row32(r, lane);
             const int pr = tr * TILE_H + m / TILE_W, pc = tc * TILE_W + m % TILE_W;
             const float y = gdn_apply(acc[t][r], d[t][r], bt, inverse);
             if (pr < p.hp && pc < p.wp)
-                out_img[((size_t)(pr * p.out_stride + pd.out_a) * p.wout + (pc * p.out_stride + pd.out_b)) * EAE_C + col0 + t * 32] = y;
+                out_img[((size_t)(pr * p.out_stride + pd.out_a) * p.wout + (pc * p.out_stride + pd.out_b)) * EAE_C + (t0 + t) * 32 + lj] = y;
         }
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Barrier-free, transposed variant (the default). Every wave owns 32 positions x 128 output channels and runs its OWN
+// software pipeline; the product is computed TRANSPOSED, Y^T[co][pos] = sum_k W^T[co][k] * X^T[k][pos]:
+//   * MFMA A operand = weights: each lane loads the 16 bytes it needs for (k, its 4 channel tiles) straight from
+//     global memory into a register ring that runs RING k-pairs (RING * 256 MFMA cycles) ahead; the waves of a CU read
+//     the same 16 KB slab within microseconds of each other, so these are L1 / L2 hits;
+//   * MFMA B operand = activations: 4 buffer loads per K-step -> wave-private LDS double buffer ([parity][k/2] rows)
+//     -> 4 ds_read_b128; only the wave itself touches that LDS region, so there is NO workgroup barrier anywhere;
+//   * the accumulator then has the POSITION on the lane and the channel in the register index, which is exactly the B
+//     operand layout of the GDN product d^T[c][pos] = sum_k gamma[k][c] * x^2[pos][k]: one v_permlane32_swap per register
+//     pair turns (k, k+4 | k+1, k+5) into the natural pairs (k, k+1), (k+4, k+5), so x^2 goes from the accumulator
+//     registers into the MFMA in ascending k with no LDS round trip; gamma streams through the same register ring;
+//   * each lane ends up with 4 consecutive channels per register quad -> 16-byte output stores.
+// Same per-element FMA chain (k ascending) as the cooperative kernel and the CPU oracle -> same bits.
+__device__ __forceinline__ void swap_halves(float& a, float& b) {
+    // lanes 32-63 of a <-> lanes 0-31 of b (v_permlane32_swap_b32)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+template <int WAVES, int NORM>
+__global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const ConvGemmParams p) {
+    constexpr int TM = WAVES * 32;
+    constexpr int TILE_W = TM / TILE_H;
+    constexpr int RING = 8;
+    constexpr int ABUF = 32 * AS_STRIDE;                       // one activation buffer of one wave
+    constexpr int WAVE_LDS = 2 * ABUF + 2 * EAE_C;             // + bias[128] + beta[128]
+    __shared__ __attribute__((aligned(16))) float lds[WAVES * WAVE_LDS];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* wlds = lds + wave * WAVE_LDS;
+    float* vec_lds = wlds + 2 * ABUF;                          // per-channel vectors for the epilogue
+    {   // bias / beta land in LDS long before the epilogue needs them (16 global loads there were 16 serial L2 trips)
+        const float2 bz = p.bias ? *reinterpret_cast<const float2*>(p.bias + 2 * lane) : make_float2(0.f, 0.f);
+        *reinterpret_cast<float2*>(vec_lds + 2 * lane) = bz;
+        if (NORM != EAE_NORM_NONE) *reinterpret_cast<float2*>(vec_lds + EAE_C + 2 * lane) = *reinterpret_cast<const float2*>(p.beta + 2 * lane);
+    }
+
+    // Block order: PHASE-MAJOR, longest phase first (launch() sorts p.phase by taps). The hardware hands workgroups to
+    // CUs in order, round-robin, and does not run ahead of a full CU: with the phase as the fastest index every CU
+    // kept receiving the SAME phase and the 4-tap CUs idled behind the 9-tap ones (measured: 70 % MFMA utilisation).
+    // Phase-major, every CU works through the same mix of phases.
+    // Blocks b and b + 8 share an XCD (round-robin over the 8 XCDs): XCD x = b % 8 owns a contiguous range of tiles_x
+    // tiles (shared halos stay in its L2) and walks them once per phase, longest phase first. The grid is padded to
+    // 8 * tiles_x tiles per phase; the (< 8 per phase) surplus blocks exit at once.
+    const int tiles_x = (int)gridDim.x / (8 * p.n_phases);
+    const int seq = (int)blockIdx.x >> 3;
+    const int ph = seq / tiles_x;
+    int b = ((int)blockIdx.x & 7) * tiles_x + seq % tiles_x;
+    if (b >= p.n * p.tiles_r * p.tiles_c) return;
+    const int tc = b % p.tiles_c; b /= p.tiles_c;
+    const int tr = b % p.tiles_r;
+    const int img = b / p.tiles_r;
+    const PhaseDesc& pd = p.phase[ph];
+
+    // activation loader: lane -> (row (lane>>3) + 8 i of this wave, channel quad lane & 7)
+    const int a_q = lane & 7;
+    int a_pr[4], a_pc[4], a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = wave * 32 + (lane >> 3) + 8 * i;
+        a_pr[i] = tr * TILE_H + m / TILE_W;
+        a_pc[i] = tc * TILE_W + m % TILE_W;
+        a_ok[i] = (a_pr[i] < p.hp) & (a_pc[i] < p.wp);
+    }
+    const float* in_img = p.in + (size_t)img * p.hin * p.win * EAE_C;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(in_img), 0, (int)((size_t)p.hin * p.win * EAE_C * sizeof(float)), 0x00020000);
+    const int hi = lane >> 5, lj = lane & 31;
+    // weights / gamma: lane reads 16 bytes at row (k = 2 kk + hi), packed column lj*4
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, (int)((size_t)MAX_TAPS * EAE_C * EAE_C * sizeof(float)), 0x00020000);
+    const int w_lane = (hi * EAE_C + lj * 4) * 4;            // byte offset inside a k-pair
+
+    float4 a_reg[4];
+#define EAE_W_PREFETCH_A(step_)                                                                                      \
+    {                                                                                                                \
+        const int packed_ = pd.tap[(step_) >> 2];                                                                    \
+        const int dr_ = (packed_ & 0xFF) - 8, dc_ = ((packed_ >> 8) & 0xFF) - 8;                                     \
+        const int ci0_ = ((step_) & 3) * KC;                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+            const int r_ = a_pr[i] * p.in_stride + dr_;                                                              \
+            const int c_ = a_pc[i] * p.in_stride + dc_;                                                              \
+            const int ok_ = a_ok[i] & ((unsigned)r_ < (unsigned)p.hin) & ((unsigned)c_ < (unsigned)p.win);           \
+            const int lin_ = ((r_ * p.win + c_) * EAE_C + ci0_ + 4 * a_q) * 4;                                       \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok_ ? lin_ : -1, 0, 0);                  \
+            a_reg[i] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z),              \
+                                   __uint_as_float(v_.w));                                                           \
+        }                                                                                                            \
+    }
+#define EAE_W_STAGE_A(buf_)                                                                                          \
+    {                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
+            float* dst_ = wlds + (buf_) * ABUF + ((lane >> 3) + 8 * i) * AS_STRIDE + 2 * a_q;                        \
+            *reinterpret_cast<float2*>(dst_) = make_float2(a_reg[i].x, a_reg[i].z);                                  \
+            *reinterpret_cast<float2*>(dst_ + 16) = make_float2(a_reg[i].y, a_reg[i].w);                             \
+        }                                                                                                            \
+    }
+    // byte offset of the weight slab of K-step `step_` (tap, 32-channel chunk)
+#define EAE_W_SLAB(step_) ((((pd.tap[(step_) >> 2] >> 16) * EAE_C + ((step_) & 3) * KC) * EAE_C) * 4)
+#define EAE_W_LOAD(dst_, rsrc_, slab_, kk_)                                                                          \
+    {                                                                                                                \
+        const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, w_lane + (kk_) * 2 * EAE_C * 4, (slab_), 0);   \
+        dst_ = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z),                      \
+                           __uint_as_float(v_.w));                                                                   \
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int nsteps = pd.ntaps * (EAE_C / KC);
+    const int a_off = lj * AS_STRIDE + hi * 16;
+
+    unsigned long long t_start = 0, t_loop = 0, t_loop_end = 0, t_gdn_end = 0;
+    if (p.stamps) t_start = __builtin_amdgcn_s_memtime();
+    float4 ring[RING];
+    {
+        const int slab0 = EAE_W_SLAB(0);
+#pragma unroll
+        for (int i = 0; i < RING; ++i) EAE_W_LOAD(ring[i], w_rsrc, slab0, i)
+    }
+    EAE_W_PREFETCH_A(0)
+    EAE_W_STAGE_A(0)
+    if (p.stamps) t_loop = __builtin_amdgcn_s_memtime();
+    for (int step = 0; step < nsteps; ++step) {
+        const int nxt = step + 1 < nsteps ? step + 1 : step;
+        const int slab_cur = EAE_W_SLAB(step);
+        const int slab_nxt = EAE_W_SLAB(nxt);
+        EAE_W_PREFETCH_A(nxt)
+        const float4* a_rd = reinterpret_cast<const float4*>(wlds + (step & 1) * ABUF + a_off);
+        const float4 a0 = a_rd[0], a1 = a_rd[1], a2 = a_rd[2], a3 = a_rd[3];
+        const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) {
+            const float4 wq = ring[kk % RING];
+            acc[0] = mfma32(wq.x, av[kk], acc[0]);      // A = W^T[co = 32 t + lj][k], B = X^T[k][pos = lj]
+            acc[1] = mfma32(wq.y, av[kk], acc[1]);
+            acc[2] = mfma32(wq.z, av[kk], acc[2]);
+            acc[3] = mfma32(wq.w, av[kk], acc[3]);
+            // refill this ring slot with the k-pair RING ahead in the K stream (next step's slab once kk + RING >= 16)
+            if (kk + RING < KC / 2) { EAE_W_LOAD(ring[kk % RING], w_rsrc, slab_cur, kk + RING) }
+            else { EAE_W_LOAD(ring[kk % RING], w_rsrc, slab_nxt, kk + RING - KC / 2) }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        EAE_W_STAGE_A((step + 1) & 1)
+    }
+
+    if (p.stamps) t_loop_end = __builtin_amdgcn_s_memtime();
+    // ---- epilogue, all in registers. acc[t][r] at lane (hi, lj): channel 32 t + (r&3) + 8 (r>>2) + 4 hi, position lj.
+    const int cbase = 4 * hi;                 // channel of (t, g, q) = 32 t + 8 g + cbase + q
+    if (p.bias) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4*>(vec_lds + 32 * t + 8 * g + cbase);
+                acc[t][4 * g + 0] = acc[t][4 * g + 0] + bv.x;
+                acc[t][4 * g + 1] = acc[t][4 * g + 1] + bv.y;
+                acc[t][4 * g + 2] = acc[t][4 * g + 2] + bv.z;
+                acc[t][4 * g + 3] = acc[t][4 * g + 3] + bv.w;
+            }
+    }
+    const int m = wave * 32 + lj;
+    const int pr = tr * TILE_H + m / TILE_W, pc = tc * TILE_W + m % TILE_W;
+    const bool valid = pr < p.hp && pc < p.wp;
+    float* o = p.out + (size_t)img * p.hout * p.wout * EAE_C +
+               ((size_t)(pr * p.out_stride + pd.out_a) * p.wout + (pc * p.out_stride + pd.out_b)) * EAE_C + cbase;
+    if constexpr (NORM == EAE_NORM_NONE) {
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(o + 32 * t + 8 * g) =
+                        make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+        }
+        return;
+    }
+    // d^T[c][pos] = sum_k gamma[k][c] x^2[pos][k], k ascending; gamma rows ride the same register ring
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.gamma), 0, (int)(EAE_C * EAE_C * sizeof(float)), 0x00020000);
+    f32x16 d[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[t][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < RING; ++i) EAE_W_LOAD(ring[i], g_rsrc, 0, i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // registers 4g..4g+3 hold channels (8g + q | 8g + 4 + q) in the (low | high) half-waves
+            float s0 = acc[t][4 * g + 0], s1 = acc[t][4 * g + 1], s2 = acc[t][4 * g + 2], s3 = acc[t][4 * g + 3];
+            swap_halves(s0, s1);     // s0 = (8g+0 | 8g+1), s1 = (8g+4 | 8g+5)
+            swap_halves(s2, s3);     // s2 = (8g+2 | 8g+3), s3 = (8g+6 | 8g+7)
+            const float xs[4] = {s0, s2, s1, s3};            // k pairs in ascending order
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = 16 * t + 4 * g + e;            // k = 2 kk + hi
+                const float x2 = xs[e] * xs[e];
+                const float4 gq = ring[kk % RING];
+                d[0] = mfma32(gq.x, x2, d[0]);
+                d[1] = mfma32(gq.y, x2, d[1]);
+                d[2] = mfma32(gq.z, x2, d[2]);
+                d[3] = mfma32(gq.w, x2, d[3]);
+                if (kk + RING < EAE_C / 2) { EAE_W_LOAD(ring[kk % RING], g_rsrc, 0, kk + RING) }
+            }
+        }
+    }
+    if (p.stamps) t_gdn_end = __builtin_amdgcn_s_memtime();
+    constexpr bool inverse = NORM == EAE_NORM_IGDN;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bt = *reinterpret_cast<const float4*>(vec_lds + EAE_C + 32 * t + 8 * g + cbase);
+            const float4 y = make_float4(gdn_apply(acc[t][4 * g + 0], d[t][4 * g + 0], bt.x, inverse),
+                                         gdn_apply(acc[t][4 * g + 1], d[t][4 * g + 1], bt.y, inverse),
+                                         gdn_apply(acc[t][4 * g + 2], d[t][4 * g + 2], bt.z, inverse),
+                                         gdn_apply(acc[t][4 * g + 3], d[t][4 * g + 3], bt.w, inverse));
+            if (valid) *reinterpret_cast<float4*>(o + 32 * t + 8 * g) = y;
+        }
+    if (p.stamps && lane == 0) {
+        unsigned long long* st = p.stamps + ((size_t)blockIdx.x * WAVES + wave) * 8;
+        st[0] = t_start; st[1] = t_loop; st[2] = t_loop_end; st[3] = t_gdn_end; st[4] = __builtin_amdgcn_s_memtime();
+        st[5] = (unsigned long long)nsteps;
+        st[6] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID
+        st[7] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);   // HW_REG_HW_ID
+    }
+}
+
 int launch(ConvGemmParams& p, hipStream_t stream) {
-    // 128-position tiles when they fill the chip twice over, else 64-position tiles (more, smaller blocks).
-    const long positions = (long)p.n * p.hp * p.wp * p.n_phases;
-    bool big = positions >= 128L * 512 && p.wp >= 16;
-    if (const char* force = std::getenv("EAE_HIP_FORCE_TILE")) big = std::atoi(force) == 128;   // tests cover both tiles
-    const int tile_w = big ? 16 : 8;
+    static const int variant = [] { const char* e = std::getenv("EAE_HIP_GEMM"); return (e && e[0] == 'l') ? 0 : 1; }();
+    p.stamps = g_stamp_buffer;
+    const long positions = (long)p.n * p.hp * p.wp;
+    if (variant == 0) {          // block-cooperative LDS slabs (one barrier per K-step); phase is the fastest index
+        bool big = positions * p.n_phases >= 128L * 512 && p.wp >= 16;
+        if (const char* force = std::getenv("EAE_HIP_FORCE_TILE")) big = std::atoi(force) == 128;
+        const int tile_w = big ? 16 : 8;
+        p.tiles_r = (p.hp + TILE_H - 1) / TILE_H;
+        p.tiles_c = (p.wp + tile_w - 1) / tile_w;
+        const int grid = p.n * p.tiles_r * p.tiles_c * p.n_phases;
+        if (big) hipLaunchKernelGGL(conv_gemm_kernel<128>, dim3(grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL(conv_gemm_kernel<64>, dim3(grid), dim3(256), 0, stream, p);
+        EAE_HIP_CHECK_LAUNCH();
+        return EAE_HIP_OK;
+    }
+    // wave-private pipelines, no barriers. Longest phase first (insertion sort of <= 4 descriptors).
+    for (int i = 1; i < p.n_phases; ++i)
+        for (int j = i; j > 0 && p.phase[j].ntaps > p.phase[j - 1].ntaps; --j) {
+            const PhaseDesc tmp = p.phase[j]; p.phase[j] = p.phase[j - 1]; p.phase[j - 1] = tmp;
+        }
+    // Waves are independent, so the block size only sets the dispatch granularity: 64-position blocks (2 waves) unless
+    // the layer is so small that even those leave CUs without work, then 32-position blocks (1 wave).
+    int waves = positions >= 64L * 1024 ? 2 : 1;
+    if (p.wp < 8 && waves == 2) waves = 1;
+    if (const char* force = std::getenv("EAE_HIP_FORCE_TILE")) waves = std::atoi(force) == 128 ? 4 : (std::atoi(force) == 64 ? 2 : 1);
+    const int tile_w = waves * 32 / TILE_H;
     p.tiles_r = (p.hp + TILE_H - 1) / TILE_H;
     p.tiles_c = (p.wp + tile_w - 1) / tile_w;
-    const int grid = p.n * p.tiles_r * p.tiles_c * p.n_phases;
-    if (big) hipLaunchKernelGGL(conv_gemm_kernel<128>, dim3(grid), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(conv_gemm_kernel<64>, dim3(grid), dim3(256), 0, stream, p);
+    const int tiles = p.n * p.tiles_r * p.tiles_c;
+    const int grid = ((tiles + 7) / 8) * 8 * p.n_phases;     // padded: see the block decode in the kernel
+#define EAE_LAUNCH_WAVE(W_, N_) hipLaunchKernelGGL((conv_gemm_wave_kernel<W_, N_>), dim3(grid), dim3(W_ * 64), 0, stream, p)
+#define EAE_LAUNCH_NORM(W_)                                                   \
+    if (p.norm == EAE_NORM_GDN) EAE_LAUNCH_WAVE(W_, EAE_NORM_GDN);            \
+    else if (p.norm == EAE_NORM_IGDN) EAE_LAUNCH_WAVE(W_, EAE_NORM_IGDN);     \
+    else EAE_LAUNCH_WAVE(W_, EAE_NORM_NONE);
+    if (waves == 4) { EAE_LAUNCH_NORM(4) } else if (waves == 2) { EAE_LAUNCH_NORM(2) } else { EAE_LAUNCH_NORM(1) }
     EAE_HIP_CHECK_LAUNCH();
     return EAE_HIP_OK;
 }
 
 }  // namespace
 
-extern "C" int eae_hip_conv5x5s2(const float* x, const float* w, const float* bias, int norm, const float* gamma,
-                                 const float* beta, float* out, int n, int h, int w_in, void* stream) {
-    if (!x || !w || !out || n <= 0 || h <= 0 || w_in <= 0) return EAE_HIP_BAD_ARGUMENT;
-    if (norm != EAE_NORM_NONE && (!gamma || !beta)) return EAE_HIP_BAD_ARGUMENT;
+extern "C" int eae_hip_conv5x5s2(const float* x, const float* w_packed, const float* bias, int norm,
+                                 const float* gamma_packed, const float* beta, float* out, int n, int h, int w_in,
+                                 void* stream) {
+    if (!x || !w_packed || !out || n <= 0 || h <= 0 || w_in <= 0) return EAE_HIP_BAD_ARGUMENT;
+    if (norm != EAE_NORM_NONE && (!gamma_packed || !beta)) return EAE_HIP_BAD_ARGUMENT;
     if ((h & 1) || (w_in & 1)) return EAE_HIP_BAD_SHAPE;
     ConvGemmParams p{};
-    p.in = x; p.out = out; p.w = w; p.bias = bias; p.gamma = gamma; p.beta = beta; p.norm = norm;
+    p.in = x; p.out = out; p.w = w_packed; p.bias = bias; p.gamma = gamma_packed; p.beta = beta; p.norm = norm;
     p.n = n; p.hin = h; p.win = w_in; p.hp = h / 2; p.wp = w_in / 2; p.hout = h / 2; p.wout = w_in / 2;
     p.in_stride = 2; p.out_stride = 1; p.n_phases = 1;
     PhaseDesc& pd = p.phase[0];
     pd.out_a = 0; pd.out_b = 0; pd.ntaps = 25;
     for (int u = 0; u < 5; ++u)
-        for (int v = 0; v < 5; ++v) {      // SAME padding for k5 s2 on even sizes: 1 before, 2 after (appendix A.2)
+        for (int v = 0; v < 5; ++v)        // SAME padding for k5 s2 on even sizes: 1 before, 2 after (appendix A.2)
             pd.tap[u * 5 + v] = pack_tap(u - 1, v - 1, u * 5 + v);
-        }
     return launch(p, (hipStream_t)stream);
 }
 
 extern "C" int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const float* bias, int norm,
-                                  const float* gamma, const float* beta, float* out, int n, int h, int w_in,
+                                  const float* gamma_packed, const float* beta, float* out, int n, int h, int w_in,
                                   void* stream) {
     if (!x || !w_packed || !out || n <= 0 || h <= 0 || w_in <= 0) return EAE_HIP_BAD_ARGUMENT;
-    if (norm != EAE_NORM_NONE && (!gamma || !beta)) return EAE_HIP_BAD_ARGUMENT;
+    if (norm != EAE_NORM_NONE && (!gamma_packed || !beta)) return EAE_HIP_BAD_ARGUMENT;
     ConvGemmParams p{};
-    p.in = x; p.out = out; p.w = w_packed; p.bias = bias; p.gamma = gamma; p.beta = beta; p.norm = norm;
+    p.in = x; p.out = out; p.w = w_packed; p.bias = bias; p.gamma = gamma_packed; p.beta = beta; p.norm = norm;
     p.n = n; p.hin = h; p.win = w_in; p.hp = h; p.wp = w_in; p.hout = 2 * h; p.wout = 2 * w_in;
     p.in_stride = 1; p.out_stride = 2; p.n_phases = 4;
     // Output pixel I = 2p' + a receives tap u from input row p = p' - (u - a - 1)/2 (appendix A.3, pad_before 1):
@@ -258,21 +572,49 @@ extern "C" int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const f
 }
 
 namespace {
-__global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int taps, int a, int b) {
-    // src [taps][a][b] -> dst [taps][b][a]
-    const long total = (long)taps * a * b;
+// src [rows][128] (or, transposed: [taps][128 cols-of-dst][128 rows-of-dst]) -> dst [rows][packed channel]
+__global__ void pack_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, int transpose_blocks) {
+    const long total = rows * EAE_C;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int t = (int)(i / (a * b));
-        const int rem = (int)(i % (a * b));
-        const int bi = rem / a, ai = rem % a;   // i indexes dst
-        dst[i] = src[((long)t * a + ai) * b + bi];
+        const long row = i / EAE_C;
+        const int c = (int)(i % EAE_C);
+        float v;
+        if (transpose_blocks) {      // dst row = (tap, ci), dst col = co ; src = [tap][co][ci]
+            const long tap = row / EAE_C;
+            const int ci = (int)(row % EAE_C);
+            v = src[(tap * EAE_C + c) * EAE_C + ci];
+        } else {
+            v = src[i];
+        }
+        dst[row * EAE_C + packed_channel(c)] = v;
     }
 }
 }  // namespace
 
-extern "C" int eae_hip_pack_tconv_weights(const float* w_tf, float* w_packed, int taps, int c_out, int c_in, void* stream) {
-    if (!w_tf || !w_packed || taps <= 0 || c_out <= 0 || c_in <= 0) return EAE_HIP_BAD_ARGUMENT;
-    hipLaunchKernelGGL(pack_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, taps, c_out, c_in);
+// Diagnostic: when set (device pointer to grid * waves * 8 u64), the wave kernel records s_memtime stamps per wave.
+extern "C" int eae_hip_debug_set_stamp_buffer(uint64_t* device_buffer) {
+    g_stamp_buffer = reinterpret_cast<unsigned long long*>(device_buffer);
+    return EAE_HIP_OK;
+}
+
+// [5][5][ci][co] (HWIO) -> [25][ci][packed co]
+extern "C" int eae_hip_pack_conv_weights(const float* w_hwio, float* w_packed, int taps, void* stream) {
+    if (!w_hwio || !w_packed || taps <= 0) return EAE_HIP_BAD_ARGUMENT;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, w_hwio, w_packed, (long)taps * EAE_C, 0);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}
+// TF conv2d_transpose filter [5][5][co][ci] -> [25][ci][packed co]
+extern "C" int eae_hip_pack_tconv_weights(const float* w_tf, float* w_packed, int taps, void* stream) {
+    if (!w_tf || !w_packed || taps <= 0) return EAE_HIP_BAD_ARGUMENT;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, w_tf, w_packed, (long)taps * EAE_C, 1);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}
+// gamma [128 k][128 c] -> [128 k][packed c]
+extern "C" int eae_hip_pack_gamma(const float* gamma, float* gamma_packed, void* stream) {
+    if (!gamma || !gamma_packed) return EAE_HIP_BAD_ARGUMENT;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, gamma, gamma_packed, (long)EAE_C, 0);
     EAE_HIP_CHECK_LAUNCH();
     return EAE_HIP_OK;
 }

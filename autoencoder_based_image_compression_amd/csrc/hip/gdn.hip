@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256, 2) void gdn_kernel(const float* __restrict__ x
     __syncthreads();
     const int col0 = lane & 31;
     f32x16 d[4];
-    gdn_denominator<4>(Xs, wm, lane, gamma, col0, d);
+    gdn_denominator<4>(Xs, wm, lane, gamma, 0, d);   // gamma is packed (eae_hip_pack_gamma)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const float bt = beta[col0 + 32 * t];

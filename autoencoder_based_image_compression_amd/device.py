@@ -44,40 +44,40 @@ def device_info():
     return {'name': name.value.decode(), 'compute_units': cus.value, 'clock_mhz': mhz.value, 'hbm_bytes': mem.value}
 
 
-def conv9x9s4_u8(x_u8, w, bias, gamma=None, beta=None, out=None):
-    """conv_1 + bias_add (+ gdn_1). x_u8: uint8 [N,H,W] or [N,H,W,1] -> f32 [N,H/4,W/4,128]."""
+def conv9x9s4_u8(x_u8, w, bias, gamma_packed=None, beta=None, out=None):
+    """conv_1 + bias_add (+ gdn_1). x_u8: uint8 [N,H,W] or [N,H,W,1] -> f32 [N,H/4,W/4,128]. gamma from `pack_gamma`."""
     if x_u8.dtype != torch.uint8:
         raise TypeError('`x_u8.dtype` is not `torch.uint8`.')
     (n, h, wd) = x_u8.shape[:3]
     if out is None:
         out = torch.empty((n, h//4, wd//4, NB_MAPS), dtype=torch.float32, device=x_u8.device)
-    _check(_native.hip().eae_hip_conv9x9s4_u8(_p(x_u8), _p(w), _p(bias), _p(gamma), _p(beta), _p(out), n, h, wd, _stream()),
+    _check(_native.hip().eae_hip_conv9x9s4_u8(_p(x_u8), _p(w), _p(bias), _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream()),
            'eae_hip_conv9x9s4_u8')
     return out
 
 
-def conv5x5s2(x, w, bias, norm=NORM_NONE, gamma=None, beta=None, out=None):
+def conv5x5s2(x, w_packed, bias, norm=NORM_NONE, gamma_packed=None, beta=None, out=None):
     (n, h, wd, c) = x.shape
     if out is None:
         out = torch.empty((n, h//2, wd//2, NB_MAPS), dtype=torch.float32, device=x.device)
-    _check(_native.hip().eae_hip_conv5x5s2(_p(x), _p(w), _p(bias), norm, _p(gamma), _p(beta), _p(out), n, h, wd, _stream()),
+    _check(_native.hip().eae_hip_conv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream()),
            'eae_hip_conv5x5s2')
     return out
 
 
-def gdn(x, gamma, beta, inverse=False, out=None):
+def gdn(x, gamma_packed, beta, inverse=False, out=None):
     if out is None:
         out = torch.empty_like(x)
     rows = x.numel()//NB_MAPS
-    _check(_native.hip().eae_hip_gdn(_p(x), _p(gamma), _p(beta), 1 if inverse else 0, _p(out), rows, _stream()), 'eae_hip_gdn')
+    _check(_native.hip().eae_hip_gdn(_p(x), _p(gamma_packed), _p(beta), 1 if inverse else 0, _p(out), rows, _stream()), 'eae_hip_gdn')
     return out
 
 
-def tconv5x5s2(x, w_packed, bias, norm=NORM_NONE, gamma=None, beta=None, out=None):
+def tconv5x5s2(x, w_packed, bias, norm=NORM_NONE, gamma_packed=None, beta=None, out=None):
     (n, h, wd, c) = x.shape
     if out is None:
         out = torch.empty((n, 2*h, 2*wd, NB_MAPS), dtype=torch.float32, device=x.device)
-    _check(_native.hip().eae_hip_tconv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma), _p(beta), _p(out), n, h, wd, _stream()),
+    _check(_native.hip().eae_hip_tconv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream()),
            'eae_hip_tconv5x5s2')
     return out
 
@@ -94,12 +94,34 @@ def tconv9x9s4_luma(x, w_phase, want_f32=False, want_u8=True, ref_u8=None, sse=N
     return out_f32, out_u8, sse
 
 
-def pack_tconv_weights(w_tf):
-    """[k,k,out,in] (TF conv2d_transpose filter) -> [k,k,in,out]."""
-    (k, k2, co, ci) = w_tf.shape
-    out = torch.empty((k, k2, ci, co), dtype=torch.float32, device=w_tf.device)
-    _check(_native.hip().eae_hip_pack_tconv_weights(_p(w_tf), _p(out), k*k2, co, ci, _stream()), 'eae_hip_pack_tconv_weights')
+def pack_conv_weights(w_hwio):
+    """HWIO [k,k,128,128] -> kernel layout [k*k,128,packed out] (include/eae_hip.h)."""
+    (k, k2, ci, co) = w_hwio.shape
+    out = torch.empty((k*k2, ci, co), dtype=torch.float32, device=w_hwio.device)
+    _check(_native.hip().eae_hip_pack_conv_weights(_p(w_hwio), _p(out), k*k2, _stream()), 'eae_hip_pack_conv_weights')
     return out
+
+
+def pack_tconv_weights(w_tf):
+    """TF conv2d_transpose filter [k,k,out,in] -> kernel layout [k*k,in,packed out]."""
+    (k, k2, co, ci) = w_tf.shape
+    out = torch.empty((k*k2, ci, co), dtype=torch.float32, device=w_tf.device)
+    _check(_native.hip().eae_hip_pack_tconv_weights(_p(w_tf), _p(out), k*k2, _stream()), 'eae_hip_pack_tconv_weights')
+    return out
+
+
+def pack_gamma(gamma):
+    """gamma [128,128] -> [128, packed c]."""
+    out = torch.empty_like(gamma)
+    _check(_native.hip().eae_hip_pack_gamma(_p(gamma), _p(out), _stream()), 'eae_hip_pack_gamma')
+    return out
+
+
+def packed_channel_order():
+    """numpy index array `perm` with packed[..., perm[c]] = plain[..., c] (c -> (c % 32)*4 + c//32)."""
+    import numpy
+    c = numpy.arange(NB_MAPS)
+    return (c % 32)*4 + c//32
 
 
 def pack_tconv9x9s4_weights(w_tf):

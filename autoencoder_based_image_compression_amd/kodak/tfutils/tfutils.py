@@ -14,8 +14,8 @@ def _apply(input, gamma, beta, inverse):
     nb_maps = input.shape[3]
     if nb_maps != 128 or tuple(gamma.shape) != (128, 128) or tuple(beta.shape) != (128,):
         raise ValueError('GDN/IGDN on this path has 128 feature maps: `gamma` (128, 128), `beta` (128,).')
-    out = dev.gdn(bk.to_device(input, numpy.float32), bk.to_device(gamma, numpy.float32), bk.to_device(beta, numpy.float32),
-                  inverse=inverse)
+    out = dev.gdn(bk.to_device(input, numpy.float32), dev.pack_gamma(bk.to_device(gamma, numpy.float32)),
+                  bk.to_device(beta, numpy.float32), inverse=inverse)
     return bk.to_host(out)
 
 

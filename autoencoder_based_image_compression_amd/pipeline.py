@@ -26,6 +26,10 @@ class DeviceEncoder(object):
         self.are_bin_widths_learned = are_bin_widths_learned
         self.device = torch.device(device)
         self.v = {name: _to_device(variables[name], self.device) for name in names}
+        # kernel-side layouts, packed once on the device (include/eae_hip.h "packed" channel order)
+        self.w2 = dev.pack_conv_weights(self.v['encoder/weights_2'])
+        self.w3 = dev.pack_conv_weights(self.v['encoder/weights_3'])
+        self.g = {i: dev.pack_gamma(self.v['encoder/gamma_{}'.format(i)]) for i in ((1, 2) if are_bin_widths_learned else (1, 2, 3))}
 
     def __call__(self, luminances_uint8):
         """uint8 [N,H,W] or [N,H,W,1] (device) -> float32 latents [N,H/16,W/16,128] (device)."""
@@ -37,14 +41,11 @@ class DeviceEncoder(object):
         if w_in % csts.STRIDE_PROD != 0:
             raise ValueError('The width of the input images is not divisible by the product of the three strides.')
         v = self.v
-        gdn_1 = dev.conv9x9s4_u8(luminances_uint8, v['encoder/weights_1'], v['encoder/biases_1'],
-                                 v['encoder/gamma_1'], v['encoder/beta_1'])
-        gdn_2 = dev.conv5x5s2(gdn_1, v['encoder/weights_2'], v['encoder/biases_2'], dev.NORM_GDN,
-                              v['encoder/gamma_2'], v['encoder/beta_2'])
+        gdn_1 = dev.conv9x9s4_u8(luminances_uint8, v['encoder/weights_1'], v['encoder/biases_1'], self.g[1], v['encoder/beta_1'])
+        gdn_2 = dev.conv5x5s2(gdn_1, self.w2, v['encoder/biases_2'], dev.NORM_GDN, self.g[2], v['encoder/beta_2'])
         if self.are_bin_widths_learned:
-            return dev.conv5x5s2(gdn_2, v['encoder/weights_3'], v['encoder/biases_3'], dev.NORM_NONE)
-        return dev.conv5x5s2(gdn_2, v['encoder/weights_3'], v['encoder/biases_3'], dev.NORM_GDN,
-                             v['encoder/gamma_3'], v['encoder/beta_3'])
+            return dev.conv5x5s2(gdn_2, self.w3, v['encoder/biases_3'], dev.NORM_NONE)
+        return dev.conv5x5s2(gdn_2, self.w3, v['encoder/biases_3'], dev.NORM_GDN, self.g[3], v['encoder/beta_3'])
 
 
 class DeviceDecoder(object):
@@ -60,15 +61,16 @@ class DeviceDecoder(object):
         self.w4 = dev.pack_tconv_weights(self.v['decoder/weights_4'])
         self.w5 = dev.pack_tconv_weights(self.v['decoder/weights_5'])
         self.w6 = dev.pack_tconv9x9s4_weights(self.v['decoder/weights_6'])
+        self.g = {i: dev.pack_gamma(self.v['decoder/gamma_{}'.format(i)]) for i in ((5, 6) if are_bin_widths_learned else (4, 5, 6))}
 
     def __call__(self, quantized_y, want_float=False, want_uint8=True, reference_uint8=None, sse=None):
         """float32 [N,h,w,128] (device) -> (float32 [N,16h,16w] or None, uint8 [N,16h,16w] or None, sse or None)."""
         v = self.v
         t = quantized_y
         if not self.are_bin_widths_learned:
-            t = dev.gdn(t, v['decoder/gamma_4'], v['decoder/beta_4'], inverse=True)
-        t = dev.tconv5x5s2(t, self.w4, v['decoder/biases_4'], dev.NORM_IGDN, v['decoder/gamma_5'], v['decoder/beta_5'])
-        t = dev.tconv5x5s2(t, self.w5, v['decoder/biases_5'], dev.NORM_IGDN, v['decoder/gamma_6'], v['decoder/beta_6'])
+            t = dev.gdn(t, self.g[4], v['decoder/beta_4'], inverse=True)
+        t = dev.tconv5x5s2(t, self.w4, v['decoder/biases_4'], dev.NORM_IGDN, self.g[5], v['decoder/beta_5'])
+        t = dev.tconv5x5s2(t, self.w5, v['decoder/biases_5'], dev.NORM_IGDN, self.g[6], v['decoder/beta_6'])
         return dev.tconv9x9s4_luma(t, self.w6, want_f32=want_float, want_u8=want_uint8, ref_u8=reference_uint8, sse=sse)
 
 

@@ -153,11 +153,11 @@ def main():
 
     def step(index, record):
         v = encoder.v
-        gdn_1 = dev.conv9x9s4_u8(images, v['encoder/weights_1'], v['encoder/biases_1'], v['encoder/gamma_1'], v['encoder/beta_1'])
-        gdn_2 = timed_launch('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, v['encoder/weights_2'], v['encoder/biases_2'], dev.NORM_GDN,
-                                                                 v['encoder/gamma_2'], v['encoder/beta_2']), record)
-        y = timed_launch('conv3_gdn3', lambda: dev.conv5x5s2(gdn_2, v['encoder/weights_3'], v['encoder/biases_3'], dev.NORM_GDN,
-                                                             v['encoder/gamma_3'], v['encoder/beta_3']), record)
+        gdn_1 = dev.conv9x9s4_u8(images, v['encoder/weights_1'], v['encoder/biases_1'], encoder.g[1], v['encoder/beta_1'])
+        gdn_2 = timed_launch('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, encoder.w2, v['encoder/biases_2'], dev.NORM_GDN,
+                                                                 encoder.g[2], v['encoder/beta_2']), record)
+        y = timed_launch('conv3_gdn3', lambda: dev.conv5x5s2(gdn_2, encoder.w3, v['encoder/biases_3'], dev.NORM_GDN,
+                                                             encoder.g[3], v['encoder/beta_3']), record)
         q = dev.quantize_maps(y, bin_widths, map_mean, want_shifted=True, want_symbols=True, want_flags=True)
         slot = index % nb_slots
         slot_free[slot].wait()
@@ -170,11 +170,11 @@ def main():
         exc_hists.append(dev.symbol_histograms(q['symbols'][:, IDX_MAP_EXCEPTION:IDX_MAP_EXCEPTION + 1].contiguous(), 255))
         dead_total.add_((q['nonzero_flags'] == 0).sum())
         d = decoder.v
-        t = dev.gdn(q['shifted'], d['decoder/gamma_4'], d['decoder/beta_4'], inverse=True)
+        t = dev.gdn(q['shifted'], decoder.g[4], d['decoder/beta_4'], inverse=True)
         t = timed_launch('tconv1_igdn5', lambda: dev.tconv5x5s2(t, decoder.w4, d['decoder/biases_4'], dev.NORM_IGDN,
-                                                                d['decoder/gamma_5'], d['decoder/beta_5']), record)
+                                                                decoder.g[5], d['decoder/beta_5']), record)
         t = timed_launch('tconv2_igdn6', lambda: dev.tconv5x5s2(t, decoder.w5, d['decoder/biases_5'], dev.NORM_IGDN,
-                                                                d['decoder/gamma_6'], d['decoder/beta_6']), record)
+                                                                decoder.g[6], d['decoder/beta_6']), record)
         dev.tconv9x9s4_luma(t, decoder.w6, want_f32=False, want_u8=True, ref_u8=images, sse=sse_total)
 
     def drain():

@@ -43,28 +43,30 @@ int eae_hip_device_info(char* name, int name_cap, int* compute_units, int* clock
 
 /* conv_1 + bias_add + gdn_1  (components.py:119-125; tf.nn.conv2d 9x9, 1->128, stride 4, 'SAME' = pad 2/3;
  * tfutils.py:393-397). x: uint8 [N][H][W] (the uint8->float32 cast of batching.py:95 is done in-kernel, no offset,
- * no scale); w: [9][9][1][128]; out: f32 [N][H/4][W/4][128]. H, W multiples of 4.
- * gamma == NULL skips the normalisation (plain conv + bias). */
-int eae_hip_conv9x9s4_u8(const uint8_t* x, const float* w, const float* bias, const float* gamma, const float* beta,
-                         float* out, int n, int h, int w_in, void* stream);
+ * no scale); w: [9][9][1][128] (TF layout as is); out: f32 [N][H/4][W/4][128]. H, W multiples of 4.
+ * gamma_packed: from eae_hip_pack_gamma; NULL skips the normalisation (plain conv + bias). */
+int eae_hip_conv9x9s4_u8(const uint8_t* x, const float* w, const float* bias, const float* gamma_packed,
+                         const float* beta, float* out, int n, int h, int w_in, void* stream);
 
 /* conv_2 / conv_3 + bias_add (+ gdn_2 / gdn_3)  (components.py:126-142; tf.nn.conv2d 5x5, 128->128, stride 2,
- * 'SAME' = pad 1/2). x: f32 [N][H][W][128]; w: [5][5][128][128] (HWIO); out: [N][H/2][W/2][128]. H, W even.
- * norm: EAE_NORM_NONE (learned-bin-width model, components.py:137-138) or EAE_NORM_GDN. */
-int eae_hip_conv5x5s2(const float* x, const float* w, const float* bias, int norm, const float* gamma,
+ * 'SAME' = pad 1/2). x: f32 [N][H][W][128]; w_packed: from eae_hip_pack_conv_weights (HWIO [5][5][128][128] with the
+ * output channels in packed order); out: [N][H/2][W/2][128]. H, W even.
+ * norm: EAE_NORM_NONE (learned-bin-width model, components.py:137-138) or EAE_NORM_GDN (gamma_packed, beta). */
+int eae_hip_conv5x5s2(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma_packed,
                       const float* beta, float* out, int n, int h, int w_in, void* stream);
 
 /* GDN / IGDN on its own (tfutils.py:363-397 / 480-509): out[r][c] = x[r][c] (/ or *) sqrt(beta[c] + sum_k x[r][k]^2
- * gamma[k][c]); x, out: [rows][128]. Used for inverse_gdn #4 (components.py:53-58) and as a standalone op. */
-int eae_hip_gdn(const float* x, const float* gamma, const float* beta, int inverse, float* out, int64_t rows,
+ * gamma[k][c]); x, out: [rows][128]; gamma_packed from eae_hip_pack_gamma. Used for inverse_gdn #4
+ * (components.py:53-58) and as a standalone op. */
+int eae_hip_gdn(const float* x, const float* gamma_packed, const float* beta, int inverse, float* out, int64_t rows,
                 void* stream);
 
 /* ---- synthesis transform (components.py:11-84) --------------------------------------------------------------------*/
 
 /* transpose_conv_1 / _2 + bias_add + inverse_gdn of the next layer (components.py:63-78; tf.nn.conv2d_transpose 5x5,
- * 128->128, stride 2, 'SAME'). x: [N][h][w][128]; w_packed: [5][5][128 in][128 out] = the TF filter [5][5][out][in]
- * with its last two axes swapped (eae_hip_pack_tconv_weights); out: [N][2h][2w][128]. */
-int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma,
+ * 128->128, stride 2, 'SAME'). x: [N][h][w][128]; w_packed: from eae_hip_pack_tconv_weights (the TF filter
+ * [5][5][out][in] as [25][in][packed out]); out: [N][2h][2w][128]. */
+int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma_packed,
                        const float* beta, float* out, int n, int h, int w_in, void* stream);
 
 /* transpose_conv_3 (components.py:79-83; 9x9, 128->1, stride 4, 'SAME', no bias) fused with what follows it on the
@@ -78,8 +80,14 @@ int eae_hip_tconv9x9s4_luma(const float* x, const float* w_phase, float* out_f32
 /* TF filter [9][9][1][128] -> [9 neighbours][128][16 output phases] (zeros where a phase has no tap); device to device. */
 int eae_hip_pack_tconv9x9s4_weights(const float* w_tf, float* w_phase, void* stream);
 
-/* [5][5][out][in] -> [5][5][in][out] (or any [taps][a][b] -> [taps][b][a]); device to device. */
-int eae_hip_pack_tconv_weights(const float* w_tf, float* w_packed, int taps, int c_out, int c_in, void* stream);
+/* Kernel-side layouts, packed once per model on the device. "Packed" channel order: out channel c sits at position
+ * (c % 32) * 4 + c / 32 of its row, so that the 4 values one lane needs for its 4 column tiles are one 16-byte load.
+ *   eae_hip_pack_conv_weights : HWIO [taps][128 in][128 out]            -> [taps][128 in][packed out]   (conv_2, conv_3)
+ *   eae_hip_pack_tconv_weights: TF conv2d_transpose [taps][128 out][128 in] -> [taps][128 in][packed out] (tconv_1, _2)
+ *   eae_hip_pack_gamma        : gamma [128 k][128 c]                     -> [128 k][packed c]            (every GDN / IGDN) */
+int eae_hip_pack_conv_weights(const float* w_hwio, float* w_packed, int taps, void* stream);
+int eae_hip_pack_tconv_weights(const float* w_tf, float* w_packed, int taps, void* stream);
+int eae_hip_pack_gamma(const float* gamma, float* gamma_packed, void* stream);
 
 /* ---- quantiser, symbols, per-map statistics ------------------------------------------------------------------------
  * One pass over the latents y: [N][h*w][C] f32, C = 128. For every element, with m = map_mean[c] (NULL = 0) and
@@ -120,6 +128,10 @@ int eae_hip_cast_int16(const float* x, int16_t* out, int64_t count, uint32_t* ra
  * int16). hist and overflow are ACCUMULATED into: the caller zeroes them. */
 int eae_hip_symbol_histograms(const int16_t* symbols_planar, uint32_t* hist, int hist_radius, uint32_t* overflow,
                               int n_maps, int map_size, void* stream);
+
+/* Diagnostic hook (not part of the path): when given a device buffer of grid * waves * 8 uint64, the conv GEMM kernel
+ * records s_memtime stamps per wave (start, loop start, loop end, GDN end, end, K-steps, XCC id, HW id). NULL disables. */
+int eae_hip_debug_set_stamp_buffer(uint64_t* device_buffer);
 
 /* tls.cast_bt601 (tools.py:61-93) on its own: u8 = uint8(round_half_even(clip(x, 16, 235))). */
 int eae_hip_cast_bt601(const float* x, uint8_t* out, int64_t count, void* stream);

@@ -15,6 +15,7 @@ HIP_SYMBOLS = {
     'eae_hip_tconv9x9s4_luma': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'eae_hip_pack_tconv9x9s4_weights': (_i, [_vp, _vp, _vp]),
     'eae_hip_pack_conv_weights': (_i, [_vp, _vp, _i, _vp]),
+    'eae_hip_pack_conv9x9s4_weights': (_i, [_vp, _vp, _vp]),
     'eae_hip_pack_tconv_weights': (_i, [_vp, _vp, _i, _vp]),
     'eae_hip_pack_gamma': (_i, [_vp, _vp, _vp]),
     'eae_hip_quantize_maps': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -24,4 +25,10 @@ HIP_SYMBOLS = {
     'eae_hip_debug_set_stamp_buffer': (_i, [_vp]),
     'eae_hip_cast_bt601': (_i, [_vp, _vp, _i64, _vp]),
     'eae_hip_sse_u8': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
+    'eae_hip_svhn_dense_f64': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'eae_hip_svhn_preprocess': (_i, [_vp, _vp, ctypes.c_double, _vp, _i, _i, _vp]),
+    'eae_hip_svhn_quantize_f64': (_i, [_vp, ctypes.c_double, _vp, _vp, _vp, _i64, _vp]),
+    'eae_hip_svhn_symbol_range': (_i, [_vp, _i64, _vp, _vp]),
+    'eae_hip_svhn_symbol_histogram': (_i, [_vp, _i64, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp]),
+    'eae_hip_svhn_postprocess': (_i, [_vp, ctypes.c_double, _vp, _vp, _vp, _vp, _i, _i, _vp]),
 }

@@ -63,6 +63,7 @@ struct Bitstream {
     uint32_t write_index = 0;
     uint32_t read_index = 0;
     uint64_t acc = 0;          // bits [write_index & ~63, write_index) not yet stored
+    uint32_t limit_bytes = 0;  // bytes that may be read from `data`
 
     bool init_owned(uint32_t required_size_in_bits) {
         size_bits = round_up_to_byte(required_size_in_bits);
@@ -71,6 +72,7 @@ struct Bitstream {
         owns = true;
         write_index = read_index = 0;
         acc = 0;
+        limit_bytes = (uint32_t)bytes;
         return data != nullptr;
     }
     void init_external(uint8_t* buf, uint32_t required_size_in_bits) {  // buf must hold capacity_bytes (+8 slack)
@@ -79,6 +81,7 @@ struct Bitstream {
         owns = false;
         write_index = read_index = 0;
         acc = 0;
+        limit_bytes = (size_bits >> 3) + 8;    // callers of init_external provide >= 8 bytes of slack
     }
     void init_reader(const uint8_t* buf, uint32_t nb_bits) {
         data = const_cast<uint8_t*>(buf);
@@ -87,6 +90,7 @@ struct Bitstream {
         write_index = nb_bits;
         read_index = 0;
         acc = 0;
+        limit_bytes = size_bits >> 3;          // exact: never read past the caller's stream
     }
     ~Bitstream() { if (owns) std::free(data); }
 
@@ -119,6 +123,23 @@ struct Bitstream {
     // Makes every written bit visible in `data` (partial last word included).
     inline void flush() {
         if (write_index & 63u) std::memcpy(data + ((write_index >> 6) << 3), &acc, 8);
+    }
+    // Up to 16 stream bits starting at read_index, first bit in time = MOST significant bit of the result
+    // (what `code = (code << 1) | bit` builds). Caller guarantees n <= occupancy(). `data` has >= 4 readable bytes of
+    // slack after the last stream byte only for internally owned buffers, so external streams are read bytewise near
+    // their end (total_bytes).
+    inline uint32_t take_msb_first(uint32_t n) {
+        const uint32_t byte = read_index >> 3;
+        uint32_t word;
+        if (byte + 4u <= limit_bytes) {
+            std::memcpy(&word, data + byte, 4);
+        } else {
+            word = 0;
+            for (uint32_t i = 0; byte + i < limit_bytes && i < 4u; i++) word |= (uint32_t)data[byte + i] << (8u * i);
+        }
+        const uint32_t field = (word >> (read_index & 7u)) & ((1u << n) - 1u);   // bit j = j-th bit in time
+        read_index += n;
+        return rev16(field) >> (16u - n);
     }
     // Bitstream.cpp:61-79 ; caller guarantees flush() happened after the last put.
     inline int read_bit(uint8_t& storage) {
@@ -207,29 +228,40 @@ struct Bac {
         return EAE_SUCCESS;
     }
 
-    // decoding() = decode_bit + rescale_decoding (:124-134, :254-320)
+    // decoding() = decode_bit + rescale_decoding (:124-134, :254-320). The renormalisation is closed-form like the
+    // encoder's: E1/E2 fire exactly while the top bits of low and high agree (n = leading equal bits, one clz), then
+    // only E3 can fire. E2's `code -= 0x8000` is absorbed by the 16-bit mask after the shift. Stream exhaustion keeps
+    // the reference's semantics: `storage` starts at 0 in every rescale call and, once no bit is left, repeats the
+    // last bit read IN THIS CALL (:275-277, :303-310).
     inline int decode(uint8_t& storage, double p) {
         int s = update_middle(p);
         if (s) return s;
         if (code >= low && code <= middle) { high = middle; storage = 0; }
         else if (code > middle && code <= high) { low = middle + 1u; storage = 1; }
-        uint8_t bit = 0;  // rescale_decoding's local `storage`
-        for (;;) {
-            if (high <= kRangeHalf) {
-            } else if (low > kRangeHalf) {
-                high -= kRangeHalf + 1u; low -= kRangeHalf + 1u; code -= kRangeHalf + 1u;
-            } else if (high <= kRangeThreeQuarters && low > kRangeQuarter) {
-                high -= kRangeQuarter + 1u; low -= kRangeQuarter + 1u; code -= kRangeQuarter + 1u;
-            } else {
-                break;
-            }
+        uint32_t sticky = 0;
+        const uint32_t diff = (low ^ high) & 0xFFFFu;
+        // rescale_decoding has no precision check; values stay within 16 bits for every valid state. For a corrupted
+        // state (low > 0xFFFF cannot happen: low <= high <= 0xFFFF by construction) the clz form is still exact.
+        const uint32_t n = diff ? (uint32_t)__builtin_clz(diff) - 16u : 16u;
+        if (n) {
+            const uint32_t avail = bs.write_index - bs.read_index;
+            const uint32_t k = n < avail ? n : avail;
+            uint32_t bits = k ? bs.take_msb_first(k) : 0u;
+            if (k) sticky = bits & 1u;
+            if (k < n) bits = (bits << (n - k)) | (sticky ? ((1u << (n - k)) - 1u) : 0u);
+            low = (low << n) & kRangeMax;
+            high = ((high << n) & kRangeMax) | ((1u << n) - 1u);
+            code = ((code << n) & kRangeMax) | bits;
+        }
+        while (high <= kRangeThreeQuarters && low > kRangeQuarter && high > kRangeHalf && low <= kRangeHalf) {
+            high -= kRangeQuarter + 1u; low -= kRangeQuarter + 1u; code -= kRangeQuarter + 1u;
             if (bs.read_index < bs.write_index) {
-                bit = (uint8_t)((bs.data[bs.read_index >> 3] >> (bs.read_index & 7u)) & 1u);
+                sticky = (uint32_t)((bs.data[bs.read_index >> 3] >> (bs.read_index & 7u)) & 1u);
                 bs.read_index++;
             }
             high = ((high << 1) & kRangeMax) | 1u;
             low = (low << 1) & kRangeMax;
-            code = ((code << 1) & kRangeMax) | bit;
+            code = ((code << 1) & kRangeMax) | sticky;
         }
         return EAE_SUCCESS;
     }
@@ -459,6 +491,7 @@ private:
 // Per-thread scratch streams for the batched entry points, reused across maps (no malloc per map).
 struct Scratch {
     std::vector<uint8_t> bac, bypass;
+    std::vector<int16_t> decoded;
     void reserve(size_t bytes) {
         if (bac.size() < bytes) { bac.resize(bytes); bypass.resize(bytes); }
     }
@@ -533,6 +566,7 @@ int eae_coder_compress_maps(uint32_t n_maps, uint32_t map_size, const int16_t* s
                             uint32_t* nb_bits, int32_t* status, int32_t* stage, int mode, int n_threads) {
     if (!symbols || !probs || !nb_bits || !status) return EAE_NULL_POINTER;
     if (mode == EAE_MODE_ROUNDTRIP && !reconstruction) return EAE_NULL_POINTER;
+    const bool verify = mode == EAE_MODE_ROUNDTRIP_VERIFY;
     const uint32_t req = required_bits(map_size, L);
     const size_t cap_bytes = (size_t)(round_up_to_byte(req) >> 3) + 16;
     int hw = (int)std::thread::hardware_concurrency();
@@ -558,7 +592,13 @@ int eae_coder_compress_maps(uint32_t n_maps, uint32_t map_size, const int16_t* s
             s = encode_map(c, map_size, in, &st);
             if (!s) {
                 nb_bits[m] = c.bac.bs.occupancy() + c.bypass.occupancy();
-                if (mode == EAE_MODE_ROUNDTRIP) s = decode_map(c, map_size, reconstruction + (size_t)m * map_size, &st);
+                if (mode == EAE_MODE_ROUNDTRIP) {
+                    s = decode_map(c, map_size, reconstruction + (size_t)m * map_size, &st);
+                } else if (verify) {      // decode into scratch and compare: compression.py:146-153 without the copy
+                    if (sc.decoded.size() < map_size) sc.decoded.resize(map_size);
+                    s = decode_map(c, map_size, sc.decoded.data(), &st);
+                    if (!s && std::memcmp(sc.decoded.data(), in, (size_t)map_size * 2) != 0) s = EAE_ROUNDTRIP_MISMATCH;
+                }
             }
         }
         status[m] = s;

@@ -81,3 +81,104 @@ __device__ __forceinline__ float gdn_apply(float x, float d, float beta, bool in
     const float s = sqrtf(d + beta);   // `+ beta` after the matmul, then sqrt, then divide / multiply (tfutils.py:396)
     return inverse ? x * s : x / s;
 }
+
+
+// ---- register-resident epilogue of the TRANSPOSED wave tile (conv_gemm.hip, conv1.hip) --------------------------------
+// acc[t][r] at lane (hi = lane >> 5, lj = lane & 31) holds channel 32 t + (r & 3) + 8 (r >> 2) + 4 hi of position lj
+// (the C/D layout of v_mfma_f32_32x32x2_f32 when the weights are the A operand). Steps:
+//   bias_add (vec_lds[0..127]);  d^T[c][pos] = sum_k gamma[k][c] * x^2[pos][k], k ascending;  x (/ or *) sqrt(d + beta)
+//   (vec_lds[128..255]);  16-byte stores of 4 consecutive channels.
+// x^2 is fed to the MFMA straight from the accumulator registers: one v_permlane32_swap per register pair turns the
+// (k | k+4), (k+1 | k+5) half-wave contents into the natural k pairs (k | k+1), (k+4 | k+5). gamma rows (packed channel
+// order, eae_hip_pack_gamma) stream through a register ring of 16-byte buffer loads.
+__device__ __forceinline__ void swap_halves(float& a, float& b) {
+    // lanes 32-63 of a <-> lanes 0-31 of b (v_permlane32_swap_b32)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+template <int NORM>
+__device__ __forceinline__ void wave_epilogue(f32x16 (&acc)[4], const float* vec_lds, bool has_bias,
+                                              const float* __restrict__ gamma_packed, float* o, bool valid, int lane) {
+    constexpr int RING = 8;
+    const int hi = lane >> 5, lj = lane & 31;
+    const int cbase = 4 * hi;                 // channel of (t, g, q) = 32 t + 8 g + cbase + q
+    o += cbase;
+    if (has_bias) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4*>(vec_lds + 32 * t + 8 * g + cbase);
+                acc[t][4 * g + 0] = acc[t][4 * g + 0] + bv.x;
+                acc[t][4 * g + 1] = acc[t][4 * g + 1] + bv.y;
+                acc[t][4 * g + 2] = acc[t][4 * g + 2] + bv.z;
+                acc[t][4 * g + 3] = acc[t][4 * g + 3] + bv.w;
+            }
+    }
+    if constexpr (NORM == EAE_NORM_NONE) {
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(o + 32 * t + 8 * g) =
+                        make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+        }
+        return;
+    } else {
+        const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(gamma_packed), 0, (int)(EAE_C * EAE_C * sizeof(float)), 0x00020000);
+        const int g_lane = (hi * EAE_C + lj * 4) * 4;        // byte offset inside a k-pair of rows
+        f32x16 d[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[t][r] = 0.f;
+        float4 ring[RING];
+#define EAE_G_LOAD(dst_, kk_)                                                                                        \
+        {                                                                                                            \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_lane + (kk_) * 2 * EAE_C * 4, 0, 0);    \
+            dst_ = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z),                  \
+                               __uint_as_float(v_.w));                                                               \
+        }
+#pragma unroll
+        for (int i = 0; i < RING; ++i) EAE_G_LOAD(ring[i], i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // registers 4g..4g+3 hold channels (8g + q | 8g + 4 + q) in the (low | high) half-waves
+                float s0 = acc[t][4 * g + 0], s1 = acc[t][4 * g + 1], s2 = acc[t][4 * g + 2], s3 = acc[t][4 * g + 3];
+                swap_halves(s0, s1);     // s0 = (8g+0 | 8g+1), s1 = (8g+4 | 8g+5)
+                swap_halves(s2, s3);     // s2 = (8g+2 | 8g+3), s3 = (8g+6 | 8g+7)
+                const float xs[4] = {s0, s2, s1, s3};            // k pairs in ascending order
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = 16 * t + 4 * g + e;            // k = 2 kk + hi
+                    const float x2 = xs[e] * xs[e];
+                    const float4 gq = ring[kk % RING];
+                    d[0] = mfma32(gq.x, x2, d[0]);
+                    d[1] = mfma32(gq.y, x2, d[1]);
+                    d[2] = mfma32(gq.z, x2, d[2]);
+                    d[3] = mfma32(gq.w, x2, d[3]);
+                    if (kk + RING < EAE_C / 2) { EAE_G_LOAD(ring[kk % RING], kk + RING) }
+                }
+            }
+        }
+#undef EAE_G_LOAD
+        constexpr bool inverse = NORM == EAE_NORM_IGDN;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bt = *reinterpret_cast<const float4*>(vec_lds + EAE_C + 32 * t + 8 * g + cbase);
+                const float4 y = make_float4(gdn_apply(acc[t][4 * g + 0], d[t][4 * g + 0], bt.x, inverse),
+                                             gdn_apply(acc[t][4 * g + 1], d[t][4 * g + 1], bt.y, inverse),
+                                             gdn_apply(acc[t][4 * g + 2], d[t][4 * g + 2], bt.z, inverse),
+                                             gdn_apply(acc[t][4 * g + 3], d[t][4 * g + 3], bt.w, inverse));
+                if (valid) *reinterpret_cast<float4*>(o + 32 * t + 8 * g) = y;
+            }
+    }
+}

@@ -258,13 +258,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 //     registers into the MFMA in ascending k with no LDS round trip; gamma streams through the same register ring;
 //   * each lane ends up with 4 consecutive channels per register quad -> 16-byte output stores.
 // Same per-element FMA chain (k ascending) as the cooperative kernel and the CPU oracle -> same bits.
-__device__ __forceinline__ void swap_halves(float& a, float& b) {
-    // lanes 32-63 of a <-> lanes 0-31 of b (v_permlane32_swap_b32)
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]);
-    b = __uint_as_float(r[1]);
-}
-
 template <int WAVES, int NORM>
 __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const ConvGemmParams p) {
     constexpr int TM = WAVES * 32;
@@ -400,81 +393,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
     }
 
     if (p.stamps) t_loop_end = __builtin_amdgcn_s_memtime();
-    // ---- epilogue, all in registers. acc[t][r] at lane (hi, lj): channel 32 t + (r&3) + 8 (r>>2) + 4 hi, position lj.
-    const int cbase = 4 * hi;                 // channel of (t, g, q) = 32 t + 8 g + cbase + q
-    if (p.bias) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 bv = *reinterpret_cast<const float4*>(vec_lds + 32 * t + 8 * g + cbase);
-                acc[t][4 * g + 0] = acc[t][4 * g + 0] + bv.x;
-                acc[t][4 * g + 1] = acc[t][4 * g + 1] + bv.y;
-                acc[t][4 * g + 2] = acc[t][4 * g + 2] + bv.z;
-                acc[t][4 * g + 3] = acc[t][4 * g + 3] + bv.w;
-            }
-    }
+    // ---- epilogue, all in registers (common.h: wave_epilogue) ---------------------------------------------------------
     const int m = wave * 32 + lj;
     const int pr = tr * TILE_H + m / TILE_W, pc = tc * TILE_W + m % TILE_W;
     const bool valid = pr < p.hp && pc < p.wp;
     float* o = p.out + (size_t)img * p.hout * p.wout * EAE_C +
-               ((size_t)(pr * p.out_stride + pd.out_a) * p.wout + (pc * p.out_stride + pd.out_b)) * EAE_C + cbase;
-    if constexpr (NORM == EAE_NORM_NONE) {
-        if (valid) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(o + 32 * t + 8 * g) =
-                        make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
-        }
-        return;
-    }
-    // d^T[c][pos] = sum_k gamma[k][c] x^2[pos][k], k ascending; gamma rows ride the same register ring
-    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.gamma), 0, (int)(EAE_C * EAE_C * sizeof(float)), 0x00020000);
-    f32x16 d[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) d[t][r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < RING; ++i) EAE_W_LOAD(ring[i], g_rsrc, 0, i)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            // registers 4g..4g+3 hold channels (8g + q | 8g + 4 + q) in the (low | high) half-waves
-            float s0 = acc[t][4 * g + 0], s1 = acc[t][4 * g + 1], s2 = acc[t][4 * g + 2], s3 = acc[t][4 * g + 3];
-            swap_halves(s0, s1);     // s0 = (8g+0 | 8g+1), s1 = (8g+4 | 8g+5)
-            swap_halves(s2, s3);     // s2 = (8g+2 | 8g+3), s3 = (8g+6 | 8g+7)
-            const float xs[4] = {s0, s2, s1, s3};            // k pairs in ascending order
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int kk = 16 * t + 4 * g + e;            // k = 2 kk + hi
-                const float x2 = xs[e] * xs[e];
-                const float4 gq = ring[kk % RING];
-                d[0] = mfma32(gq.x, x2, d[0]);
-                d[1] = mfma32(gq.y, x2, d[1]);
-                d[2] = mfma32(gq.z, x2, d[2]);
-                d[3] = mfma32(gq.w, x2, d[3]);
-                if (kk + RING < EAE_C / 2) { EAE_W_LOAD(ring[kk % RING], g_rsrc, 0, kk + RING) }
-            }
-        }
-    }
+               ((size_t)(pr * p.out_stride + pd.out_a) * p.wout + (pc * p.out_stride + pd.out_b)) * EAE_C;
+    wave_epilogue<NORM>(acc, vec_lds, p.bias != nullptr, p.gamma, o, valid, lane);
     if (p.stamps) t_gdn_end = __builtin_amdgcn_s_memtime();
-    constexpr bool inverse = NORM == EAE_NORM_IGDN;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 bt = *reinterpret_cast<const float4*>(vec_lds + EAE_C + 32 * t + 8 * g + cbase);
-            const float4 y = make_float4(gdn_apply(acc[t][4 * g + 0], d[t][4 * g + 0], bt.x, inverse),
-                                         gdn_apply(acc[t][4 * g + 1], d[t][4 * g + 1], bt.y, inverse),
-                                         gdn_apply(acc[t][4 * g + 2], d[t][4 * g + 2], bt.z, inverse),
-                                         gdn_apply(acc[t][4 * g + 3], d[t][4 * g + 3], bt.w, inverse));
-            if (valid) *reinterpret_cast<float4*>(o + 32 * t + 8 * g) = y;
-        }
     if (p.stamps && lane == 0) {
         unsigned long long* st = p.stamps + ((size_t)blockIdx.x * WAVES + wave) * 8;
         st[0] = t_start; st[1] = t_loop; st[2] = t_loop_end; st[3] = t_gdn_end; st[4] = __builtin_amdgcn_s_memtime();

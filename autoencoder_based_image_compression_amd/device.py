@@ -44,14 +44,15 @@ def device_info():
     return {'name': name.value.decode(), 'compute_units': cus.value, 'clock_mhz': mhz.value, 'hbm_bytes': mem.value}
 
 
-def conv9x9s4_u8(x_u8, w, bias, gamma_packed=None, beta=None, out=None):
-    """conv_1 + bias_add (+ gdn_1). x_u8: uint8 [N,H,W] or [N,H,W,1] -> f32 [N,H/4,W/4,128]. gamma from `pack_gamma`."""
+def conv9x9s4_u8(x_u8, w_packed, bias, gamma_packed=None, beta=None, out=None):
+    """conv_1 + bias_add (+ gdn_1). x_u8: uint8 [N,H,W] or [N,H,W,1] -> f32 [N,H/4,W/4,128].
+    w_packed from `pack_conv9x9s4_weights`, gamma_packed from `pack_gamma`."""
     if x_u8.dtype != torch.uint8:
         raise TypeError('`x_u8.dtype` is not `torch.uint8`.')
     (n, h, wd) = x_u8.shape[:3]
     if out is None:
         out = torch.empty((n, h//4, wd//4, NB_MAPS), dtype=torch.float32, device=x_u8.device)
-    _check(_native.hip().eae_hip_conv9x9s4_u8(_p(x_u8), _p(w), _p(bias), _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream()),
+    _check(_native.hip().eae_hip_conv9x9s4_u8(_p(x_u8), _p(w_packed), _p(bias), _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream()),
            'eae_hip_conv9x9s4_u8')
     return out
 
@@ -99,6 +100,13 @@ def pack_conv_weights(w_hwio):
     (k, k2, ci, co) = w_hwio.shape
     out = torch.empty((k*k2, ci, co), dtype=torch.float32, device=w_hwio.device)
     _check(_native.hip().eae_hip_pack_conv_weights(_p(w_hwio), _p(out), k*k2, _stream()), 'eae_hip_pack_conv_weights')
+    return out
+
+
+def pack_conv9x9s4_weights(w_tf):
+    """conv_1 filter [9,9,1,128] -> kernel layout [82, packed out] (row 81 is zero)."""
+    out = torch.empty((82, NB_MAPS), dtype=torch.float32, device=w_tf.device)
+    _check(_native.hip().eae_hip_pack_conv9x9s4_weights(_p(w_tf), _p(out), _stream()), 'eae_hip_pack_conv9x9s4_weights')
     return out
 
 
@@ -191,3 +199,56 @@ def sse_u8(a, b):
     sse = torch.zeros(n, dtype=torch.int64, device=a.device)
     _check(_native.hip().eae_hip_sse_u8(_p(a), _p(b), _p(sse), n, a.numel()//n, _stream()), 'eae_hip_sse_u8')
     return sse
+
+
+# ---- SVHN float64 path (include/eae_hip.h, "SVHN path") -------------------------------------------------------------
+
+def svhn_dense(x, w, b, leaky_relu):
+    """act(x . w + b) in float64; x [n,k], w [k,m], b [m] or [1,m]."""
+    (n, k) = x.shape
+    m = w.shape[1]
+    out = torch.empty((n, m), dtype=torch.float64, device=x.device)
+    _check(_native.hip().eae_hip_svhn_dense_f64(_p(x), _p(w), _p(b), _p(out), n, k, m, 1 if leaky_relu else 0, _stream()),
+           'eae_hip_svhn_dense_f64')
+    return out
+
+
+def svhn_preprocess(images_u8, mean, std_training):
+    (n, d) = images_u8.shape
+    out = torch.empty((n, d), dtype=torch.float64, device=images_u8.device)
+    _check(_native.hip().eae_hip_svhn_preprocess(_p(images_u8), _p(mean), float(std_training), _p(out), n, d, _stream()),
+           'eae_hip_svhn_preprocess')
+    return out
+
+
+def svhn_quantize(y, bin_width, want_q=True, want_symbols=False):
+    q = torch.empty_like(y) if want_q else None
+    symbols = torch.empty(y.shape, dtype=torch.int32, device=y.device) if want_symbols else None
+    checks = torch.zeros(2, dtype=torch.int32, device=y.device)
+    _check(_native.hip().eae_hip_svhn_quantize_f64(_p(y), float(bin_width), _p(q), _p(symbols), _p(checks), y.numel(), _stream()),
+           'eae_hip_svhn_quantize_f64')
+    return q, symbols, checks
+
+
+def svhn_symbol_histogram(symbols):
+    """Exact histogram of int32 symbols from their minimum to their maximum: (hist int64 numpy, minimum)."""
+    minmax = torch.tensor([2147483647, -2147483648], dtype=torch.int32, device=symbols.device)
+    _check(_native.hip().eae_hip_svhn_symbol_range(_p(symbols), symbols.numel(), _p(minmax), _stream()), 'eae_hip_svhn_symbol_range')
+    (lo, hi) = minmax.cpu().tolist()
+    nb = hi - lo + 1
+    hist = torch.zeros(nb, dtype=torch.int32, device=symbols.device)
+    overflow = torch.zeros(1, dtype=torch.int32, device=symbols.device)
+    _check(_native.hip().eae_hip_svhn_symbol_histogram(_p(symbols), symbols.numel(), lo, nb, _p(hist), _p(overflow), _stream()),
+           'eae_hip_svhn_symbol_histogram')
+    if int(overflow.item()) != 0:
+        raise HipError('symbol outside [min, max]')
+    return hist.cpu().numpy().astype('int64'), lo
+
+
+def svhn_postprocess(reconstruction, std_training, mean, ref_u8=None):
+    (n, d) = reconstruction.shape
+    out = torch.empty((n, d), dtype=torch.uint8, device=reconstruction.device)
+    sse = torch.zeros(n, dtype=torch.int64, device=reconstruction.device) if ref_u8 is not None else None
+    _check(_native.hip().eae_hip_svhn_postprocess(_p(reconstruction), float(std_training), _p(mean), _p(out), _p(ref_u8), _p(sse),
+                                                  n, d, _stream()), 'eae_hip_svhn_postprocess')
+    return out, sse

@@ -30,11 +30,14 @@ def load_binary_probabilities(path_to_binary_probabilities):
     return _probabilities_cache[key]
 
 
-def code_planar_symbols(symbols_planar, binary_probabilities, idx_map_exception=-1, nb_threads=0, roundtrip=True):
+def code_planar_symbols(symbols_planar, binary_probabilities, idx_map_exception=-1, nb_threads=0, roundtrip=True,
+                        verify_only=False):
     """Codes every map of a batch after the single device -> host copy.
 
     symbols_planar : int16 (nb_images, nb_maps, map_size), C-contiguous (the layout of `eae_hip_quantize_maps`).
     binary_probabilities : float64 (nb_maps, L).
+    roundtrip : encode + decode like `compress_lossless`; with `verify_only` the decoded symbols are compared with the
+    input inside the coder threads and not returned (AssertionError on a mismatch, compression.py:146-153).
     Returns (reconstruction int16 like `symbols_planar` or None, nb_bits uint32 (nb_images, nb_maps)); the entry of
     the exception map is 0 here -- its cost comes from its histogram (compression.py:68-75).
     Raises like `compress_lossless_flattened_map` for the first failing map.
@@ -51,15 +54,19 @@ def code_planar_symbols(symbols_planar, binary_probabilities, idx_map_exception=
     nb_bits = numpy.zeros(n, dtype=numpy.uint32)
     status = numpy.zeros(n, dtype=numpy.int32)
     stage = numpy.zeros(n, dtype=numpy.int32)
-    reconstruction = numpy.empty_like(symbols_planar) if roundtrip else None
+    keep = roundtrip and not verify_only
+    reconstruction = numpy.empty_like(symbols_planar) if keep else None
+    mode = (2 if verify_only else 0) if roundtrip else 1
     lib = _native.coder()
     lib.eae_coder_compress_maps(n, map_size, _native.ptr(symbols_planar, _native.c_i16p),
-                                _native.ptr(reconstruction, _native.c_i16p) if roundtrip else None,
+                                _native.ptr(reconstruction, _native.c_i16p) if keep else None,
                                 truncated_unary_length, _native.ptr(probabilities, _native.c_f64p),
                                 _native.ptr(prob_row, _native.c_i32p), _native.ptr(nb_bits, _native.c_u32p),
                                 _native.ptr(status, _native.c_i32p), _native.ptr(stage, _native.c_i32p),
-                                0 if roundtrip else 1, nb_threads)
+                                mode, nb_threads)
     bad = numpy.flatnonzero(status)
+    if bad.size and int(status[bad[0]]) == 6:
+        raise AssertionError('\nArrays are not equal\nThe lossless compression has altered the centered quantized data.')
     if bad.size:
         interface_cython.raise_for_status(int(status[bad[0]]), int(stage[bad[0]]))
     return (reconstruction, nb_bits.reshape(nb_images, nb_maps))

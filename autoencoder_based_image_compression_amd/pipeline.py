@@ -27,6 +27,7 @@ class DeviceEncoder(object):
         self.device = torch.device(device)
         self.v = {name: _to_device(variables[name], self.device) for name in names}
         # kernel-side layouts, packed once on the device (include/eae_hip.h "packed" channel order)
+        self.w1 = dev.pack_conv9x9s4_weights(self.v['encoder/weights_1'])
         self.w2 = dev.pack_conv_weights(self.v['encoder/weights_2'])
         self.w3 = dev.pack_conv_weights(self.v['encoder/weights_3'])
         self.g = {i: dev.pack_gamma(self.v['encoder/gamma_{}'.format(i)]) for i in ((1, 2) if are_bin_widths_learned else (1, 2, 3))}
@@ -41,7 +42,7 @@ class DeviceEncoder(object):
         if w_in % csts.STRIDE_PROD != 0:
             raise ValueError('The width of the input images is not divisible by the product of the three strides.')
         v = self.v
-        gdn_1 = dev.conv9x9s4_u8(luminances_uint8, v['encoder/weights_1'], v['encoder/biases_1'], self.g[1], v['encoder/beta_1'])
+        gdn_1 = dev.conv9x9s4_u8(luminances_uint8, self.w1, v['encoder/biases_1'], self.g[1], v['encoder/beta_1'])
         gdn_2 = dev.conv5x5s2(gdn_1, self.w2, v['encoder/biases_2'], dev.NORM_GDN, self.g[2], v['encoder/beta_2'])
         if self.are_bin_widths_learned:
             return dev.conv5x5s2(gdn_2, self.w3, v['encoder/biases_3'], dev.NORM_NONE)

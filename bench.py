@@ -78,10 +78,9 @@ class CoderWorker(threading.Thread):
                 event.synchronize()
                 t0 = time.perf_counter()
                 sym = symbols_host.numpy()
-                (rec, nb_bits) = lossless_compression.code_planar_symbols(sym, self.probabilities, IDX_MAP_EXCEPTION,
-                                                                         nb_threads=self.nb_threads, roundtrip=True)
-                if not numpy.array_equal(rec, sym):
-                    raise AssertionError('The lossless compression has altered the centered quantized data.')
+                (_, nb_bits) = lossless_compression.code_planar_symbols(sym, self.probabilities, IDX_MAP_EXCEPTION,
+                                                                       nb_threads=self.nb_threads, roundtrip=True,
+                                                                       verify_only=True)
                 self.busy_s += time.perf_counter() - t0
                 self.results.append(nb_bits)
             except Exception as exc:   # surfaced by the main thread
@@ -112,7 +111,7 @@ def main():
         dist.init_process_group(backend='nccl', rank=rank, world_size=world)
     device = torch.device('cuda', local_rank)
     cores = os.cpu_count() or 1
-    coder_threads = args.coder_threads if args.coder_threads > 0 else max(1, cores//max(world, 1) - 2)
+    coder_threads = args.coder_threads if args.coder_threads > 0 else max(1, min(96, cores//max(world, 1) - 2))
 
     # ---- model, inputs, coder tables (outside the timed region) ---------------------------------------------------
     variables = synthetic_model(1.)
@@ -136,6 +135,7 @@ def main():
         e.set()
     worker = CoderWorker(probabilities, coder_threads)
     worker.start()
+    copy_stream = torch.cuda.Stream()
     sse_total = torch.zeros(args.batch, dtype=torch.int64, device=device)
     dead_total = torch.zeros(1, dtype=torch.int64, device=device)
     exc_hists = []
@@ -153,7 +153,7 @@ def main():
 
     def step(index, record):
         v = encoder.v
-        gdn_1 = dev.conv9x9s4_u8(images, v['encoder/weights_1'], v['encoder/biases_1'], encoder.g[1], v['encoder/beta_1'])
+        gdn_1 = dev.conv9x9s4_u8(images, encoder.w1, v['encoder/biases_1'], encoder.g[1], v['encoder/beta_1'])
         gdn_2 = timed_launch('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, encoder.w2, v['encoder/biases_2'], dev.NORM_GDN,
                                                                  encoder.g[2], v['encoder/beta_2']), record)
         y = timed_launch('conv3_gdn3', lambda: dev.conv5x5s2(gdn_2, encoder.w3, v['encoder/biases_3'], dev.NORM_GDN,
@@ -162,9 +162,15 @@ def main():
         slot = index % nb_slots
         slot_free[slot].wait()
         slot_free[slot].clear()
-        pinned[slot].copy_(q['symbols'], non_blocking=True)          # the single device -> host copy
-        copied = torch.cuda.Event()
-        copied.record()
+        # the single device -> host copy, on its own stream so that it overlaps the decoder kernels
+        quantized = torch.cuda.Event()
+        quantized.record()
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(quantized)
+            pinned[slot].copy_(q['symbols'], non_blocking=True)
+            q['symbols'].record_stream(copy_stream)
+            copied = torch.cuda.Event()
+            copied.record()
         worker.jobs.put((copied, pinned[slot], slot_free[slot]))
         # exception map: exact histogram on the device, entropy on the host after the timed region's sync
         exc_hists.append(dev.symbol_histograms(q['symbols'][:, IDX_MAP_EXCEPTION:IDX_MAP_EXCEPTION + 1].contiguous(), 255))
@@ -178,9 +184,9 @@ def main():
         dev.tconv9x9s4_luma(t, decoder.w6, want_f32=False, want_u8=True, ref_u8=images, sse=sse_total)
 
     def drain():
+        torch.cuda.synchronize()
         for e in slot_free:
             e.wait()
-        torch.cuda.synchronize()
         if worker.error is not None:
             raise worker.error
 

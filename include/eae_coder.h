@@ -35,6 +35,8 @@ typedef enum {
     EAE_PRECISION_ERROR = 3,   /* low/high left the 16-bit range       (BinaryArithmeticCoder.cpp:184-187) */
     EAE_PROBABILITY_ERROR = 4, /* p is NaN or outside ]0,1[            (BinaryArithmeticCoder.cpp:146-153) */
     EAE_OUT_OF_RANGE = 5,      /* std::out_of_range: m_probabilities.at(i) with L == 0 (LosslessCoder.cpp:173,189,208) */
+    EAE_ROUNDTRIP_MISMATCH = 6,/* decode(encode(x)) != x in EAE_MODE_ROUNDTRIP_VERIFY: the AssertionError of
+                                  lossless/compression.py:146-153 (cannot happen unless the coder is broken) */
     EAE_NULL_POINTER = -1,     /* std::invalid_argument                (compression.cpp:9-12) */
     EAE_BAD_ALLOC = -2
 } eae_error_code;
@@ -61,7 +63,7 @@ int eae_coder_compress_lossless(uint32_t size, const int16_t* array_input, int16
 /* ---- (2) split encode / decode: the streams the reference never returns (compression.cpp:27-64) ------------------
  * eae_coder_stream_capacity_bytes: bytes the caller must provide per stream = ceil(size*max(32,L)/8).
  * encode: writes the BAC stream (after stop_encoding) and the bypass stream; *_bits = number of valid bits.
- * decode: inverse; needs both streams and their bit lengths. */
+ * decode: inverse; needs both streams and their bit lengths; reads exactly ceil(bits/8) bytes of each stream. */
 uint32_t eae_coder_stream_capacity_bytes(uint32_t size, uint8_t truncated_unary_length);
 int eae_coder_encode(uint32_t size, const int16_t* array_input, uint8_t truncated_unary_length,
                      const double* probabilities,
@@ -79,18 +81,21 @@ int eae_coder_decode(uint32_t size, int16_t* array_output, uint8_t truncated_una
  *          cost is computed by the caller from its histogram); skipped maps get nb_bits[m] = 0, status[m] = 0 and,
  *          when `reconstruction` is given, a verbatim copy.
  * mode:    EAE_MODE_ROUNDTRIP = encode + decode + write `reconstruction` (what compress_lossless does per map);
- *          EAE_MODE_ENCODE_ONLY = encode and count bits only (`reconstruction` may be NULL).
+ *          EAE_MODE_ENCODE_ONLY = encode and count bits only (`reconstruction` may be NULL);
+ *          EAE_MODE_ROUNDTRIP_VERIFY = encode + decode + compare with the input inside the worker threads
+ *          (`reconstruction` may be NULL; status EAE_ROUNDTRIP_MISMATCH on a difference).
  * nb_bits[m], status[m], stage[m]: per-map results. Return value: 0, or the first non-zero status encountered.
  * n_threads <= 0 -> all hardware threads (capped at n_maps). */
-enum { EAE_MODE_ROUNDTRIP = 0, EAE_MODE_ENCODE_ONLY = 1 };
+enum { EAE_MODE_ROUNDTRIP = 0, EAE_MODE_ENCODE_ONLY = 1, EAE_MODE_ROUNDTRIP_VERIFY = 2 };
 int eae_coder_compress_maps(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, int16_t* reconstruction,
                             uint8_t truncated_unary_length, const double* probabilities, const int32_t* prob_row,
                             uint32_t* nb_bits, int32_t* status, int32_t* stage, int mode, int n_threads);
 
-/* Same, but keeps the streams: stream_offsets has n_maps+1 entries (bytes into `streams`), map m's BAC bytes start at
- * stream_offsets[m] and its bypass bytes follow at +ceil(bac_bits[m]/8). Call once with streams == NULL to size
- * (stream_offsets is filled from the worst-case capacities), or pass a buffer of eae_coder_stream_capacity_bytes*2 per
- * map and read the packed sizes from bac_bits/bypass_bits. */
+/* Same, but keeps the streams. Map m owns the region [m*stream_stride_bytes, (m+1)*stream_stride_bytes) of `streams`:
+ * its BAC bytes start at the beginning of the region, its bypass bytes at +stream_stride_bytes/2; bac_bits[m] and
+ * bypass_bits[m] give the valid lengths. stream_stride_bytes/2 must be >= eae_coder_stream_capacity_bytes(map_size, L)
+ * + 16 (whole-word stores), else EAE_CAPACITY_ERROR is returned before any work. Skipped maps (prob_row < 0) get 0 bits.
+ * decode_maps is the inverse over the same layout. */
 int eae_coder_encode_maps(uint32_t n_maps, uint32_t map_size, const int16_t* symbols,
                           uint8_t truncated_unary_length, const double* probabilities, const int32_t* prob_row,
                           uint8_t* streams, uint64_t stream_stride_bytes,

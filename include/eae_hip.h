@@ -43,9 +43,9 @@ int eae_hip_device_info(char* name, int name_cap, int* compute_units, int* clock
 
 /* conv_1 + bias_add + gdn_1  (components.py:119-125; tf.nn.conv2d 9x9, 1->128, stride 4, 'SAME' = pad 2/3;
  * tfutils.py:393-397). x: uint8 [N][H][W] (the uint8->float32 cast of batching.py:95 is done in-kernel, no offset,
- * no scale); w: [9][9][1][128] (TF layout as is); out: f32 [N][H/4][W/4][128]. H, W multiples of 4.
- * gamma_packed: from eae_hip_pack_gamma; NULL skips the normalisation (plain conv + bias). */
-int eae_hip_conv9x9s4_u8(const uint8_t* x, const float* w, const float* bias, const float* gamma_packed,
+ * no scale); w_packed: [82][128] from eae_hip_pack_conv9x9s4_weights; out: f32 [N][H/4][W/4][128]. H, W multiples
+ * of 4. gamma_packed: from eae_hip_pack_gamma; NULL skips the normalisation (plain conv + bias). */
+int eae_hip_conv9x9s4_u8(const uint8_t* x, const float* w_packed, const float* bias, const float* gamma_packed,
                          const float* beta, float* out, int n, int h, int w_in, void* stream);
 
 /* conv_2 / conv_3 + bias_add (+ gdn_2 / gdn_3)  (components.py:126-142; tf.nn.conv2d 5x5, 128->128, stride 2,
@@ -86,6 +86,8 @@ int eae_hip_pack_tconv9x9s4_weights(const float* w_tf, float* w_phase, void* str
  *   eae_hip_pack_tconv_weights: TF conv2d_transpose [taps][128 out][128 in] -> [taps][128 in][packed out] (tconv_1, _2)
  *   eae_hip_pack_gamma        : gamma [128 k][128 c]                     -> [128 k][packed c]            (every GDN / IGDN) */
 int eae_hip_pack_conv_weights(const float* w_hwio, float* w_packed, int taps, void* stream);
+/* conv_1 filter [9][9][1][128] -> [82 taps (81 + one zero row)][packed out] */
+int eae_hip_pack_conv9x9s4_weights(const float* w_tf, float* w_packed, void* stream);
 int eae_hip_pack_tconv_weights(const float* w_tf, float* w_packed, int taps, void* stream);
 int eae_hip_pack_gamma(const float* gamma, float* gamma_packed, void* stream);
 
@@ -138,6 +140,34 @@ int eae_hip_cast_bt601(const float* x, uint8_t* out, int64_t count, void* stream
 
 /* Squared error per image for tls.psnr_2d (tools.py:873-875): sse[i] += sum (a - b)^2 over pixels_per_image. */
 int eae_hip_sse_u8(const uint8_t* a, const uint8_t* b, uint64_t* sse, int n, int64_t pixels_per_image, void* stream);
+
+/* ---- SVHN path, BASELINE.json configs[0] (svhn/eae/EntropyAutoencoder.py, svhn/eae/utils.py) ------------------------
+ * The reference's pure-numpy FLOAT64 fully connected autoencoder 3072 -> 300 -> 200 -> 300 -> 3072, LeakyReLU(0.1).
+ * All tensors row-major float64 on the device. Every dot product is one float64 FMA chain, k ascending from +0, bias
+ * added afterwards (oracle/svhn_oracle.c runs the same chain; numpy.dot's BLAS order is unspecified). */
+
+/* out[n][m] = act(x[n][:] . w[:][m] + b[m]); act = LeakyReLU(0.1) when leaky_relu != 0 (svhn/tools/tools.py:676-694).
+ * One call per layer of `encoder` (EntropyAutoencoder.py:239-246) / `decoder` (:270-277). x: [n][k], w: [k][m]. */
+int eae_hip_svhn_dense_f64(const double* x, const double* w, const double* b, double* out, int n, int k, int m,
+                           int leaky_relu, void* stream);
+/* preprocess_svhn (svhn/svhn/svhn.py:210): (uint8 - mean[j]) / std. images: [n][d] uint8, mean: [d]. */
+int eae_hip_svhn_preprocess(const uint8_t* images, const double* mean, double std_training, double* out, int n, int d,
+                            void* stream);
+/* tls.quantization (svhn/tools/tools.py:1095): q = bw * round_half_even(y / bw) with ONE scalar bin width, plus the
+ * int32 symbols round(q / bw) behind tls.count_symbols / discrete_entropy (:214-231, :289-). q and symbols nullable.
+ * checks[2] (caller zeroes): [0] symbols outside int32, [1] |q - y| >= 1.5e-10 ("The quantization was omitted.",
+ * tools.py:214-217, when y is passed as already quantised). */
+int eae_hip_svhn_quantize_f64(const double* y, double bin_width, double* q, int32_t* symbols, uint32_t* checks,
+                              int64_t count, void* stream);
+/* minmax[0] = min(minmax[0], min symbols), minmax[1] = max(...): caller initialises to (INT32_MAX, INT32_MIN). */
+int eae_hip_svhn_symbol_range(const int32_t* symbols, int64_t count, int32_t* minmax, void* stream);
+/* hist[s - lowest] += 1 for lowest <= s < lowest + nb_bins, *overflow += 1 otherwise (caller zeroes both). */
+int eae_hip_svhn_symbol_histogram(const int32_t* symbols, int64_t count, int32_t lowest, int32_t nb_bins, uint32_t* hist,
+                                  uint32_t* overflow, void* stream);
+/* utils.py:71-74: uint8(round_half_even(clip(rec*std + mean[j], 0, 255))) (tools.py:166) and, with ref_u8 + sse, the
+ * squared error per image behind tls.mean_psnr (tools.py:857-859). sse[i] is overwritten. */
+int eae_hip_svhn_postprocess(const double* reconstruction, double std_training, const double* mean, uint8_t* out_u8,
+                             const uint8_t* ref_u8, uint64_t* sse, int n, int d, void* stream);
 
 #ifdef __cplusplus
 }

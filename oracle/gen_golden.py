@@ -231,6 +231,58 @@ def tools_golden(tls, ref_compression, ref_stats, g_coder_dir):
     print('tools_golden.npz: rate', g['lat_rate'], 'bits', g['lossless_bits'], 'psnr', g['psnr_known'])
 
 
+def svhn_golden():
+    """BASELINE.json configs[0]: the reference's numpy SVHN entropy autoencoder (svhn/), seeded random initialisation
+    (its trained .pkl files are absent from the mount). The 15 MB of parameters are NOT stored: both sides draw them with
+    numpy.random.normal in the same order under the same seed; a checksum pins that."""
+    import importlib
+    for name in [m for m in sys.modules if m.split('.')[0] in ('tools', 'eae', 'lossless', 'svhn')]:
+        del sys.modules[name]
+    sys.path.remove(REF)
+    svhn_root = '/root/reference/svhn'
+    sys.path.insert(0, svhn_root)
+    ref_eae = importlib.import_module('eae.EntropyAutoencoder')
+    ref_utils = importlib.import_module('eae.utils')
+    ref_tls = importlib.import_module('tools.tools')
+    ref_svhn = importlib.import_module('svhn.svhn')
+    g = {}
+    numpy.random.seed(20)
+    ae = ref_eae.EntropyAutoencoder(3072, 300, 200, 1., 15., False)
+    params = ae._EntropyAutoencoder__parameters_eae
+    g['seed'] = numpy.int64(20)
+    g['param_checksum'] = numpy.array([params['weights_encoder']['l1'].sum(), params['weights_encoder']['latent'].sum(),
+                                       params['weights_decoder']['l1'].sum(), params['weights_decoder']['mean'].sum()])
+    rng = numpy.random.RandomState(21)
+    images = rng.randint(0, 256, size=(3, 3072)).astype(numpy.uint8)
+    mean_training = rng.uniform(90., 140., size=(1, 3072))
+    std_training = numpy.float64(57.3)
+    x = ref_svhn.preprocess_svhn(images, mean_training, std_training)
+    (hidden, y) = ae.encoder(x)
+    g.update(images=images, mean_training=mean_training, std_training=std_training, preprocessed=x, hidden_encoder=hidden, y=y)
+    for (i, bw) in enumerate((1., 0.25)):
+        q = ref_tls.quantization(y, bw)
+        ent = ref_tls.discrete_entropy(q, bw)
+        (hd, rec) = ae.decoder(q)
+        rec_u8 = ref_tls.cast_float_to_uint8(rec*std_training + numpy.tile(mean_training, (3, 1)))
+        psnr = ref_tls.mean_psnr(images, rec_u8)
+        g['bw{}'.format(i)] = numpy.float64(bw)
+        g['q{}'.format(i)] = q
+        g['entropy{}'.format(i)] = numpy.float64(ent)
+        g['rate{}'.format(i)] = numpy.float64(200*ent/3072)
+        g['reconstruction{}'.format(i)] = rec
+        g['rec_u8_{}'.format(i)] = rec_u8
+        g['psnr{}'.format(i)] = numpy.float64(psnr)
+        g['count_symbols{}'.format(i)] = ref_tls.count_symbols(q, bw)
+    # batch = 1 (the config's own batch size) through the reference's compute_rate_psnr
+    os.makedirs('/tmp/eae_golden', exist_ok=True)
+    (rate1, psnr1) = ref_utils.compute_rate_psnr(images[:1], mean_training, std_training, ae, 1., 1, '/tmp/eae_golden/rec.png')
+    g.update(rate_batch1=numpy.float64(rate1), psnr_batch1=numpy.float64(psnr1))
+    halves = numpy.array([-0.5, 0.5, 1.5, 2.5, 254.5, 255.5, 300., -3., 17.49999], dtype=numpy.float64)
+    g.update(u8_in=halves, u8_out=ref_tls.cast_float_to_uint8(halves), lrelu_in=halves - 2., lrelu_out=ref_tls.leaky_relu(halves - 2.))
+    numpy.savez_compressed(os.path.join(OUT, 'svhn_golden.npz'), **g)
+    print('svhn_golden.npz: rate', g['rate0'], g['rate1'], 'psnr', g['psnr0'], g['psnr1'], 'batch1', rate1, psnr1)
+
+
 if __name__ == '__main__':
     if not os.path.isdir(REF):
         raise SystemExit('/root/reference is not mounted: the fixtures can only be generated in the build container.')
@@ -238,3 +290,4 @@ if __name__ == '__main__':
     (ref, tls, ref_compression, ref_stats) = import_reference()
     coder_golden(ref)
     tools_golden(tls, ref_compression, ref_stats, OUT)
+    svhn_golden()

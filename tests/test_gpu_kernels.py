@@ -51,7 +51,7 @@ def test_conv1_gdn1(T, dev, orc, shape, with_gdn):
     ref = orc.conv2d_same(x.astype(numpy.float32)[..., None], v['encoder/weights_1'], 4, v['encoder/biases_1'])
     if with_gdn:
         ref = orc.gdn(ref, v['encoder/gamma_1'], v['encoder/beta_1'])
-    got = dev.conv9x9s4_u8(_cuda(T, x), _cuda(T, v['encoder/weights_1']), _cuda(T, v['encoder/biases_1']),
+    got = dev.conv9x9s4_u8(_cuda(T, x), dev.pack_conv9x9s4_weights(_cuda(T, v['encoder/weights_1'])), _cuda(T, v['encoder/biases_1']),
                            dev.pack_gamma(_cuda(T, v['encoder/gamma_1'])) if with_gdn else None,
                            _cuda(T, v['encoder/beta_1']) if with_gdn else None).cpu().numpy()
     assert got.shape == ref.shape

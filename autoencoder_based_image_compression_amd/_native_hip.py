@@ -19,6 +19,7 @@ HIP_SYMBOLS = {
     'eae_hip_pack_tconv_weights': (_i, [_vp, _vp, _i, _vp]),
     'eae_hip_pack_gamma': (_i, [_vp, _vp, _vp]),
     'eae_hip_quantize_maps': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'eae_hip_map_sums': (_i, [_vp, _vp, _i64, _i, _vp]),
     'eae_hip_nonzero_flags': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'eae_hip_cast_int16': (_i, [_vp, _vp, _i64, _vp, _vp]),
     'eae_hip_symbol_histograms': (_i, [_vp, _vp, _i, _vp, _i, _i, _vp]),

@@ -9,8 +9,11 @@
 //     Y[TM][128] = sum over taps t, input channels ci of  X[pos + offset(t)][ci] * Wp[t][ci][:]
 // as a GEMM with K = taps * 128. Per K-step (32 input channels of one tap) a [TM x 32] slab of activations (gathered
 // rows, zero outside the image) and a [32 x 128] slab of weights are staged in LDS and consumed by
-// v_mfma_f32_32x32x2_f32. Accumulation order per output element: taps in table order, ci ascending, ONE accumulator
-// -- exactly the f32 FMA chain oracle/transforms_oracle.c runs, so results are bit-identical to the CPU oracle.
+// v_mfma_f32_32x32x2_f32. Accumulation order per output element: 32-channel block (outer), taps in table order, channel
+// within the block, ONE accumulator -- exactly the f32 FMA chain oracle/transforms_oracle.c runs, so results are
+// bit-identical to the CPU oracle. The channel block is the OUTER loop on purpose: the 25 taps of a block then re-read
+// the same 128-byte slice of each input pixel, which keeps the per-XCD reuse distance (~1.5 MB) inside the 4 MB L2;
+// tap-outer order re-fetched the input ~6x from beyond L2 (profiles/traffic_conv_gemm.json).
 //
 // Data movement (what makes it MFMA-bound rather than LDS/issue-bound):
 //  * weights arrive pre-packed (eae_hip_pack_*): output channels permuted so that the 4 values a lane needs for its 4
@@ -109,9 +112,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     const int w_lane_off = tid * 16;
 #define EAE_PREFETCH(step_)                                                                                          \
     {                                                                                                                \
-        const int packed_ = pd.tap[(step_) >> 2];                                                                    \
+        const int packed_ = pd.tap[(step_) % pd.ntaps];   /* K order: 32-channel chunk (outer), then tap */          \
         const int dr_ = (packed_ & 0xFF) - 8, dc_ = ((packed_ >> 8) & 0xFF) - 8, widx_ = packed_ >> 16;              \
-        const int ci0_ = ((step_) & 3) * KC;                                                                         \
+        const int ci0_ = ((step_) / pd.ntaps) * KC;                                                                  \
         _Pragma("unroll") for (int i = 0; i < A_PASSES; ++i) {                                                       \
             const int r_ = a_pr[i] * p.in_stride + dr_;                                                              \
             const int c_ = a_pc[i] * p.in_stride + dc_;                                                              \
@@ -316,9 +319,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
     float4 a_reg[4];
 #define EAE_W_PREFETCH_A(step_)                                                                                      \
     {                                                                                                                \
-        const int packed_ = pd.tap[(step_) >> 2];                                                                    \
+        const int packed_ = pd.tap[(step_) % pd.ntaps];   /* K order: 32-channel chunk (outer), then tap */          \
         const int dr_ = (packed_ & 0xFF) - 8, dc_ = ((packed_ >> 8) & 0xFF) - 8;                                     \
-        const int ci0_ = ((step_) & 3) * KC;                                                                         \
+        const int ci0_ = ((step_) / pd.ntaps) * KC;                                                                  \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                              \
             const int r_ = a_pr[i] * p.in_stride + dr_;                                                              \
             const int c_ = a_pc[i] * p.in_stride + dc_;                                                              \
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
         }                                                                                                            \
     }
     // byte offset of the weight slab of K-step `step_` (tap, 32-channel chunk)
-#define EAE_W_SLAB(step_) ((((pd.tap[(step_) >> 2] >> 16) * EAE_C + ((step_) & 3) * KC) * EAE_C) * 4)
+#define EAE_W_SLAB(step_) ((((pd.tap[(step_) % pd.ntaps] >> 16) * EAE_C + ((step_) / pd.ntaps) * KC) * EAE_C) * 4)
 #define EAE_W_LOAD(dst_, rsrc_, slab_, kk_)                                                                          \
     {                                                                                                                \
         const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, w_lane + (kk_) * 2 * EAE_C * 4, (slab_), 0);   \

@@ -113,6 +113,20 @@ __global__ void cast_int16_kernel(const float* __restrict__ x, int16_t* __restri
     }
 }
 
+// Per-map sums over all rows (lossless/stats.py:306 `numpy.mean(y, axis=(0, 1, 2))` is sums / rows). float64
+// accumulation: thread-private partial over a strided set of rows, then one f64 atomic per (block, channel).
+__global__ __launch_bounds__(256) void map_sums_kernel(const float* __restrict__ y, double* __restrict__ sums, long rows,
+                                                       int c_count) {
+    const int c = threadIdx.x % c_count;
+    const int lanes_per_c = 256 / c_count;          // 2 for 128 maps
+    const int sub = threadIdx.x / c_count;
+    if (sub >= lanes_per_c) return;
+    double acc = 0.0;
+    for (long r = (long)blockIdx.x * lanes_per_c + sub; r < rows; r += (long)gridDim.x * lanes_per_c)
+        acc += (double)y[r * c_count + c];
+    atomicAdd(&sums[c], acc);
+}
+
 // One block per map. LDS histogram when the bins fit, global atomics otherwise (caller zeroed hist/overflow).
 constexpr int LDS_BINS = 8192;
 __global__ __launch_bounds__(256) void hist_kernel(const int16_t* __restrict__ symbols, unsigned int* __restrict__ hist,
@@ -191,6 +205,17 @@ extern "C" int eae_hip_nonzero_flags(const float* x, uint32_t* nonzero_flags, in
     const long total = (long)n * hw * c;
     hipLaunchKernelGGL(nonzero_flags_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, nonzero_flags, total,
                        hw, c);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}
+
+extern "C" int eae_hip_map_sums(const float* y, double* sums, int64_t rows, int c, void* stream) {
+    if (!y || !sums || rows <= 0 || c <= 0 || c > 256) return EAE_HIP_BAD_ARGUMENT;
+    const long per_block = 256 / c;
+    long blocks = (rows + per_block * 64 - 1) / (per_block * 64);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(map_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, sums, (long)rows, c);
     EAE_HIP_CHECK_LAUNCH();
     return EAE_HIP_OK;
 }

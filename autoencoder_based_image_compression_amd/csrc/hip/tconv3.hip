@@ -6,11 +6,12 @@
 // v = b + 2 - 4*dc from the input sites (p'+dr, q'+dc), dr, dc in {-1, 0, +1}. So for a tile of input sites
 //     D[site][phase = 4a+b] = sum over (dr, dc) descending, ci ascending of X[site + (dr,dc)][ci] * Wp[(dr,dc)][ci][phase]
 // is a GEMM with N = 16 phases and K = 9 * 128, Wp holding zeros where 0 <= u,v <= 8 fails (x * 0 adds +0: exact).
-// Descending (dr, dc) == ascending (u, v): the oracle's accumulation order. v_mfma_f32_16x16x4_f32.
+// K order = the oracle's: 32-channel block (outer), then (dr, dc) descending == (u, v) ascending, then the channel inside
+// the block. v_mfma_f32_16x16x4_f32.
 //
 // One block = 4 x 16 sites -> 16 x 64 output pixels; the input patch 6 x 18 sites x 128 channels sits in LDS for the
-// whole block (site stride 130 floats: 16 sites x 2 k read 32 distinct banks), Wp is streamed per neighbour through a
-// double-buffered 8 KB slab. Bound: MFMA for the contraction; 32 B/pixel read + 1 B/pixel write is the HBM term.
+// whole block (site stride 130 floats: 16 sites x 2 k read 32 distinct banks); the weights of one 32-channel block
+// ([9 neighbours][32][16] = 18 KB) are staged in LDS per block of channels (4 stages per tile). Bound: MFMA for the contraction; 32 B/pixel read + 1 B/pixel write is the HBM term.
 #include "common.h"
 
 namespace {
@@ -18,8 +19,8 @@ constexpr int TH = 4, TW = 16;
 constexpr int PS = 130;                       // floats per site in the LDS patch
 constexpr int PATCH_R = TH + 2, PATCH_C = TW + 2;
 constexpr int PATCH_FLOATS = PATCH_R * PATCH_C * PS;   // 14040
-constexpr int WSLAB = EAE_C * 16;             // one neighbour: [128][16]
-constexpr int LDS_FLOATS = PATCH_FLOATS + 2 * WSLAB;   // 18136 floats = 72,544 B -> 2 blocks / CU
+constexpr int WSLAB = 9 * 32 * 16;            // one channel block: [9 neighbours][32 ci][16 phases]
+constexpr int LDS_FLOATS = PATCH_FLOATS + WSLAB;       // 18648 floats = 74,592 B -> 2 blocks / CU
 
 __global__ __launch_bounds__(256, 2) void tconv3_kernel(const float* __restrict__ x, const float* __restrict__ wp,
                                                         float* __restrict__ out_f32, uint8_t* __restrict__ out_u8,
@@ -45,30 +46,23 @@ __global__ __launch_bounds__(256, 2) void tconv3_kernel(const float* __restrict_
         dst[0] = make_float2(v.x, v.y);
         dst[1] = make_float2(v.z, v.w);
     }
-    // first weight slab
-    float4 w0 = reinterpret_cast<const float4*>(wp)[tid], w1 = reinterpret_cast<const float4*>(wp)[tid + 256];
-    reinterpret_cast<float4*>(Wl)[tid] = w0;
-    reinterpret_cast<float4*>(Wl)[tid + 256] = w1;
-    __syncthreads();
-
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15, kq = lane >> 4;
-    for (int nb = 0; nb < 9; ++nb) {
-        const int dr = 1 - nb / 3, dc = 1 - nb % 3;     // (+1,+1), (+1,0), ... (-1,-1)
-        if (nb + 1 < 9) {
-            w0 = reinterpret_cast<const float4*>(wp + (size_t)(nb + 1) * WSLAB)[tid];
-            w1 = reinterpret_cast<const float4*>(wp + (size_t)(nb + 1) * WSLAB)[tid + 256];
-        }
-        const float* a_rd = patch + ((wave + dr + 1) * PATCH_C + (i16 + dc + 1)) * PS + kq;
-        const float* b_rd = Wl + (nb & 1) * WSLAB + kq * 16 + i16;
-#pragma unroll 8
-        for (int kk = 0; kk < EAE_C / 4; ++kk) acc = mfma16(a_rd[4 * kk], b_rd[4 * kk * 16], acc);
-        if (nb + 1 < 9) {   // the other buffer was last read two iterations ago (barrier below separates)
-            reinterpret_cast<float4*>(Wl + ((nb + 1) & 1) * WSLAB)[tid] = w0;
-            reinterpret_cast<float4*>(Wl + ((nb + 1) & 1) * WSLAB)[tid + 256] = w1;
-        }
+    for (int cb = 0; cb < EAE_C / 32; ++cb) {
+        __syncthreads();                       // patch staged (cb == 0) / previous channel block's weights consumed
+        for (int i = tid; i < WSLAB / 4; i += 256)
+            reinterpret_cast<float4*>(Wl)[i] = reinterpret_cast<const float4*>(wp + (size_t)cb * WSLAB)[i];
         __syncthreads();
+#pragma unroll
+        for (int nb = 0; nb < 9; ++nb) {
+            const int dr = 1 - nb / 3, dc = 1 - nb % 3;     // (+1,+1), (+1,0), ... (-1,-1)
+            const float* a_rd = patch + ((wave + dr + 1) * PATCH_C + (i16 + dc + 1)) * PS + cb * 32 + kq;
+            const float* b_rd = Wl + nb * 32 * 16 + kq * 16 + i16;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) acc = mfma16(a_rd[4 * kk], b_rd[4 * kk * 16], acc);
+        }
     }
+    __syncthreads();
     // ---- epilogue: 16 x 64 pixel tile through LDS, then 4 consecutive pixels per thread ----------------------------
     float* ot = lds;                                   // [16][64]; the patch is dead after the last barrier
     {
@@ -110,12 +104,13 @@ __global__ __launch_bounds__(256, 2) void tconv3_kernel(const float* __restrict_
     }
 }
 
-// TF filter [9][9][1][128] -> phase-packed [9 neighbours (dr,dc) descending][128 ci][16 phases], zeros where the tap
-// falls outside the 9x9 kernel.
+// TF filter [9][9][1][128] -> phase-packed [4 channel blocks][9 neighbours (dr,dc) descending][32 ci][16 phases], zeros
+// where the tap falls outside the 9x9 kernel.
 __global__ void pack_tconv3_kernel(const float* __restrict__ w_tf, float* __restrict__ wp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 9 * EAE_C * 16) return;
-    const int phase = i & 15, ci = (i >> 4) & 127, nb = i >> 11;
+    const int phase = i & 15, cin = (i >> 4) & 31, nb = (i >> 9) % 9, cb = i / (9 * 32 * 16);
+    const int ci = cb * 32 + cin;
     const int dr = 1 - nb / 3, dc = 1 - nb % 3;
     const int u = (phase >> 2) + 2 - 4 * dr, v = (phase & 3) + 2 - 4 * dc;
     wp[i] = (u >= 0 && u < 9 && v >= 0 && v < 9) ? w_tf[(u * 9 + v) * EAE_C + ci] : 0.f;

@@ -159,6 +159,15 @@ def quantize_maps(y, bin_widths, map_mean=None, want_cq=False, want_shifted=Fals
     return {'cq': cq, 'shifted': shifted, 'symbols': symbols, 'nonzero_flags': flags, 'checks': checks}
 
 
+def map_means(y):
+    """float32 per-map means over every other axis of y [..., C] (lossless/stats.py:306), float64 accumulation."""
+    c = y.shape[-1]
+    rows = y.numel()//c
+    sums = torch.zeros(c, dtype=torch.float64, device=y.device)
+    _check(_native.hip().eae_hip_map_sums(_p(y), _p(sums), rows, c, _stream()), 'eae_hip_map_sums')
+    return (sums/rows).to(torch.float32)
+
+
 def nonzero_flags(x):
     """x [N, ..., C] -> int32 [N, C], 1 where map (n, c) has a non-zero element."""
     n = x.shape[0]

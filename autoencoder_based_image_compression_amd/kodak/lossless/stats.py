@@ -34,6 +34,15 @@ def _abs_histograms(quantized, bin_widths):
     return hist_abs
 
 
+def compute_map_mean(y_float32):
+    """Per-map mean of the latent variables, `numpy.mean(y_float32, axis=(0, 1, 2))` of stats.py:306, on the device.
+
+    float64 accumulation then rounding to float32: within a few float32 ulps of numpy's float32 pairwise mean.
+    """
+    from ... import device as dev
+    return bk.to_host(dev.map_means(bk.to_device(y_float32, numpy.float32)))
+
+
 # The functions are sorted in alphabetic order.
 
 def compute_binary_probabilities(y_float32, bin_widths_test, map_mean, truncated_unary_length):

@@ -71,13 +71,13 @@ int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const float* bias,
 
 /* transpose_conv_3 (components.py:79-83; 9x9, 128->1, stride 4, 'SAME', no bias) fused with what follows it on the
  * path: tls.cast_bt601 (tools.py:93: uint8(round_half_even(clip(x,16,235)))) and the squared error of tls.psnr_2d
- * (tools.py:873-875). x: [N][h][w][128]; w_phase: [9][128][16] from eae_hip_pack_tconv9x9s4_weights;
+ * (tools.py:873-875). x: [N][h][w][128]; w_phase: [4 channel blocks][9][32][16] from eae_hip_pack_tconv9x9s4_weights;
  * out_f32 (nullable): [N][4h][4w] float reconstruction; out_u8 (nullable): [N][4h][4w] BT.601 cast;
  * ref_u8 + sse (both nullable): sse[i] += sum over image i of (ref - out_u8)^2, exact uint64 (caller zeroes). */
 int eae_hip_tconv9x9s4_luma(const float* x, const float* w_phase, float* out_f32, uint8_t* out_u8,
                             const uint8_t* ref_u8, uint64_t* sse, int n, int h, int w_in, void* stream);
 
-/* TF filter [9][9][1][128] -> [9 neighbours][128][16 output phases] (zeros where a phase has no tap); device to device. */
+/* TF filter [9][9][1][128] -> [4 channel blocks][9 neighbours][32][16 output phases] (zeros where a phase has no tap). */
 int eae_hip_pack_tconv9x9s4_weights(const float* w_tf, float* w_phase, void* stream);
 
 /* Kernel-side layouts, packed once per model on the device. "Packed" channel order: out channel c sits at position
@@ -114,6 +114,12 @@ int eae_hip_pack_gamma(const float* gamma, float* gamma_packed, void* stream);
 int eae_hip_quantize_maps(const float* y, const float* map_mean, const float* bin_widths,
                           float* cq_out, float* shifted_out, int16_t* symbols_planar,
                           uint32_t* nonzero_flags, uint32_t* checks, int n, int hw, int c, void* stream);
+
+/* Per-map sums for the map means of lossless/stats.py:306 (`numpy.mean(y_float32, axis=(0, 1, 2))`): sums[c] += sum over
+ * rows of y[row][c], accumulated in float64 (caller zeroes; the mean is sums / rows, rounded to float32 by the caller).
+ * The reference's float32 accumulation is not reproduced (it carries ~1e-6 relative error itself): the result is the
+ * exact mean rounded to float32, within 1e-5 relative of numpy's float32 `mean`. */
+int eae_hip_map_sums(const float* y, double* sums, int64_t rows, int c, void* stream);
 
 /* tls.count_nb_deads (tools.py:294-320) for an arbitrary stack x [N][hw][C]: nonzero_flags[n][c] = 1 when some
  * element of map (n, c) is != 0 (caller zeroes); the number of dead maps of image n is the number of zero flags. */

@@ -18,15 +18,19 @@
  * Conv / transposed-conv OUTPUT VALUES of the TF graph are "parity unpinned" by the reference (no golden tensors,
  * no trained weights in the mount: .MISSING_LARGE_BLOBS).
  *
- * Arithmetic: float32 throughout (the TF graph is float32). Each dot product is one fused-multiply-add chain in the
- * natural loop order (kernel row, kernel column, input channel), started from +0, bias added afterwards
- * (tf.nn.bias_add is a separate op). TF's own summation order is unspecified (Eigen contraction); this order is a
+ * Arithmetic: float32 throughout (the TF graph is float32). Each dot product is one fused-multiply-add chain, started
+ * from +0, bias added afterwards (tf.nn.bias_add is a separate op), in this fixed order:
+ *     input channels in blocks of ORC_CHANNEL_BLOCK = 32 (outer), then kernel row, kernel column, channel within the block.
+ * Blocking the reduction over input channels is what cache-friendly convolution code does (the 25 taps then re-use one
+ * 128-byte slice of every input pixel); TF's own summation order is unspecified (Eigen contraction). This order is a
  * legitimate instance, and it is the one the gfx950 kernels reproduce bit for bit.
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+#define ORC_CHANNEL_BLOCK 32
 
 /* TF 'SAME' padding before the first element (appendix A.2). */
 static int same_pad_before(int in, int k, int s) {
@@ -49,17 +53,20 @@ void orc_conv2d_same(const float* x, int n, int h, int w, int cin, const float* 
             float* acc = (float*)malloc(sizeof(float) * (size_t)cout);
             for (int j = 0; j < wo; ++j) {
                 for (int co = 0; co < cout; ++co) acc[co] = 0.f;
-                for (int u = 0; u < k; ++u) {
-                    const int r = i * s + u - pbh;
-                    for (int v = 0; v < k; ++v) {
-                        const int c = j * s + v - pbw;
-                        if (r < 0 || r >= h || c < 0 || c >= w) continue;  /* zero padding contributes nothing */
-                        const float* xp = x + (((size_t)b * h + r) * w + c) * cin;
-                        const float* wp = wt + ((size_t)(u * k + v) * cin) * cout;
-                        for (int ci = 0; ci < cin; ++ci) {
-                            const float xv = xp[ci];
-                            const float* wrow = wp + (size_t)ci * cout;
-                            for (int co = 0; co < cout; ++co) acc[co] = fmaf(xv, wrow[co], acc[co]);
+                for (int c0 = 0; c0 < cin; c0 += ORC_CHANNEL_BLOCK) {
+                    const int c1 = c0 + ORC_CHANNEL_BLOCK < cin ? c0 + ORC_CHANNEL_BLOCK : cin;
+                    for (int u = 0; u < k; ++u) {
+                        const int r = i * s + u - pbh;
+                        for (int v = 0; v < k; ++v) {
+                            const int c = j * s + v - pbw;
+                            if (r < 0 || r >= h || c < 0 || c >= w) continue;  /* zero padding contributes nothing */
+                            const float* xp = x + (((size_t)b * h + r) * w + c) * cin;
+                            const float* wp = wt + ((size_t)(u * k + v) * cin) * cout;
+                            for (int ci = c0; ci < c1; ++ci) {
+                                const float xv = xp[ci];
+                                const float* wrow = wp + (size_t)ci * cout;
+                                for (int co = 0; co < cout; ++co) acc[co] = fmaf(xv, wrow[co], acc[co]);
+                            }
                         }
                     }
                 }
@@ -73,7 +80,8 @@ void orc_conv2d_same(const float* x, int n, int h, int w, int cin, const float* 
 /* tf.nn.conv2d_transpose(x, w[k,k,cout,cin], output_shape=[n, s*h, s*w, cout], strides=[1,s,s,1], 'SAME')
  * (+ bias if non-NULL): the gradient of the forward conv (whose input is [s*h][s*w][cout]) w.r.t. its input.
  * y[I][J][co] = sum_{u,v,ci : I = p*s+u-pb, J = q*s+v-pb} x[p][q][ci] * w[u][v][co][ci]   (appendix A.3)
- * with pb = SAME pad_before of the forward conv on the OUTPUT size. Chain order: u ascending, v ascending, ci. */
+ * with pb = SAME pad_before of the forward conv on the OUTPUT size. Chain order: channel block, u ascending, v
+ * ascending, ci within the block. */
 void orc_conv2d_transpose_same(const float* x, int n, int h, int w, int cin, const float* wt, int k, int s, int cout,
                                const float* bias, float* out) {
     const int ho = h * s, wo = w * s;
@@ -89,22 +97,25 @@ void orc_conv2d_transpose_same(const float* x, int n, int h, int w, int cin, con
             float* acc = (float*)malloc(sizeof(float) * (size_t)cout);
             for (int J = 0; J < wo; ++J) {
                 for (int co = 0; co < cout; ++co) acc[co] = 0.f;
-                for (int u = 0; u < k; ++u) {
-                    const int pn = I + pbh - u;
-                    if (pn < 0 || pn % s != 0) continue;
-                    const int p = pn / s;
-                    if (p >= h) continue;
-                    for (int v = 0; v < k; ++v) {
-                        const int qn = J + pbw - v;
-                        if (qn < 0 || qn % s != 0) continue;
-                        const int q = qn / s;
-                        if (q >= w) continue;
-                        const float* xp = x + (((size_t)b * h + p) * w + q) * cin;
-                        const float* wslab = wp + (size_t)(u * k + v) * cin * cout;
-                        for (int ci = 0; ci < cin; ++ci) {
-                            const float xv = xp[ci];
-                            const float* wrow = wslab + (size_t)ci * cout;
-                            for (int co = 0; co < cout; ++co) acc[co] = fmaf(xv, wrow[co], acc[co]);
+                for (int c0 = 0; c0 < cin; c0 += ORC_CHANNEL_BLOCK) {
+                    const int c1 = c0 + ORC_CHANNEL_BLOCK < cin ? c0 + ORC_CHANNEL_BLOCK : cin;
+                    for (int u = 0; u < k; ++u) {
+                        const int pn = I + pbh - u;
+                        if (pn < 0 || pn % s != 0) continue;
+                        const int p = pn / s;
+                        if (p >= h) continue;
+                        for (int v = 0; v < k; ++v) {
+                            const int qn = J + pbw - v;
+                            if (qn < 0 || qn % s != 0) continue;
+                            const int q = qn / s;
+                            if (q >= w) continue;
+                            const float* xp = x + (((size_t)b * h + p) * w + q) * cin;
+                            const float* wslab = wp + (size_t)(u * k + v) * cin * cout;
+                            for (int ci = c0; ci < c1; ++ci) {
+                                const float xv = xp[ci];
+                                const float* wrow = wslab + (size_t)ci * cout;
+                                for (int co = 0; co < cout; ++co) acc[co] = fmaf(xv, wrow[co], acc[co]);
+                            }
                         }
                     }
                 }

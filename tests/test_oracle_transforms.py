@@ -2,7 +2,7 @@
 gamma = 0, beta = 4: test_tfutils.py:398-423, 493-518; the x16 shape law: test_eae.py:71-139, 178-247; zero latents
 decode to a constant image: test_eae.py:141-176); (2) against an INDEPENDENT evaluation of TensorFlow's published op
 definitions in float64 (torch on CPU: padded cross-correlation; conv2d_transpose as the autograd gradient of the
-forward conv). Tolerance for (2): |oracle - float64| <= 3e-7 * (|x| conv |w|) + 1e-6 elementwise, i.e. a few float32
+forward conv). Tolerance for (2): |oracle - float64| <= 1e-6 * (|x| conv |w|) + 1e-6 elementwise, i.e. a few float32
 roundings relative to the sum of the magnitudes of the K <= 3200 products (a float32 FMA chain measures
 0.75-1.5e-7 * sum|a*b|); TF itself is not installable here, its conv OUTPUT VALUES are 'parity unpinned'."""
 import numpy
@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
 from oracle import transforms as T
 
-REL = 3e-7
+REL = 1e-6
 ABS = 1e-6
 
 
@@ -97,7 +97,8 @@ def test_shape_law_times_16_and_zero_latents_give_a_constant_image():
 
 
 def test_oracle_order_is_one_fma_chain():
-    """The documented accumulation order: taps row-major, then input channel, one float32 FMA chain from +0, bias after."""
+    """The documented accumulation order: 32-channel block (outer), kernel row, kernel column, channel inside the block;
+    one float32 FMA chain from +0, bias after."""
     rng = numpy.random.RandomState(6)
     x = rng.standard_normal(size=(1, 4, 4, 128)).astype(numpy.float32)
     w = (rng.standard_normal(size=(5, 5, 128, 128))*0.05).astype(numpy.float32)
@@ -106,13 +107,14 @@ def test_oracle_order_is_one_fma_chain():
     import math
     (i, j, co) = (1, 0, 7)
     acc = numpy.float32(0.)
-    for u in range(5):
-        for v in range(5):
-            (r, c) = (2*i + u - 1, 2*j + v - 1)
-            if not (0 <= r < 4 and 0 <= c < 4):
-                continue
-            for ci in range(128):
-                # float64 product of two float32 is exact; one rounding on the sum == fmaf
-                acc = numpy.float32(numpy.float64(x[0, r, c, ci])*numpy.float64(w[u, v, ci, co]) + numpy.float64(acc))
+    for c0 in range(0, 128, 32):
+        for u in range(5):
+            for v in range(5):
+                (r, c) = (2*i + u - 1, 2*j + v - 1)
+                if not (0 <= r < 4 and 0 <= c < 4):
+                    continue
+                for ci in range(c0, c0 + 32):
+                    # float64 product of two float32 is exact; one rounding on the sum == fmaf
+                    acc = numpy.float32(numpy.float64(x[0, r, c, ci])*numpy.float64(w[u, v, ci, co]) + numpy.float64(acc))
     assert got[0, i, j, co] == numpy.float32(acc + b[co])
     assert math.isfinite(float(acc))

@@ -210,6 +210,69 @@ def sse_u8(a, b):
     return sse
 
 
+# ---- lossless coder on the device (include/eae_hip.h, "lossless coder on the device") ---------------------------------
+
+CODER_ROUNDTRIP, CODER_ENCODE_ONLY, CODER_ROUNDTRIP_VERIFY = 0, 1, 2
+
+
+class CoderStreams(object):
+    """Per-map streams of one batch, resident in HBM, in the layout of eae_coder_encode_maps (include/eae_coder.h):
+    map m owns `streams[m]` (stride bytes): BAC bytes at +0, bypass bytes at +stride/2."""
+
+    def __init__(self, n_maps, map_size, truncated_unary_length, device):
+        self.n_maps = n_maps
+        self.map_size = map_size
+        self.truncated_unary_length = truncated_unary_length
+        self.stride = int(_native.hip().eae_hip_coder_stream_stride_bytes(map_size, truncated_unary_length))
+        self.streams = torch.empty((n_maps, self.stride), dtype=torch.uint8, device=device)
+        # one allocation so that a caller can fetch all four per-map results with a single device -> host copy
+        self.results = torch.zeros((4, n_maps), dtype=torch.int32, device=device)
+        (self.bac_bits, self.bypass_bits, self.status, self.stage) = self.results.unbind(0)
+
+    def nb_bits(self):
+        return self.bac_bits + self.bypass_bits
+
+
+def coder_compress_maps(symbols_planar, probabilities, prob_row, truncated_unary_length, mode=CODER_ROUNDTRIP_VERIFY,
+                        out=None, lanes_per_wave=0):
+    """symbols [..., map_size] int16 (device), probabilities [rows, L] float64 (device), prob_row int32 [n_maps] or None
+    -> (CoderStreams, reconstruction or None). Asynchronous: per-map errors are in `streams.status`."""
+    map_size = symbols_planar.shape[-1]
+    n_maps = symbols_planar.numel()//map_size
+    if symbols_planar.dtype != torch.int16 or probabilities.dtype != torch.float64:
+        raise TypeError('`symbols_planar` must be int16 and `probabilities` float64.')
+    if out is None:
+        out = CoderStreams(n_maps, map_size, truncated_unary_length, symbols_planar.device)
+    reconstruction = torch.empty_like(symbols_planar) if mode == CODER_ROUNDTRIP else None
+    _check(_native.hip().eae_hip_coder_compress_maps(n_maps, map_size, _p(symbols_planar), _p(reconstruction) if reconstruction is not None else None,
+                                                     truncated_unary_length, _p(probabilities), _p(prob_row) if prob_row is not None else None,
+                                                     _p(out.streams), out.stride, _p(out.bac_bits), _p(out.bypass_bits), _p(out.status),
+                                                     _p(out.stage), mode, lanes_per_wave, _stream()), 'eae_hip_coder_compress_maps')
+    return out, reconstruction
+
+
+def coder_decode_maps(streams, probabilities, prob_row, lanes_per_wave=0):
+    """CoderStreams -> int16 [n_maps, map_size] (device); maps with prob_row < 0 are left untouched (zeros)."""
+    out = torch.zeros((streams.n_maps, streams.map_size), dtype=torch.int16, device=streams.streams.device)
+    _check(_native.hip().eae_hip_coder_decode_maps(streams.n_maps, streams.map_size, _p(out), streams.truncated_unary_length,
+                                                   _p(probabilities), _p(prob_row) if prob_row is not None else None,
+                                                   _p(streams.streams), streams.stride, _p(streams.bac_bits), _p(streams.bypass_bits),
+                                                   _p(streams.status), _p(streams.stage), lanes_per_wave, _stream()),
+           'eae_hip_coder_decode_maps')
+    return out
+
+
+def coder_verify_maps(streams, expected_symbols, probabilities, prob_row, lanes_per_wave=0):
+    """Decodes every map of `streams` and compares with `expected_symbols` on the device; failures land in
+    `streams.status` (6 = roundtrip mismatch)."""
+    if expected_symbols.dtype != torch.int16 or expected_symbols.numel() != streams.n_maps*streams.map_size:
+        raise TypeError('`expected_symbols` must hold n_maps x map_size int16 symbols.')
+    _check(_native.hip().eae_hip_coder_verify_maps(streams.n_maps, streams.map_size, _p(expected_symbols), streams.truncated_unary_length,
+                                                   _p(probabilities), _p(prob_row), _p(streams.streams), streams.stride,
+                                                   _p(streams.bac_bits), _p(streams.bypass_bits), _p(streams.status), _p(streams.stage),
+                                                   lanes_per_wave, _stream()), 'eae_hip_coder_verify_maps')
+
+
 # ---- SVHN float64 path (include/eae_hip.h, "SVHN path") -------------------------------------------------------------
 
 def svhn_dense(x, w, b, leaky_relu):

@@ -4,8 +4,8 @@
 One STEP = one pass of the whole hot path over one batch of Kodak-sized (512x768) synthetic luminance images that
 are already resident in HBM:
     conv1+GDN1 -> conv2+GDN2 -> conv3+GDN3 -> centre/quantise/int16 symbols (+dead-map flags, exception-map histogram)
-    -> ONE device->host copy of the symbols -> host coder (UEG0 + binary arithmetic coder, encode + decode + verify,
-       threaded over maps, overlapped with the GPU decode)
+    -> lossless coder ON THE DEVICE (UEG0 + binary arithmetic coder, one map per lane: encode + decode + compare, on its
+       own stream, concurrent with the synthesis transforms); streams stay in HBM, per-map bit counts go to the host
     -> IGDN4 -> tconv1+IGDN5 -> tconv2+IGDN6 -> tconv3 + BT.601 cast + squared error vs the input (PSNR).
 Nothing is skipped or cached between steps. Multi-GPU: one process per GPU, each rank codes its own batch (weak
 scaling, no data-path collective); one RCCL all-reduce sums the rate / PSNR statistics at the end of the timed region.
@@ -55,16 +55,17 @@ def synthetic_model(bin_width=1.):
     return v
 
 
-class CoderWorker(threading.Thread):
-    """Host entropy coding off the launch thread: waits for a batch's D2H copy, codes every map (encode + decode +
-    verify, like compress_lossless), and leaves the bit counts. ctypes releases the GIL inside the coder."""
+class RateWorker(threading.Thread):
+    """Host end of the rate measurement, off the launch thread: waits for a batch's (small) device -> host copy of the
+    coder's per-map results and of the exception-map histograms, checks every status, sums the bit counts and forms the
+    exception map's ceil(h*w*entropy) (compression.py:68-75) in numpy float64 like the reference."""
 
-    def __init__(self, probabilities, nb_threads):
-        super(CoderWorker, self).__init__(daemon=True)
-        self.probabilities = probabilities
-        self.nb_threads = nb_threads
+    def __init__(self, map_size):
+        super(RateWorker, self).__init__(daemon=True)
+        self.map_size = map_size
         self.jobs = queue.Queue()
-        self.results = []
+        self.coder_bits = 0
+        self.exception_bits = 0
         self.error = None
         self.busy_s = 0.
 
@@ -73,16 +74,20 @@ class CoderWorker(threading.Thread):
             job = self.jobs.get()
             if job is None:
                 return
-            (event, symbols_host, slot_free) = job
+            (event, results_host, hist_host, overflow_host, slot_free) = job
             try:
                 event.synchronize()
                 t0 = time.perf_counter()
-                sym = symbols_host.numpy()
-                (_, nb_bits) = lossless_compression.code_planar_symbols(sym, self.probabilities, IDX_MAP_EXCEPTION,
-                                                                       nb_threads=self.nb_threads, roundtrip=True,
-                                                                       verify_only=True)
+                results = results_host.numpy()
+                if results[2].any():
+                    bad = int(numpy.flatnonzero(results[2])[0])
+                    raise RuntimeError('device coder: map {0} failed with status {1} at stage {2}'.format(bad, results[2, bad], results[3, bad]))
+                if int(overflow_host.numpy().sum()) != 0:
+                    raise RuntimeError('exception-map symbols outside the histogram radius')
+                self.coder_bits += int(results[0].astype(numpy.int64).sum()) + int(results[1].astype(numpy.int64).sum())
+                self.exception_bits += sum(int(lossless_compression.exception_map_nb_bits(row, self.map_size))
+                                           for row in hist_host.numpy().astype(numpy.int64))
                 self.busy_s += time.perf_counter() - t0
-                self.results.append(nb_bits)
             except Exception as exc:   # surfaced by the main thread
                 self.error = exc
             finally:
@@ -92,13 +97,16 @@ class CoderWorker(threading.Thread):
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
-    parser.add_argument('--steps', type=int, default=10)
-    parser.add_argument('--warmup', type=int, default=2)
+    parser.add_argument('--steps', type=int, default=30)
+    parser.add_argument('--warmup', type=int, default=5)
     parser.add_argument('--batch', type=int, default=24, help='Kodak-sized images per GPU per step')
     parser.add_argument('--no-cpu-baseline', action='store_true')
-    parser.add_argument('--coder-threads', type=int, default=0)
+    parser.add_argument('--coder-lanes', type=int, default=int(os.environ.get('EAE_CODER_LANES', '0')),
+                        help='maps per 64-thread block of the device coder (0 = library default)')
     args = parser.parse_args()
 
+    # two Python threads share the GIL (kernel launches; rate bookkeeping): hand it over quickly
+    sys.setswitchinterval(1e-4)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -111,7 +119,6 @@ def main():
         dist.init_process_group(backend='nccl', rank=rank, world_size=world)
     device = torch.device('cuda', local_rank)
     cores = os.cpu_count() or 1
-    coder_threads = args.coder_threads if args.coder_threads > 0 else max(1, min(96, cores//max(world, 1) - 2))
 
     # ---- model, inputs, coder tables (outside the timed region) ---------------------------------------------------
     variables = synthetic_model(1.)
@@ -128,17 +135,26 @@ def main():
                                                                 TRUNCATED_UNARY_LENGTH)
     map_mean = torch.from_numpy(map_mean_host).to(device)
     del y0
+    probabilities_dev = torch.from_numpy(numpy.ascontiguousarray(probabilities, dtype=numpy.float64)).to(device)
+    # row of `probabilities` per map of the batch; -1 = the exception map, costed from its histogram (compression.py:68-75)
+    prob_row = torch.arange(128, dtype=torch.int32).repeat(args.batch)
+    prob_row[IDX_MAP_EXCEPTION::128] = -1
+    prob_row = prob_row.to(device)
+    n_maps = args.batch*128
     nb_slots = 3
-    pinned = [torch.empty((args.batch, 128, map_size), dtype=torch.int16).pin_memory() for _ in range(nb_slots)]
+    streams = [dev.CoderStreams(n_maps, map_size, TRUNCATED_UNARY_LENGTH, device) for _ in range(nb_slots)]
+    pinned_results = [torch.empty((4, n_maps), dtype=torch.int32).pin_memory() for _ in range(nb_slots)]
+    pinned_hist = [(torch.empty((args.batch, 511), dtype=torch.int32).pin_memory(), torch.empty(args.batch, dtype=torch.int32).pin_memory())
+                   for _ in range(nb_slots)]
     slot_free = [threading.Event() for _ in range(nb_slots)]
     for e in slot_free:
         e.set()
-    worker = CoderWorker(probabilities, coder_threads)
+    worker = RateWorker(map_size)
     worker.start()
-    copy_stream = torch.cuda.Stream()
+    encode_stream = torch.cuda.Stream()
+    verify_stream = torch.cuda.Stream()
     sse_total = torch.zeros(args.batch, dtype=torch.int64, device=device)
     dead_total = torch.zeros(1, dtype=torch.int64, device=device)
-    exc_hists = []
     gemm_events = []            # (start, stop, launch name) around every conv_gemm launch of the timed region
 
     def timed_launch(name, fn, record):
@@ -162,18 +178,35 @@ def main():
         slot = index % nb_slots
         slot_free[slot].wait()
         slot_free[slot].clear()
-        # the single device -> host copy, on its own stream so that it overlaps the decoder kernels
+        # exception map: exact histogram on the device; its entropy is formed on the host by the rate worker
+        (hist, overflow) = dev.symbol_histograms(q['symbols'][:, IDX_MAP_EXCEPTION:IDX_MAP_EXCEPTION + 1].contiguous(), 255)
         quantized = torch.cuda.Event()
         quantized.record()
-        with torch.cuda.stream(copy_stream):
-            copy_stream.wait_event(quantized)
-            pinned[slot].copy_(q['symbols'], non_blocking=True)
-            q['symbols'].record_stream(copy_stream)
+        # entropy coding off the transform stream, concurrent with the synthesis transforms below: every map is encoded
+        # (streams left in HBM), then decoded back and compared in a second launch on another stream (what
+        # compress_lossless + the assert of compression.py:146-153 do), which overlaps the NEXT batch's encode;
+        # then ONE small device -> host copy of the per-map bit counts / statuses
+        symbols = q['symbols'].view(n_maps, map_size)
+        with torch.cuda.stream(encode_stream):
+            encode_stream.wait_event(quantized)
+            if not os.environ.get('EAE_BENCH_NO_CODER'):      # diagnostic only: transforms without the coder
+                dev.coder_compress_maps(symbols, probabilities_dev, prob_row, TRUNCATED_UNARY_LENGTH,
+                                        mode=dev.CODER_ENCODE_ONLY, out=streams[slot], lanes_per_wave=args.coder_lanes)
+            encoded = torch.cuda.Event()
+            encoded.record()
+        with torch.cuda.stream(verify_stream):
+            verify_stream.wait_event(encoded)
+            if not os.environ.get('EAE_BENCH_NO_CODER'):
+                dev.coder_verify_maps(streams[slot], symbols, probabilities_dev, prob_row, args.coder_lanes)
+            pinned_results[slot].copy_(streams[slot].results, non_blocking=True)
+            pinned_hist[slot][0].copy_(hist, non_blocking=True)
+            pinned_hist[slot][1].copy_(overflow, non_blocking=True)
             copied = torch.cuda.Event()
             copied.record()
-        worker.jobs.put((copied, pinned[slot], slot_free[slot]))
-        # exception map: exact histogram on the device, entropy on the host after the timed region's sync
-        exc_hists.append(dev.symbol_histograms(q['symbols'][:, IDX_MAP_EXCEPTION:IDX_MAP_EXCEPTION + 1].contiguous(), 255))
+        for t_ in (q['symbols'], hist, overflow):
+            t_.record_stream(encode_stream)
+            t_.record_stream(verify_stream)
+        worker.jobs.put((copied, pinned_results[slot], pinned_hist[slot][0], pinned_hist[slot][1], slot_free[slot]))
         dead_total.add_((q['nonzero_flags'] == 0).sum())
         d = decoder.v
         t = dev.gdn(q['shifted'], decoder.g[4], d['decoder/beta_4'], inverse=True)
@@ -198,26 +231,24 @@ def main():
     for i in range(args.warmup):
         step(i, False)
     drain()
-    worker.results.clear()
-    del exc_hists[:]
+    worker.coder_bits = 0
+    worker.exception_bits = 0
     sse_total.zero_()
     dead_total.zero_()
     worker.busy_s = 0.
 
     barrier()
     t0 = time.perf_counter()
+    step_marks = []
     for i in range(args.steps):
+        if os.environ.get('EAE_BENCH_TRACE'):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            step_marks.append((time.perf_counter() - t0, ev))
         step(i, True)
     drain()
-    # exception map (compression.py:68-75): ceil(h*w*entropy) from the exact device histogram
-    exception_bits = 0
-    for (hist, overflow) in exc_hists:
-        if int(overflow.sum().item()) != 0:
-            raise RuntimeError('exception-map symbols outside the histogram radius')
-        for row in hist.cpu().numpy().astype(numpy.int64):
-            exception_bits += int(lossless_compression.exception_map_nb_bits(row, map_size))
     # the path's only exchange step: sum the rate / PSNR accumulators over ranks
-    coder_bits = float(sum(int(r.sum()) for r in worker.results)) + float(exception_bits)
+    coder_bits = float(worker.coder_bits) + float(worker.exception_bits)
     stats = torch.tensor([coder_bits, float(sse_total.sum().item()), float(dead_total.item()), float(args.steps*args.batch)],
                          dtype=torch.float64, device=device)
     if world > 1:
@@ -260,17 +291,20 @@ def main():
                    'truncated_unary_length': TRUNCATED_UNARY_LENGTH, 'idx_map_exception': IDX_MAP_EXCEPTION,
                    'weights': 'random-init fixed-bin-width architecture (trained checkpoints absent from the reference)',
                    'parallelism': 'image shards, one process per GPU' if world > 1 else 'single GPU',
-                   'coder_threads_per_rank': coder_threads},
+                   'coder': 'device, one map per lane, encode + decode + compare'},
         'images_per_s': round(nb_images_total/elapsed, 2),
         'rate_bpp': round(bpp, 5), 'psnr_db_pooled': round(mean_psnr, 4), 'dead_maps_per_image': round(stats[2].item()/nb_images_total, 3),
-        'coder_busy_fraction': round(worker.busy_s/elapsed, 3),
-        'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_kernel<128> (conv2+GDN2, conv3+GDN3, tconv1+IGDN5, tconv2+IGDN6)',
+        'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_wave_kernel (conv2+GDN2, conv3+GDN3, tconv1+IGDN5, tconv2+IGDN6)',
                      'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(achieved/PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
                      'avg_launch_ms': round(gemm_ms/max(gemm_launches, 1), 4),
                      'per_launch_ms': {k: round(sum(v)/len(v), 4) for (k, v) in per_launch_ms.items()},
                      'algorithmic_flop_per_launch': {k: flops[k]*pixels_per_step for k in flops}},
     }
+    if step_marks:
+        host = [round(m[0]*1e3, 2) for m in step_marks]
+        gpu = [round(step_marks[0][1].elapsed_time(m[1]), 2) for m in step_marks]
+        sys.stderr.write('TRACE host enqueue start (ms): {}\nTRACE gpu step start (ms): {}\nTRACE total ms {}\n'.format(host, gpu, round(elapsed*1e3, 2)))
     worker.jobs.put(None)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

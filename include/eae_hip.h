@@ -71,13 +71,14 @@ int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const float* bias,
 
 /* transpose_conv_3 (components.py:79-83; 9x9, 128->1, stride 4, 'SAME', no bias) fused with what follows it on the
  * path: tls.cast_bt601 (tools.py:93: uint8(round_half_even(clip(x,16,235)))) and the squared error of tls.psnr_2d
- * (tools.py:873-875). x: [N][h][w][128]; w_phase: [4 channel blocks][9][32][16] from eae_hip_pack_tconv9x9s4_weights;
+ * (tools.py:873-875). x: [N][h][w][128]; w_phase: 18432 floats from eae_hip_pack_tconv9x9s4_weights;
  * out_f32 (nullable): [N][4h][4w] float reconstruction; out_u8 (nullable): [N][4h][4w] BT.601 cast;
  * ref_u8 + sse (both nullable): sse[i] += sum over image i of (ref - out_u8)^2, exact uint64 (caller zeroes). */
 int eae_hip_tconv9x9s4_luma(const float* x, const float* w_phase, float* out_f32, uint8_t* out_u8,
                             const uint8_t* ref_u8, uint64_t* sse, int n, int h, int w_in, void* stream);
 
-/* TF filter [9][9][1][128] -> [4 channel blocks][9 neighbours][32][16 output phases] (zeros where a phase has no tap). */
+/* TF filter [9][9][1][128] -> per-lane MFMA fragments [4 channel blocks][9 neighbours][64 lanes][8] (zeros where an
+ * output phase has no tap). */
 int eae_hip_pack_tconv9x9s4_weights(const float* w_tf, float* w_phase, void* stream);
 
 /* Kernel-side layouts, packed once per model on the device. "Packed" channel order: out channel c sits at position
@@ -136,6 +137,40 @@ int eae_hip_cast_int16(const float* x, int16_t* out, int64_t count, uint32_t* ra
  * int16). hist and overflow are ACCUMULATED into: the caller zeroes them. */
 int eae_hip_symbol_histograms(const int16_t* symbols_planar, uint32_t* hist, int hist_radius, uint32_t* overflow,
                               int n_maps, int map_size, void* stream);
+
+/* ---- lossless coder on the device: one feature map per lane --------------------------------------------------------
+ * Replaces the per-map compress_lossless loop of lossless/compression.py:76-81 (and, underneath it,
+ * lossless/c++/source/compression.cpp:3-65) for a whole batch of images whose symbols are already in HBM
+ * (symbols_planar of eae_hip_quantize_maps). Same arguments and stream layout as the HOST entry points
+ * eae_coder_compress_maps / eae_coder_encode_maps / eae_coder_decode_maps of include/eae_coder.h, every pointer a
+ * DEVICE pointer; same source for the arithmetic (csrc/coder/coder_core.h), so bits, bytes, bit counts and error codes
+ * are identical to the host library's and therefore to the reference's.
+ *   symbols [n_maps][map_size] int16; probs [rows][L] float64; prob_row[m] = row for map m, < 0 skips the map
+ *   (exception map: 0 bits, verbatim copy when `reconstruction` is given), NULL = row m;
+ *   streams: n_maps regions of `stride` bytes, BAC bytes at +0, bypass bytes at +stride/2 (stride from
+ *   eae_hip_coder_stream_stride_bytes; 8-byte aligned base); bac_bits/bypass_bits/status/stage: per map.
+ *   mode: 0 encode + decode into `reconstruction`; 1 encode only; 2 encode + decode + compare in registers
+ *   (status 6 = EAE_ROUNDTRIP_MISMATCH). lanes_per_wave: maps per 64-thread block (1..64, <= 0 -> 8): fewer lanes =
+ *   more blocks over more CUs and less divergence per wave.
+ * Returns 0, -1 (NULL argument / bad mode), 1 (stride too small: EAE_CAPACITY_ERROR) or a hipError_t. Per-map failures
+ * are reported in status[] (the launch is asynchronous). */
+uint64_t eae_hip_coder_stream_stride_bytes(uint32_t map_size, uint8_t truncated_unary_length);
+int eae_hip_coder_compress_maps(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, int16_t* reconstruction,
+                                uint8_t truncated_unary_length, const double* probabilities, const int32_t* prob_row,
+                                uint8_t* streams, uint64_t stream_stride_bytes, uint32_t* bac_bits, uint32_t* bypass_bits,
+                                int32_t* status, int32_t* stage, int mode, int lanes_per_wave, void* stream);
+int eae_hip_coder_decode_maps(uint32_t n_maps, uint32_t map_size, int16_t* symbols_out, uint8_t truncated_unary_length,
+                              const double* probabilities, const int32_t* prob_row, const uint8_t* streams,
+                              uint64_t stream_stride_bytes, const uint32_t* bac_bits, const uint32_t* bypass_bits,
+                              int32_t* status, int32_t* stage, int lanes_per_wave, void* stream);
+/* The second half of compress_lossless as its own launch (so that it can run on another stream, concurrently with the
+ * next batch's encode): decodes every map from its streams and compares with `expected` (the symbols that were
+ * encoded) in registers. status[m] = 6 (EAE_ROUNDTRIP_MISMATCH) or a decoder error; maps whose status is already
+ * non-zero (failed encode) and skipped maps are left alone. */
+int eae_hip_coder_verify_maps(uint32_t n_maps, uint32_t map_size, const int16_t* expected, uint8_t truncated_unary_length,
+                              const double* probabilities, const int32_t* prob_row, const uint8_t* streams,
+                              uint64_t stream_stride_bytes, const uint32_t* bac_bits, const uint32_t* bypass_bits,
+                              int32_t* status, int32_t* stage, int lanes_per_wave, void* stream);
 
 /* Diagnostic hook (not part of the path): when given a device buffer of grid * waves * 8 uint64, the conv GEMM kernel
  * records s_memtime stamps per wave (start, loop start, loop end, GDN end, end, K-steps, XCC id, HW id). NULL disables. */

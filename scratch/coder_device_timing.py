@@ -1,0 +1,62 @@
+"""Times the device coder on the bench's own symbols (24 Kodak-sized images) for several lanes-per-wave settings."""
+import os, sys, time
+import numpy, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from autoencoder_based_image_compression_amd import device as dev, pipeline
+from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+from autoencoder_based_image_compression_amd.kodak.lossless import stats as lossless_stats
+
+variables = bench.synthetic_model(1.)
+enc = pipeline.DeviceEncoder(variables, False, 'cuda')
+images = torch.from_numpy(bench.synthetic_images(1000, 24, 512, 768)).cuda()
+y = enc(images)
+mm = dev.map_means(y).cpu().numpy()
+probs = lossless_stats.compute_binary_probabilities(y.cpu().numpy(), variables[var.BIN_WIDTHS_NAME], mm, 10)
+q = dev.quantize_maps(y, torch.from_numpy(variables[var.BIN_WIDTHS_NAME]).cuda(), torch.from_numpy(mm).cuda(), want_shifted=False, want_symbols=True, want_flags=False)
+sym = q['symbols'].reshape(-1, 1536)
+p = torch.from_numpy(probs).cuda()
+rows = torch.arange(128, dtype=torch.int32).repeat(24)
+rows[67::128] = -1
+rows = rows.cuda()
+print('abs mean', sym.abs().float().mean().item(), 'max', sym.abs().max().item())
+for mode in (1, 2, 3):
+    for lanes in (1, 2, 8, 64):
+        (s, _) = dev.coder_compress_maps(sym, p, rows, 10, mode=min(mode, 2), lanes_per_wave=lanes)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            if mode == 3:
+                dev.coder_verify_maps(s, sym, p, rows, lanes)
+            else:
+                dev.coder_compress_maps(sym, p, rows, 10, mode=mode, out=s, lanes_per_wave=lanes)
+        b.record(); torch.cuda.synchronize()
+        print('mode', mode, 'lanes', lanes, 'ms', round(a.elapsed_time(b)/5, 3), 'bits', int(s.nb_bits().sum().item()), 'errors', int((s.status != 0).sum().item()))
+nb = s.nb_bits().cpu().numpy().astype(numpy.int64)
+a = sym.abs().to(torch.int64)
+dec = (torch.clamp(a, max=10) + (a < 10).to(torch.int64)).sum(1).cpu().numpy()
+nz = (a != 0).sum(1).cpu().numpy()
+order = numpy.argsort(nb)[::-1][:8]
+print('bits per map: mean', nb.mean(), 'p50', numpy.percentile(nb, 50), 'p99', numpy.percentile(nb, 99), 'max', nb.max())
+print('densest maps (map, bits, decisions, nonzeros):', [(int(m), int(nb[m]), int(dec[m]), int(nz[m])) for m in order])
+print('decisions per map: mean', dec.mean(), 'max', dec.max())
+def timeit(symbols, mode, lanes=1):
+    (s2, _) = dev.coder_compress_maps(symbols, p, rows, 10, mode=min(mode, 2), lanes_per_wave=lanes)
+    torch.cuda.synchronize()
+    a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a_.record()
+    for _ in range(5):
+        if mode == 3:
+            dev.coder_verify_maps(s2, symbols, p, rows, lanes)
+        else:
+            dev.coder_compress_maps(symbols, p, rows, 10, mode=mode, out=s2, lanes_per_wave=lanes)
+    b_.record(); torch.cuda.synchronize()
+    return round(a_.elapsed_time(b_)/5, 3)
+zeros = torch.zeros_like(sym)
+ones = torch.ones_like(sym)
+few = sym[:64].contiguous()
+print('all-zero symbols: encode', timeit(zeros, 1), 'verify', timeit(zeros, 3))
+print('all-one symbols: encode', timeit(ones, 1), 'verify', timeit(ones, 3))
+rows = rows[:64].contiguous()
+print('64 maps only: encode', timeit(few, 1), 'verify', timeit(few, 3))

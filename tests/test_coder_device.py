@@ -1,0 +1,212 @@
+"""The lossless coder on the GPU (eae_hip_coder_compress_maps / eae_hip_coder_decode_maps, one map per lane) against the
+host C-ABI coder (itself pinned to the reference's C++ coder by tests/test_coder_host.py), the C oracle and the golden
+streams produced by the real reference build: bit counts, stream BYTES, decoded symbols, error codes and stages are
+identical."""
+import os
+
+import numpy
+import pytest
+import torch
+
+from autoencoder_based_image_compression_amd import _native
+from oracle import coder as oc
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'coder_golden.npz')
+
+
+@pytest.fixture(scope='module')
+def gold():
+    with numpy.load(GOLD, allow_pickle=False) as g:
+        return {k: g[k] for k in g.files}
+
+
+@pytest.fixture(scope='module')
+def dev():
+    from autoencoder_based_image_compression_amd import device
+    return device
+
+
+def host_encode_maps(planar, probs, prob_row):
+    """eae_coder_encode_maps on the host: (streams [n, stride], bac_bits, bypass_bits, status, stage)."""
+    lib = _native.coder()
+    (n, size) = planar.shape
+    L = probs.shape[1]
+    stride = int(_native.hip().eae_hip_coder_stream_stride_bytes(size, L))
+    streams = numpy.zeros((n, stride), dtype=numpy.uint8)
+    (bac, byp) = (numpy.zeros(n, dtype=numpy.uint32), numpy.zeros(n, dtype=numpy.uint32))
+    (status, stage) = (numpy.zeros(n, dtype=numpy.int32), numpy.zeros(n, dtype=numpy.int32))
+    pp = numpy.ascontiguousarray(probs, dtype=numpy.float64)
+    rows = numpy.ascontiguousarray(prob_row, dtype=numpy.int32)
+    lib.eae_coder_encode_maps(n, size, _native.ptr(planar, _native.c_i16p), L, _native.ptr(pp, _native.c_f64p),
+                              _native.ptr(rows, _native.c_i32p), _native.ptr(streams, _native.c_u8p), stride,
+                              _native.ptr(bac, _native.c_u32p), _native.ptr(byp, _native.c_u32p),
+                              _native.ptr(status, _native.c_i32p), _native.ptr(stage, _native.c_i32p), 4)
+    return streams, bac, byp, status, stage
+
+
+def device_code(dev, planar, probs, prob_row, mode, lanes=0):
+    sym = torch.from_numpy(planar).cuda()
+    p = torch.from_numpy(numpy.ascontiguousarray(probs, dtype=numpy.float64)).cuda()
+    rows = torch.from_numpy(numpy.ascontiguousarray(prob_row, dtype=numpy.int32)).cuda()
+    (streams, rec) = dev.coder_compress_maps(sym, p, rows, probs.shape[1], mode=mode, lanes_per_wave=lanes)
+    torch.cuda.synchronize()
+    return streams, rec, p, rows
+
+
+def valid_bytes_equal(a, b, bits):
+    nbytes = (int(bits) + 7)//8
+    return numpy.array_equal(a[:nbytes], b[:nbytes])
+
+
+@pytest.mark.parametrize('lanes', [1, 8, 64])
+def test_streams_bits_and_symbols_equal_the_host_coder(gold, dev, lanes):
+    rng = numpy.random.RandomState(3)
+    probs = gold['real_probabilities_1']
+    planar = numpy.round(rng.laplace(size=(3*128, 96))*numpy.tile(rng.uniform(0.1, 4., size=128), 3)[:, None]).astype(numpy.int16)
+    prob_row = numpy.tile(numpy.arange(128, dtype=numpy.int32), 3)
+    prob_row[67::128] = -1
+    (h_streams, h_bac, h_byp, h_status, _) = host_encode_maps(planar, probs, prob_row)
+    assert not h_status.any()
+    (streams, rec, p, rows) = device_code(dev, planar, probs, prob_row, dev.CODER_ROUNDTRIP, lanes)
+    assert not streams.status.cpu().numpy().any()
+    assert numpy.array_equal(streams.bac_bits.cpu().numpy().astype(numpy.uint32), h_bac)
+    assert numpy.array_equal(streams.bypass_bits.cpu().numpy().astype(numpy.uint32), h_byp)
+    assert numpy.array_equal(rec.cpu().numpy(), planar)            # skipped maps are copied verbatim
+    d = streams.streams.cpu().numpy()
+    half = streams.stride//2
+    for m in range(planar.shape[0]):
+        assert valid_bytes_equal(d[m], h_streams[m], h_bac[m]), m
+        assert valid_bytes_equal(d[m, half:], h_streams[m, half:], h_byp[m]), m
+    # the decoder on its own, from the device streams and from the HOST streams
+    out = dev.coder_decode_maps(streams, p, rows, lanes).cpu().numpy()
+    keep = prob_row >= 0
+    assert numpy.array_equal(out[keep], planar[keep]) and not out[~keep].any()
+    streams.streams.copy_(torch.from_numpy(h_streams))
+    out = dev.coder_decode_maps(streams, p, rows, lanes).cpu().numpy()
+    assert numpy.array_equal(out[keep], planar[keep])
+    # one map against the C oracle directly
+    ref = oc.CoderLib('oracle').compress_lossless(planar[9], probs[9], want_streams=True)
+    assert (int(h_bac[9]), int(h_byp[9])) == (ref[2]['bac_bits'], ref[2]['bypass_bits'])
+    assert numpy.array_equal(d[9, :ref[2]['bac_bytes'].size], ref[2]['bac_bytes'])
+    assert numpy.array_equal(d[9, half:half + ref[2]['bypass_bytes'].size], ref[2]['bypass_bytes'])
+
+
+def test_golden_streams_of_the_reference_build(gold, dev):
+    """tests/golden/coder_golden.npz: streams dumped from the reference's own C++ classes (oracle/gen_golden.py)."""
+    for i in range(int(gold['nb_cases'])):
+        x = numpy.ascontiguousarray(gold['case{}_in'.format(i)]).reshape(1, -1)
+        p = gold['case{}_p'.format(i)].reshape(1, -1)
+        if x.size == 0:
+            continue
+        (streams, rec, _, _) = device_code(dev, x, p, numpy.zeros(1, dtype=numpy.int32), dev.CODER_ROUNDTRIP)
+        assert int(streams.status.item()) == 0, i
+        assert (int(streams.bac_bits.item()), int(streams.bypass_bits.item())) == (int(gold['case{}_bac_bits'.format(i)]),
+                                                                                  int(gold['case{}_byp_bits'.format(i)])), i
+        d = streams.streams.cpu().numpy()[0]
+        (bac, byp) = (gold['case{}_bac'.format(i)], gold['case{}_byp'.format(i)])
+        assert numpy.array_equal(d[:bac.size], bac) and numpy.array_equal(d[streams.stride//2:streams.stride//2 + byp.size], byp), i
+        assert numpy.array_equal(rec.cpu().numpy(), x), i
+
+
+def test_error_codes_and_stages_equal_the_host_coder(gold, dev):
+    """Capacity / probability / out-of-range failures: same per-map status and stage as the host library, whose
+    messages tests/test_coder_host.py pins to the reference's (compression.cpp:32-62)."""
+    seen = set()
+    for i in range(int(gold['nb_err_cases'])):
+        x = numpy.ascontiguousarray(gold['err{}_in'.format(i)]).reshape(1, -1)
+        p = gold['err{}_p'.format(i)].reshape(1, -1)
+        if x.size == 0 or p.size == 0:
+            continue
+        (_, _, _, h_status, h_stage) = host_encode_maps(x, p, numpy.zeros(1, dtype=numpy.int32))
+        (streams, _, _, _) = device_code(dev, x, p, numpy.zeros(1, dtype=numpy.int32), dev.CODER_ROUNDTRIP_VERIFY)
+        if h_status[0] != 0:       # encode-side failures are what encode_maps can show
+            assert (int(streams.status.item()), int(streams.stage.item())) == (int(h_status[0]), int(h_stage[0])), i
+        seen.add(int(streams.status.item()))
+    assert {1, 4} <= seen          # capacity and probability errors are both exercised by the golden cases
+    # mixed launch: one bad map does not disturb its neighbours
+    planar = numpy.zeros((4, 16), dtype=numpy.int16)
+    planar[2] = 3
+    probs = numpy.full((4, 5), 0.5)
+    probs[2, 1] = numpy.nan
+    (streams, _, _, _) = device_code(dev, planar, probs, numpy.arange(4), dev.CODER_ROUNDTRIP_VERIFY)
+    assert streams.status.cpu().tolist() == [0, 0, 4, 0] and streams.stage.cpu().tolist() == [0, 0, 1, 0]
+
+
+def test_fuzz_against_host_coder_and_oracle(dev):
+    orc = oc.CoderLib('oracle')
+    rng = numpy.random.RandomState(77)
+    for t in range(120):
+        n_maps = int(rng.randint(1, 9))
+        size = int(rng.randint(1, 300))
+        L = int(rng.randint(1, 60))
+        scale = rng.choice([0.2, 1, 3, 10, 100, 5000], size=(n_maps, 1))
+        planar = numpy.clip(numpy.round(rng.laplace(size=(n_maps, size))*scale), -32768, 32767).astype(numpy.int16)
+        probs = numpy.clip(rng.rand(n_maps, L), 0.005, 0.995)
+        rows = numpy.arange(n_maps, dtype=numpy.int32)
+        (h_streams, h_bac, h_byp, h_status, h_stage) = host_encode_maps(planar, probs, rows)
+        (streams, _, _, _) = device_code(dev, planar, probs, rows, dev.CODER_ROUNDTRIP_VERIFY, lanes=int(rng.choice([1, 4, 64])))
+        status = streams.status.cpu().numpy()
+        assert numpy.array_equal(status, h_status), t
+        assert numpy.array_equal(streams.stage.cpu().numpy(), h_stage), t
+        ok = status == 0
+        assert numpy.array_equal(streams.bac_bits.cpu().numpy()[ok], h_bac[ok].astype(numpy.int32))
+        assert numpy.array_equal(streams.bypass_bits.cpu().numpy()[ok], h_byp[ok].astype(numpy.int32))
+        d = streams.streams.cpu().numpy()
+        half = streams.stride//2
+        for m in numpy.nonzero(ok)[0]:
+            assert valid_bytes_equal(d[m], h_streams[m], h_bac[m]) and valid_bytes_equal(d[m, half:], h_streams[m, half:], h_byp[m]), (t, m)
+        if ok[0]:
+            assert orc.compress_lossless(planar[0], probs[0])[1] == int(h_bac[0] + h_byp[0])
+
+
+def test_full_kodak_batch_verifies_on_the_device(gold, dev):
+    """BASELINE.json configs[1] size: 24 images x 128 maps of 32x48 symbols, roundtrip verified in registers; bit counts
+    equal the threaded host coder's."""
+    from autoencoder_based_image_compression_amd.kodak.lossless import compression
+    rng = numpy.random.RandomState(11)
+    probs = gold['real_probabilities_1']
+    planar = numpy.round(rng.laplace(size=(24, 128, 1536))*rng.uniform(0.05, 6., size=(1, 128, 1))).astype(numpy.int16)
+    prob_row = numpy.tile(numpy.arange(128, dtype=numpy.int32), 24)
+    prob_row[67::128] = -1
+    (_, nb_bits) = compression.code_planar_symbols(planar, probs, idx_map_exception=67, nb_threads=8, roundtrip=False)
+    (streams, _, _, _) = device_code(dev, planar.reshape(-1, 1536), probs, prob_row, dev.CODER_ROUNDTRIP_VERIFY)
+    assert not streams.status.cpu().numpy().any()
+    assert numpy.array_equal(streams.nb_bits().cpu().numpy().reshape(24, 128), nb_bits.astype(numpy.int32))
+
+
+def test_verify_launch_detects_a_corrupted_stream(gold, dev):
+    """eae_hip_coder_verify_maps = the decode half of compress_lossless + the comparison of compression.py:146-153."""
+    rng = numpy.random.RandomState(5)
+    probs = gold['real_probabilities_1']
+    planar = numpy.round(rng.laplace(size=(128, 1536))*rng.uniform(0.3, 4., size=(128, 1))).astype(numpy.int16)
+    rows = numpy.arange(128, dtype=numpy.int32)
+    rows[67] = -1
+    (streams, _, p, r) = device_code(dev, planar, probs, rows, dev.CODER_ENCODE_ONLY)
+    sym = torch.from_numpy(planar).cuda()
+    dev.coder_verify_maps(streams, sym, p, r)
+    assert not streams.status.cpu().numpy().any()
+    streams.streams[5, 3] ^= 0x10            # one flipped bit in the arithmetic-coded stream of map 5
+    streams.streams[67, 0] ^= 0xFF           # the skipped map's region is never read
+    dev.coder_verify_maps(streams, sym, p, r)
+    status = streams.status.cpu().numpy()
+    assert status[5] != 0 and not numpy.delete(status, 5).any()
+    # a failed encode is not overwritten by the verify launch
+    streams.status[9] = 1
+    dev.coder_verify_maps(streams, sym, p, r)
+    assert int(streams.status[9].item()) == 1
+
+
+def test_argument_checks(dev):
+    lib = _native.hip()
+    assert lib.eae_hip_coder_compress_maps(1, 4, None, None, 3, None, None, None, 64, None, None, None, None, 1, 0, None) == -1
+    sym = torch.zeros((1, 64), dtype=torch.int16, device='cuda')
+    p = torch.full((1, 10), 0.5, dtype=torch.float64, device='cuda')
+    s = dev.CoderStreams(1, 64, 10, sym.device)
+    # a stride below capacity + slack is refused before any work, like eae_coder_encode_maps
+    rc = lib.eae_hip_coder_compress_maps(1, 64, sym.data_ptr(), None, 10, p.data_ptr(), None, s.streams.data_ptr(), 64,
+                                         s.bac_bits.data_ptr(), s.bypass_bits.data_ptr(), s.status.data_ptr(), None, 1, 0, None)
+    assert rc == 1
+    with pytest.raises(TypeError):
+        dev.coder_compress_maps(sym.int(), p, None, 10)

@@ -93,23 +93,42 @@ __device__ __forceinline__ bool decode_zero_fast(Bac& b, double p0) {
 // Probabilities of the lanes of a block, interleaved in LDS ([i][lane]: conflict-free, one ds_read per decision instead of a
 // global load on the serial chain). Each lane reads back only what it wrote itself.
 extern __shared__ double lds_probabilities[];
+template <bool UNIFORM>
 __device__ __forceinline__ void stage_probabilities(LosslessCoder& c, const CoderParams& p, int32_t row) {
-    double* mine = lds_probabilities + threadIdx.x;
+    const uint32_t stride = UNIFORM ? 1u : p.lanes;
+    double* mine = lds_probabilities + (UNIFORM ? 0u : threadIdx.x);
     const double* src = p.probs + (size_t)row * p.L;
-    for (uint32_t i = 0; i < p.L; i++) mine[i * p.lanes] = src[i];
+    for (uint32_t i = 0; i < p.L; i++) mine[i * stride] = src[i];
     c.L = p.L;
-    c.prob_stride = p.lanes;
+    c.prob_stride = stride;
     c.probabilities = mine;
 }
 
+// Which map a thread codes. UNIFORM = one wavefront per map, every lane computing the same thing: all coder state is
+// then wave-uniform, the compiler keeps it in SGPRs, runs the integer state machine on the scalar unit and branches
+// without touching the exec mask; a wave needs few VGPRs, so it fits next to the transform kernels' waves without
+// lowering their occupancy. Otherwise `lanes` maps per 64-thread block, one per lane.
+template <bool UNIFORM>
+__device__ __forceinline__ bool map_of_thread(const CoderParams& p, uint32_t& m) {
+    if (UNIFORM) {
+        m = blockIdx.x;
+        return true;
+    }
+    if (threadIdx.x >= p.lanes) return false;
+    m = blockIdx.x * p.lanes + threadIdx.x;
+    return m < p.n_maps;
+}
+
 // MODE: 0 = encode + decode into `reconstruction`; 1 = encode only; 2 = encode + decode + compare (status MISMATCH).
-template <int MODE>
+template <int MODE, bool UNIFORM>
 __global__ __launch_bounds__(64) void coder_maps_kernel(const CoderParams p) {
     // a handful of latency-bound waves next to the transforms' MFMA waves: let them issue whenever they are ready
     __builtin_amdgcn_s_setprio(EAE_CODER_PRIO);
-    if (threadIdx.x >= p.lanes) return;
-    const uint32_t m = blockIdx.x * p.lanes + threadIdx.x;
-    if (m >= p.n_maps) return;
+#ifdef EAE_CODER_DEBUG_CLOCKS
+    const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    uint32_t m;
+    if (!map_of_thread<UNIFORM>(p, m)) return;
     const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
     const int16_t* in = p.symbols + (size_t)m * p.map_size;
     int st = STAGE_NONE, s = OK;
@@ -123,7 +142,7 @@ __global__ __launch_bounds__(64) void coder_maps_kernel(const CoderParams p) {
         c.bac.init();
         c.bac.bs.init_writer(p.streams + (uint64_t)m * p.stride, req);
         c.bypass.init_writer(p.streams + (uint64_t)m * p.stride + p.stride / 2, req);
-        stage_probabilities(c, p, row);
+        stage_probabilities<UNIFORM>(c, p, row);
         SymbolReader rd;
         rd.init(in, p.map_size);
         // LosslessCoder::encode_map with the wide symbol reader
@@ -168,17 +187,20 @@ __global__ __launch_bounds__(64) void coder_maps_kernel(const CoderParams p) {
     p.bypass_bits[m] = nbyp;
     p.status[m] = s;
     if (p.stage) p.stage[m] = st;
+#ifdef EAE_CODER_DEBUG_CLOCKS
+    p.stage[m] = (int)(__builtin_amdgcn_s_memtime() - dbg_t0);
+    p.bypass_bits[m] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
+#endif
 }
 
 // The decoder side on its own: streams + bit lengths -> symbols (COMPARE = false), or -> a comparison with the symbols
 // that were encoded (COMPARE = true: nothing is stored, status MISMATCH on a difference, maps whose status is already
 // non-zero -- a failed encode -- are left alone).
-template <bool COMPARE>
+template <bool COMPARE, bool UNIFORM>
 __global__ __launch_bounds__(64) void decoder_maps_kernel(const CoderParams p) {
     __builtin_amdgcn_s_setprio(EAE_CODER_PRIO);
-    if (threadIdx.x >= p.lanes) return;
-    const uint32_t m = blockIdx.x * p.lanes + threadIdx.x;
-    if (m >= p.n_maps) return;
+    uint32_t m;
+    if (!map_of_thread<UNIFORM>(p, m)) return;
     const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
     if (COMPARE && p.status[m] != 0) return;
     int st = STAGE_NONE, s = OK;
@@ -187,7 +209,7 @@ __global__ __launch_bounds__(64) void decoder_maps_kernel(const CoderParams p) {
         c.bac.init();
         c.bac.bs.init_reader(p.streams + (uint64_t)m * p.stride, p.bac_bits[m]);
         c.bypass.init_reader(p.streams + (uint64_t)m * p.stride + p.stride / 2, p.bypass_bits[m]);
-        stage_probabilities(c, p, row);
+        stage_probabilities<UNIFORM>(c, p, row);
         const double p0 = p.L ? c.probability(0) : 0.;
         const bool fast = p0 > 0. && p0 < 1.;
         s = c.bac.start_decoding();
@@ -220,6 +242,23 @@ int check_layout(uint32_t map_size, uint8_t L, const uint8_t* streams, uint64_t 
     return 0;
 }
 
+// lanes_per_wave: 1..64 = that many maps per 64-thread block, one per lane; <= 0 = one wavefront per map (uniform).
+struct Geometry {
+    bool uniform;
+    uint32_t lanes;
+    dim3 grid, block;
+    size_t lds;
+};
+Geometry geometry(uint32_t n_maps, uint8_t L, int lanes_per_wave) {
+    Geometry g;
+    g.uniform = lanes_per_wave <= 0;
+    g.lanes = g.uniform ? 1u : (uint32_t)(lanes_per_wave > 64 ? 64 : lanes_per_wave);
+    g.grid = dim3((n_maps + g.lanes - 1) / g.lanes);
+    g.block = dim3(64);
+    g.lds = (size_t)g.lanes * L * sizeof(double);
+    return g;
+}
+
 }  // namespace
 
 extern "C" {
@@ -237,16 +276,16 @@ int eae_hip_coder_compress_maps(uint32_t n_maps, uint32_t map_size, const int16_
     if (mode < 0 || mode > 2 || (mode == 0 && !reconstruction)) return -1;
     if (check_layout(map_size, L, streams, stride)) return 1;
     if (n_maps == 0) return 0;
-    if (lanes_per_wave <= 0) lanes_per_wave = 8;
-    if (lanes_per_wave > 64) lanes_per_wave = 64;
-    CoderParams p{n_maps, map_size, L, (uint32_t)lanes_per_wave, symbols, reconstruction, probs, prob_row, streams, stride,
+    const Geometry g = geometry(n_maps, L, lanes_per_wave);
+    CoderParams p{n_maps, map_size, L, g.lanes, symbols, reconstruction, probs, prob_row, streams, stride,
                   bac_bits, bypass_bits, status, stage};
-    const dim3 grid((n_maps + p.lanes - 1) / p.lanes), block(64);
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)p.lanes * L * sizeof(double);
-    if (mode == 0) hipLaunchKernelGGL(coder_maps_kernel<0>, grid, block, lds, s, p);
-    else if (mode == 1) hipLaunchKernelGGL(coder_maps_kernel<1>, grid, block, lds, s, p);
-    else hipLaunchKernelGGL(coder_maps_kernel<2>, grid, block, lds, s, p);
+    // the scalar-cache loads of the one-wave-per-map form are not coherent with the stores of the same launch: only the
+    // encode-only mode uses it; the combined modes read their own streams back through the vector path
+    if (mode == 1 && g.uniform) hipLaunchKernelGGL((coder_maps_kernel<1, true>), g.grid, g.block, g.lds, s, p);
+    else if (mode == 0) hipLaunchKernelGGL((coder_maps_kernel<0, false>), g.grid, g.block, g.lds, s, p);
+    else if (mode == 1) hipLaunchKernelGGL((coder_maps_kernel<1, false>), g.grid, g.block, g.lds, s, p);
+    else hipLaunchKernelGGL((coder_maps_kernel<2, false>), g.grid, g.block, g.lds, s, p);
     return (int)hipGetLastError();
 }
 
@@ -255,13 +294,12 @@ int eae_hip_coder_decode_maps(uint32_t n_maps, uint32_t map_size, int16_t* symbo
                               const uint32_t* bypass_bits, int32_t* status, int32_t* stage, int lanes_per_wave, void* stream) {
     if (!symbols_out || !probs || !streams || !bac_bits || !bypass_bits || !status) return -1;
     if (n_maps == 0) return 0;
-    if (lanes_per_wave <= 0) lanes_per_wave = 8;
-    if (lanes_per_wave > 64) lanes_per_wave = 64;
-    CoderParams p{n_maps, map_size, L, (uint32_t)lanes_per_wave, nullptr, symbols_out, probs, prob_row,
+    const Geometry g = geometry(n_maps, L, lanes_per_wave);
+    CoderParams p{n_maps, map_size, L, g.lanes, nullptr, symbols_out, probs, prob_row,
                   const_cast<uint8_t*>(streams), stride, const_cast<uint32_t*>(bac_bits), const_cast<uint32_t*>(bypass_bits),
                   status, stage};
-    const dim3 grid((n_maps + p.lanes - 1) / p.lanes), block(64);
-    hipLaunchKernelGGL(decoder_maps_kernel<false>, grid, block, (size_t)p.lanes * L * sizeof(double), (hipStream_t)stream, p);
+    if (g.uniform) hipLaunchKernelGGL((decoder_maps_kernel<false, true>), g.grid, g.block, g.lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((decoder_maps_kernel<false, false>), g.grid, g.block, g.lds, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 
@@ -270,13 +308,12 @@ int eae_hip_coder_verify_maps(uint32_t n_maps, uint32_t map_size, const int16_t*
                               const uint32_t* bypass_bits, int32_t* status, int32_t* stage, int lanes_per_wave, void* stream) {
     if (!expected || !probs || !streams || !bac_bits || !bypass_bits || !status) return -1;
     if (n_maps == 0) return 0;
-    if (lanes_per_wave <= 0) lanes_per_wave = 8;
-    if (lanes_per_wave > 64) lanes_per_wave = 64;
-    CoderParams p{n_maps, map_size, L, (uint32_t)lanes_per_wave, expected, nullptr, probs, prob_row,
+    const Geometry g = geometry(n_maps, L, lanes_per_wave);
+    CoderParams p{n_maps, map_size, L, g.lanes, expected, nullptr, probs, prob_row,
                   const_cast<uint8_t*>(streams), stride, const_cast<uint32_t*>(bac_bits), const_cast<uint32_t*>(bypass_bits),
                   status, stage};
-    const dim3 grid((n_maps + p.lanes - 1) / p.lanes), block(64);
-    hipLaunchKernelGGL(decoder_maps_kernel<true>, grid, block, (size_t)p.lanes * L * sizeof(double), (hipStream_t)stream, p);
+    if (g.uniform) hipLaunchKernelGGL((decoder_maps_kernel<true, true>), g.grid, g.block, g.lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((decoder_maps_kernel<true, false>), g.grid, g.block, g.lds, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 

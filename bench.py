@@ -84,6 +84,11 @@ class RateWorker(threading.Thread):
                     raise RuntimeError('device coder: map {0} failed with status {1} at stage {2}'.format(bad, results[2, bad], results[3, bad]))
                 if int(overflow_host.numpy().sum()) != 0:
                     raise RuntimeError('exception-map symbols outside the histogram radius')
+                if os.environ.get('EAE_CODER_DEBUG_CLOCKS'):
+                    keep = results[1] > 0
+                    sys.stderr.write('CLOCKS shader-cycles mean {:.0f} max {} refclk-ticks mean {:.0f} -> MHz {:.0f}\n'.format(
+                        results[3][keep].mean(), results[3][keep].max(), results[1][keep].mean(),
+                        100.*results[3][keep].mean()/results[1][keep].mean()))
                 self.coder_bits += int(results[0].astype(numpy.int64).sum()) + int(results[1].astype(numpy.int64).sum())
                 self.exception_bits += sum(int(lossless_compression.exception_map_nb_bits(row, self.map_size))
                                            for row in hist_host.numpy().astype(numpy.int64))
@@ -101,8 +106,10 @@ def main():
     parser.add_argument('--warmup', type=int, default=5)
     parser.add_argument('--batch', type=int, default=24, help='Kodak-sized images per GPU per step')
     parser.add_argument('--no-cpu-baseline', action='store_true')
-    parser.add_argument('--coder-lanes', type=int, default=int(os.environ.get('EAE_CODER_LANES', '0')),
-                        help='maps per 64-thread block of the device coder (0 = library default)')
+    parser.add_argument('--coder-streams', type=int, default=int(os.environ.get('EAE_CODER_STREAMS', '2')),
+                        help='batches whose entropy coding may be in flight at once (each on its own HIP stream)')
+    parser.add_argument('--coder-lanes', type=int, default=int(os.environ.get('EAE_CODER_LANES', '8')),
+                        help='maps per 64-thread block of the device coder (0 = one wavefront per map)')
     args = parser.parse_args()
 
     # two Python threads share the GIL (kernel launches; rate bookkeeping): hand it over quickly
@@ -141,7 +148,7 @@ def main():
     prob_row[IDX_MAP_EXCEPTION::128] = -1
     prob_row = prob_row.to(device)
     n_maps = args.batch*128
-    nb_slots = 3
+    nb_slots = args.coder_streams + 2
     streams = [dev.CoderStreams(n_maps, map_size, TRUNCATED_UNARY_LENGTH, device) for _ in range(nb_slots)]
     pinned_results = [torch.empty((4, n_maps), dtype=torch.int32).pin_memory() for _ in range(nb_slots)]
     pinned_hist = [(torch.empty((args.batch, 511), dtype=torch.int32).pin_memory(), torch.empty(args.batch, dtype=torch.int32).pin_memory())
@@ -151,8 +158,7 @@ def main():
         e.set()
     worker = RateWorker(map_size)
     worker.start()
-    encode_stream = torch.cuda.Stream()
-    verify_stream = torch.cuda.Stream()
+    coder_streams = [torch.cuda.Stream() for _ in range(args.coder_streams)]
     sse_total = torch.zeros(args.batch, dtype=torch.int64, device=device)
     dead_total = torch.zeros(1, dtype=torch.int64, device=device)
     gemm_events = []            # (start, stop, launch name) around every conv_gemm launch of the timed region
@@ -182,21 +188,17 @@ def main():
         (hist, overflow) = dev.symbol_histograms(q['symbols'][:, IDX_MAP_EXCEPTION:IDX_MAP_EXCEPTION + 1].contiguous(), 255)
         quantized = torch.cuda.Event()
         quantized.record()
-        # entropy coding off the transform stream, concurrent with the synthesis transforms below: every map is encoded
-        # (streams left in HBM), then decoded back and compared in a second launch on another stream (what
-        # compress_lossless + the assert of compression.py:146-153 do), which overlaps the NEXT batch's encode;
-        # then ONE small device -> host copy of the per-map bit counts / statuses
+        # entropy coding off the transform stream, concurrent with the transforms of this and the next batches: every map
+        # is encoded (streams left in HBM), then decoded back and compared in a second launch (what compress_lossless +
+        # the assert of compression.py:146-153 do); then ONE small device -> host copy of the per-map bit counts /
+        # statuses. The coder is a few latency-bound waves: several batches are kept in flight on separate streams.
         symbols = q['symbols'].view(n_maps, map_size)
-        with torch.cuda.stream(encode_stream):
-            encode_stream.wait_event(quantized)
+        coder_stream = coder_streams[index % len(coder_streams)]
+        with torch.cuda.stream(coder_stream):
+            coder_stream.wait_event(quantized)
             if not os.environ.get('EAE_BENCH_NO_CODER'):      # diagnostic only: transforms without the coder
                 dev.coder_compress_maps(symbols, probabilities_dev, prob_row, TRUNCATED_UNARY_LENGTH,
                                         mode=dev.CODER_ENCODE_ONLY, out=streams[slot], lanes_per_wave=args.coder_lanes)
-            encoded = torch.cuda.Event()
-            encoded.record()
-        with torch.cuda.stream(verify_stream):
-            verify_stream.wait_event(encoded)
-            if not os.environ.get('EAE_BENCH_NO_CODER'):
                 dev.coder_verify_maps(streams[slot], symbols, probabilities_dev, prob_row, args.coder_lanes)
             pinned_results[slot].copy_(streams[slot].results, non_blocking=True)
             pinned_hist[slot][0].copy_(hist, non_blocking=True)
@@ -204,8 +206,7 @@ def main():
             copied = torch.cuda.Event()
             copied.record()
         for t_ in (q['symbols'], hist, overflow):
-            t_.record_stream(encode_stream)
-            t_.record_stream(verify_stream)
+            t_.record_stream(coder_stream)
         worker.jobs.put((copied, pinned_results[slot], pinned_hist[slot][0], pinned_hist[slot][1], slot_free[slot]))
         dead_total.add_((q['nonzero_flags'] == 0).sum())
         d = decoder.v

@@ -150,8 +150,9 @@ int eae_hip_symbol_histograms(const int16_t* symbols_planar, uint32_t* hist, int
  *   streams: n_maps regions of `stride` bytes, BAC bytes at +0, bypass bytes at +stride/2 (stride from
  *   eae_hip_coder_stream_stride_bytes; 8-byte aligned base); bac_bits/bypass_bits/status/stage: per map.
  *   mode: 0 encode + decode into `reconstruction`; 1 encode only; 2 encode + decode + compare in registers
- *   (status 6 = EAE_ROUNDTRIP_MISMATCH). lanes_per_wave: maps per 64-thread block (1..64, <= 0 -> 8): fewer lanes =
- *   more blocks over more CUs and less divergence per wave.
+ *   (status 6 = EAE_ROUNDTRIP_MISMATCH). lanes_per_wave: 1..64 = that many maps per 64-thread block, one per lane
+ *   (fewer lanes = more blocks over more CUs and less divergence per wave, but more wave-instructions in total);
+ *   <= 0 = one wavefront per map with wave-uniform state (scalar registers, ~20 VGPRs: shortest latency per map).
  * Returns 0, -1 (NULL argument / bad mode), 1 (stride too small: EAE_CAPACITY_ERROR) or a hipError_t. Per-map failures
  * are reported in status[] (the launch is asynchronous). */
 uint64_t eae_hip_coder_stream_stride_bytes(uint32_t map_size, uint8_t truncated_unary_length);

@@ -60,7 +60,7 @@ def valid_bytes_equal(a, b, bits):
     return numpy.array_equal(a[:nbytes], b[:nbytes])
 
 
-@pytest.mark.parametrize('lanes', [1, 8, 64])
+@pytest.mark.parametrize('lanes', [0, 1, 8, 64])
 def test_streams_bits_and_symbols_equal_the_host_coder(gold, dev, lanes):
     rng = numpy.random.RandomState(3)
     probs = gold['real_probabilities_1']
@@ -146,7 +146,7 @@ def test_fuzz_against_host_coder_and_oracle(dev):
         probs = numpy.clip(rng.rand(n_maps, L), 0.005, 0.995)
         rows = numpy.arange(n_maps, dtype=numpy.int32)
         (h_streams, h_bac, h_byp, h_status, h_stage) = host_encode_maps(planar, probs, rows)
-        (streams, _, _, _) = device_code(dev, planar, probs, rows, dev.CODER_ROUNDTRIP_VERIFY, lanes=int(rng.choice([1, 4, 64])))
+        (streams, _, _, _) = device_code(dev, planar, probs, rows, dev.CODER_ROUNDTRIP_VERIFY, lanes=int(rng.choice([0, 1, 4, 64])))
         status = streams.status.cpu().numpy()
         assert numpy.array_equal(status, h_status), t
         assert numpy.array_equal(streams.stage.cpu().numpy(), h_stage), t

@@ -30,6 +30,12 @@ HIP_SYMBOLS = {
                                        _vp, _vp, _vp, _vp, _i, _vp]),
     'eae_hip_coder_verify_maps': (_i, [ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_uint8, _vp, _vp, _vp, ctypes.c_uint64,
                                        _vp, _vp, _vp, _vp, _i, _vp]),
+    'eae_hip_coder_workspace_bytes': (ctypes.c_uint64, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint8]),
+    'eae_hip_coder_encode_batch': (_i, [ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_uint8, _vp, _vp, _vp, ctypes.c_uint64,
+                                        _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp]),
+    'eae_hip_coder_decode_batch': (_i, [ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, ctypes.c_uint8, _vp, _vp, _vp, ctypes.c_uint64,
+                                        _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp]),
+    'eae_hip_publish_to_host': (_i, [_vp, _vp, ctypes.c_uint64, _vp]),
     'eae_hip_debug_set_stamp_buffer': (_i, [_vp]),
     'eae_hip_cast_bt601': (_i, [_vp, _vp, _i64, _vp]),
     'eae_hip_sse_u8': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),

@@ -33,6 +33,7 @@ struct CoderParams {
     uint32_t* bypass_bits;
     int32_t* status;
     int32_t* stage;               // nullable
+    int32_t only_status;          // non-zero: code only the maps whose status currently holds this value (fallback pass)
 };
 
 // Eight int16 symbols per 16-byte load when the map is 16-byte aligned (every Kodak-sized map is), else one by one. The
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(64) void coder_maps_kernel(const CoderParams p) {
 #endif
     uint32_t m;
     if (!map_of_thread<UNIFORM>(p, m)) return;
+    if (p.only_status && p.status[m] != p.only_status) return;
     const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
     const int16_t* in = p.symbols + (size_t)m * p.map_size;
     int st = STAGE_NONE, s = OK;
@@ -201,8 +203,9 @@ __global__ __launch_bounds__(64) void decoder_maps_kernel(const CoderParams p) {
     __builtin_amdgcn_s_setprio(EAE_CODER_PRIO);
     uint32_t m;
     if (!map_of_thread<UNIFORM>(p, m)) return;
+    if (p.only_status && p.status[m] != p.only_status) return;
     const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
-    if (COMPARE && p.status[m] != 0) return;
+    if (COMPARE && !p.only_status && p.status[m] != 0) return;
     int st = STAGE_NONE, s = OK;
     if (row >= 0) {
         LosslessCoder c;
@@ -261,6 +264,26 @@ Geometry geometry(uint32_t n_maps, uint8_t L, int lanes_per_wave) {
 
 }  // namespace
 
+// Fallback passes of coder_simd.hip: the general per-lane kernels over the maps whose status holds `only_status`.
+int eae_coder_generic_encode(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, uint8_t L, const double* probs,
+                             const int32_t* prob_row, uint8_t* streams, uint64_t stride, uint32_t* bac_bits,
+                             uint32_t* bypass_bits, int32_t* status, int32_t* stage, int only_status, hipStream_t stream) {
+    const Geometry g = geometry(n_maps, L, 64);
+    CoderParams p{n_maps, map_size, L, g.lanes, symbols, nullptr, probs, prob_row, streams, stride,
+                  bac_bits, bypass_bits, status, stage, only_status};
+    hipLaunchKernelGGL((coder_maps_kernel<1, false>), g.grid, g.block, g.lds, stream, p);
+    return (int)hipGetLastError();
+}
+int eae_coder_generic_decode(uint32_t n_maps, uint32_t map_size, int16_t* out, uint8_t L, const double* probs,
+                             const int32_t* prob_row, const uint8_t* streams, uint64_t stride, const uint32_t* bac_bits,
+                             const uint32_t* bypass_bits, int32_t* status, int32_t* stage, int only_status, hipStream_t stream) {
+    const Geometry g = geometry(n_maps, L, 64);
+    CoderParams p{n_maps, map_size, L, g.lanes, nullptr, out, probs, prob_row, const_cast<uint8_t*>(streams), stride,
+                  const_cast<uint32_t*>(bac_bits), const_cast<uint32_t*>(bypass_bits), status, stage, only_status};
+    hipLaunchKernelGGL((decoder_maps_kernel<false, false>), g.grid, g.block, g.lds, stream, p);
+    return (int)hipGetLastError();
+}
+
 extern "C" {
 
 uint64_t eae_hip_coder_stream_stride_bytes(uint32_t map_size, uint8_t L) {
@@ -278,7 +301,7 @@ int eae_hip_coder_compress_maps(uint32_t n_maps, uint32_t map_size, const int16_
     if (n_maps == 0) return 0;
     const Geometry g = geometry(n_maps, L, lanes_per_wave);
     CoderParams p{n_maps, map_size, L, g.lanes, symbols, reconstruction, probs, prob_row, streams, stride,
-                  bac_bits, bypass_bits, status, stage};
+                  bac_bits, bypass_bits, status, stage, 0};
     hipStream_t s = (hipStream_t)stream;
     // the scalar-cache loads of the one-wave-per-map form are not coherent with the stores of the same launch: only the
     // encode-only mode uses it; the combined modes read their own streams back through the vector path
@@ -297,7 +320,7 @@ int eae_hip_coder_decode_maps(uint32_t n_maps, uint32_t map_size, int16_t* symbo
     const Geometry g = geometry(n_maps, L, lanes_per_wave);
     CoderParams p{n_maps, map_size, L, g.lanes, nullptr, symbols_out, probs, prob_row,
                   const_cast<uint8_t*>(streams), stride, const_cast<uint32_t*>(bac_bits), const_cast<uint32_t*>(bypass_bits),
-                  status, stage};
+                  status, stage, 0};
     if (g.uniform) hipLaunchKernelGGL((decoder_maps_kernel<false, true>), g.grid, g.block, g.lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((decoder_maps_kernel<false, false>), g.grid, g.block, g.lds, (hipStream_t)stream, p);
     return (int)hipGetLastError();
@@ -311,7 +334,7 @@ int eae_hip_coder_verify_maps(uint32_t n_maps, uint32_t map_size, const int16_t*
     const Geometry g = geometry(n_maps, L, lanes_per_wave);
     CoderParams p{n_maps, map_size, L, g.lanes, expected, nullptr, probs, prob_row,
                   const_cast<uint8_t*>(streams), stride, const_cast<uint32_t*>(bac_bits), const_cast<uint32_t*>(bypass_bits),
-                  status, stage};
+                  status, stage, 0};
     if (g.uniform) hipLaunchKernelGGL((decoder_maps_kernel<true, true>), g.grid, g.block, g.lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((decoder_maps_kernel<true, false>), g.grid, g.block, g.lds, (hipStream_t)stream, p);
     return (int)hipGetLastError();

@@ -1,0 +1,509 @@
+// coder_simd.hip -- the lossless coder reorganised for a 64-wide machine: 64 maps per wavefront, every lane in step.
+//
+// A binary arithmetic coder is a serial chain per stream (lossless/c++/source/BinaryArithmeticCoder.cpp:144-252), so the
+// only parallelism is across the feature maps of a batch. The per-lane kernels of coder_device.hip run the reference's
+// control flow in every lane; lanes diverge at every symbol, and the many long-lived waves cost the transform kernels
+// that run next to them about a tenth of their rate. Here the work is split so that the serial part is the same
+// instruction stream for all 64 lanes:
+//
+//   encode   (1) binarise_kernel, one wavefront per map, fully parallel over the symbols: UEG0 binarisation
+//                (LosslessCoder.cpp:232-252) -> a list of (bit, context) decisions, one byte each, and the complete
+//                bypass stream (signs, Exp-Golomb suffixes: bit offsets by wave prefix sums).
+//            (2) bac_encode_kernel, 64 maps per wavefront: step j feeds decision j of every lane's map to the interval
+//                update; the renormalisation is closed-form and the pending-bit queue is emitted in one 64-bit put, so
+//                the step is branch-light and the lanes stay converged.
+//   decode   (3) bac_decode_kernel, 64 maps per wavefront: both streams of the 64 maps are staged in LDS; each step decodes
+//                one decision per lane and advances a three-register binarisation state (unary count, symbol index).
+//            (4) compare_kernel: decoded == encoded symbols (the assert of lossless/compression.py:146-153).
+//
+// Anything the fast kernels do not handle -- an error of any kind (their exact code and stage matter), more than 32
+// pending E3 bits, a stream longer than its LDS window, L == 0 or L > 32 -- marks the map RETRY, and the general
+// per-lane kernel (the shared core of coder_core.h, statement for statement the reference) recodes that map from
+// scratch. Results are therefore identical to the host library's in every case; tests/test_coder_device.py compares
+// bytes, bit counts, symbols, statuses and stages.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../coder/coder_core.h"
+#include "eae_hip.h"
+
+// coder_device.hip
+int eae_coder_generic_encode(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, uint8_t L, const double* probs,
+                             const int32_t* prob_row, uint8_t* streams, uint64_t stride, uint32_t* bac_bits,
+                             uint32_t* bypass_bits, int32_t* status, int32_t* stage, int only_status, hipStream_t stream);
+int eae_coder_generic_decode(uint32_t n_maps, uint32_t map_size, int16_t* out, uint8_t L, const double* probs,
+                             const int32_t* prob_row, const uint8_t* streams, uint64_t stride, const uint32_t* bac_bits,
+                             const uint32_t* bypass_bits, int32_t* status, int32_t* stage, int only_status, hipStream_t stream);
+
+namespace {
+
+using namespace eae_core;
+
+#ifndef EAE_SIMD_PRIO
+#define EAE_SIMD_PRIO 3
+#endif
+
+constexpr int32_t RETRY = -100;           // internal: recode this map with the general kernel
+constexpr uint32_t kMaxFastL = 32;        // contexts staged in LDS: 32 x 64 lanes x 8 B = 16 KB
+constexpr uint32_t kBacWindowWords = 64;  // LDS window per lane, arithmetic-coded stream: 64 dwords = 2048 bits
+constexpr uint32_t kBypassWindowWords = 16;   // bypass stream: 512 bits
+
+struct SimdParams {
+    uint32_t n_maps, map_size, L, dcap;   // dcap: bytes of decision storage per map (multiple of 8)
+    const int16_t* symbols;
+    int16_t* decoded;
+    const double* probs;
+    const int32_t* prob_row;
+    uint8_t* streams;
+    uint64_t stride;
+    uint32_t* bac_bits;
+    uint32_t* bypass_bits;
+    int32_t* status;
+    int32_t* stage;
+    uint8_t* decisions;                   // [group][j / 8][lane][8]
+    uint32_t* ndec;                       // [n_maps]
+};
+
+__device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t& total) {
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d, 64);
+        if ((int)threadIdx.x >= d) inc += up;
+    }
+    total = __shfl(inc, 63, 64);
+    return inc - v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (1) one wavefront per map: symbols -> decisions + bypass stream
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void binarise_kernel(const SimdParams p) {
+    __shared__ unsigned long long ybuf[40];            // one tile of bypass bits: carry word + 64 x (33 + 1) bits
+    const uint32_t m = blockIdx.x, lane = threadIdx.x;
+    const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
+    if (row < 0) {                                     // exception map: no streams (compression.py:68-75)
+        if (lane == 0) { p.ndec[m] = 0; p.bac_bits[m] = 0; p.bypass_bits[m] = 0; p.status[m] = 0; if (p.stage) p.stage[m] = 0; }
+        return;
+    }
+    const uint32_t L = p.L;
+    const int16_t* in = p.symbols + (size_t)m * p.map_size;
+    uint8_t* dec = p.decisions + (size_t)(m >> 6) * 64u * p.dcap + (size_t)(m & 63u) * 8u;
+    unsigned long long* ystream = reinterpret_cast<unsigned long long*>(p.streams + (uint64_t)m * p.stride + p.stride / 2);
+    const uint32_t size_bits = round_up_to_byte(required_bits(p.map_size, L));
+    uint32_t jbase = 0, bbase = 0;
+    bool overflow = false;
+    if (lane < 40) ybuf[lane] = 0;
+    for (uint32_t t = 0; t < p.map_size; t += 64) {
+        const uint32_t i = t + lane;
+        const bool valid = i < p.map_size;
+        const int s = valid ? (int)in[i] : 0;
+        const uint32_t a = (uint32_t)(s < 0 ? -s : s);
+        const uint32_t ones = a < L ? a : L;
+        const uint32_t nd = valid ? ones + (a < L ? 1u : 0u) : 0u;
+        // bypass bits of this symbol, first bit in time at bit 0: Exp-Golomb of a - L (LosslessCoder.cpp:58-111), then the sign
+        unsigned long long bb = 0;
+        uint32_t nb = 0;
+        if (valid && a >= L) {
+            const uint32_t v = a - L + 1u;
+            const uint32_t n = count_nb_bits(v) - 1u;
+            bb = ((1ull << n) - 1ull) | ((unsigned long long)(n ? rev16(v - (1u << n)) >> (16u - n) : 0u) << (n + 1u));
+            nb = 2u * n + 1u;
+        }
+        if (valid && s != 0) {
+            bb |= (unsigned long long)(s > 0 ? 1u : 0u) << nb;   // LosslessCoder.cpp:22-37: 0 = negative
+            nb++;
+        }
+        uint32_t jtot, btot;
+        const uint32_t jo = wave_exclusive_scan(nd, jtot);
+        const uint32_t bo = wave_exclusive_scan(nb, btot);
+        // decisions: `ones` ones in contexts 0..ones-1, then a zero in context a when a < L (LosslessCoder.cpp:167-191)
+        for (uint32_t q = 0; q < nd; q++) {
+            const uint32_t j = jbase + jo + q;
+            dec[(size_t)(j >> 3) * 512u + (j & 7u)] = (uint8_t)((q << 1) | (q < ones ? 1u : 0u));
+        }
+        // bypass: assemble the tile in LDS behind the carried partial word, flush the complete words
+        if (nb) {
+            const uint32_t pos = (bbase & 63u) + bo;
+            atomicOr(&ybuf[pos >> 6], bb << (pos & 63u));
+            if ((pos & 63u) + nb > 64u) atomicOr(&ybuf[(pos >> 6) + 1u], bb >> (64u - (pos & 63u)));
+        }
+        if (bbase + btot > size_bits) overflow = true;          // Bitstream.cpp:32-35 -> general kernel for the exact error
+        if (overflow) break;
+        const uint32_t nfull = ((bbase & 63u) + btot) >> 6;
+        const unsigned long long mine = lane < 40 ? ybuf[lane] : 0ull;
+        const unsigned long long carry = ybuf[nfull];
+        if (lane < nfull) ystream[(bbase >> 6) + lane] = mine;
+        if (lane < 40) ybuf[lane] = lane == 0 ? carry : 0ull;
+        jbase += jtot;
+        bbase += btot;
+    }
+    if (lane == 0) {
+        if (!overflow && (bbase & 63u)) ystream[bbase >> 6] = ybuf[0];     // Bitstream flush of the partial word
+        p.ndec[m] = jbase;
+        p.bypass_bits[m] = bbase;
+        p.bac_bits[m] = 0;
+        p.status[m] = overflow ? RETRY : 0;
+        if (p.stage) p.stage[m] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (2) 64 maps per wavefront: decision j of every map through the interval update, in step
+// ---------------------------------------------------------------------------------------------------------------------
+extern __shared__ double lds_dyn[];
+
+__global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
+    __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t m = blockIdx.x * 64u + lane;
+    const bool in_range = m < p.n_maps;
+    const int32_t row = in_range ? (p.prob_row ? p.prob_row[m] : (int32_t)m) : -1;
+    bool live = in_range && row >= 0 && p.status[m] == 0;
+    const uint32_t L = p.L;
+    double* probs = lds_dyn;                            // [context][lane]
+    if (live)
+        for (uint32_t k = 0; k < L; k++) probs[k * 64u + lane] = p.probs[(size_t)row * L + k];
+    const uint32_t nd = live ? p.ndec[m] : 0u;
+    const uint32_t steps = wave_max(nd);
+    Bac bac;
+    bac.init();
+    bac.bs.init_writer(p.streams + (uint64_t)(in_range ? m : 0u) * p.stride, required_bits(p.map_size, L));
+    const uint8_t* dec = p.decisions + (size_t)blockIdx.x * 64u * p.dcap + (size_t)lane * 8u;
+    uint32_t low = 0, high = kRangeMax, e3 = 0;
+    bool retry = false;
+    uint2 ahead = steps ? *reinterpret_cast<const uint2*>(dec) : make_uint2(0, 0);
+    for (uint32_t jb = 0; jb < steps; jb += 8) {
+        const unsigned long long d8 = (unsigned long long)ahead.x | ((unsigned long long)ahead.y << 32);
+        if (jb + 8 < steps) ahead = *reinterpret_cast<const uint2*>(dec + (size_t)((jb >> 3) + 1u) * 512u);
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+            const uint32_t j = jb + q;
+            if (j < nd && !retry) {
+                const uint32_t d = (uint32_t)(d8 >> (8u * q)) & 0xFFu;
+                const uint32_t bit = d & 1u;
+                const double pk = probs[(d >> 1) * 64u + lane];
+                // Bac::update_middle + encode_bit (BinaryArithmeticCoder.cpp:144-180)
+                const uint32_t mid = low + (uint32_t)(pk * (double)(high - low));
+                uint32_t nl = bit ? mid + 1u : low;
+                uint32_t nh = bit ? high : mid;
+                if (!(pk > 0. && pk < 1.) || nl > kRangeMax) retry = true;
+                // E1/E2 in closed form (as Bac::encode): n leading equal bits leave, with the pending E3 bits behind the first
+                const uint32_t diff = (nl ^ nh) & 0xFFFFu;
+                const uint32_t n = diff ? (uint32_t)__builtin_clz(diff) - 16u : 16u;
+                if (n && !retry) {
+                    if (e3 > 32u) retry = true;
+                    else {
+                        const uint32_t out = rev16(nh);
+                        const unsigned long long first = out & 1u;
+                        const unsigned long long run = first ? 0ull : ((1ull << e3) - 1ull);
+                        const unsigned long long rest = (out >> 1) & ((1u << (n - 1u)) - 1u);
+                        const unsigned long long bits = first | (run << 1) | (rest << (1u + e3));
+                        const uint32_t cnt = n + e3;
+                        Bitstream& bs = bac.bs;
+                        if (bs.write_index + cnt > bs.size_bits) retry = true;
+                        else {
+                            const uint32_t sh = bs.write_index & 63u;
+                            bs.acc |= bits << sh;
+                            if (sh + cnt >= 64u) {
+                                store64(bs.data + ((bs.write_index >> 6) << 3), bs.acc);
+                                bs.acc = sh ? bits >> (64u - sh) : 0ull;
+                            }
+                            bs.write_index += cnt;
+                            e3 = 0;
+                            nl = (nl << n) & 0xFFFFu;
+                            nh = ((nh << n) & 0xFFFFu) | ((1u << n) - 1u);
+                        }
+                    }
+                }
+                // E3 (BinaryArithmeticCoder.cpp:238-245)
+                while (!retry && nl > kRangeQuarter && nh <= kRangeThreeQuarters) {
+                    nh = ((nh - (kRangeQuarter + 1u)) << 1) | 1u;
+                    nl = (nl - (kRangeQuarter + 1u)) << 1;
+                    e3++;
+                }
+                low = nl;
+                high = nh;
+            }
+        }
+    }
+    if (live) {
+        int s = OK;
+        if (!retry) {
+            bac.low = low;
+            bac.high = high;
+            bac.nb_e3 = e3;
+            s = bac.stop_encoding();                    // BinaryArithmeticCoder.cpp:61-102, flushes the stream
+        }
+        if (retry || s) p.status[m] = RETRY;            // the general kernel reproduces the exact code and stage
+        else p.bac_bits[m] = bac.bs.write_index;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (3) 64 maps per wavefront: decode, streams staged in LDS
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
+    __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t m = blockIdx.x * 64u + lane;
+    const bool in_range = m < p.n_maps;
+    const int32_t row = in_range ? (p.prob_row ? p.prob_row[m] : (int32_t)m) : -1;
+    const uint32_t L = p.L;
+    double* probs = lds_dyn;                                                        // [context][lane]
+    uint32_t* wbac = reinterpret_cast<uint32_t*>(lds_dyn + (size_t)L * 64u);        // [word][lane]
+    uint32_t* wbyp = wbac + kBacWindowWords * 64u;                                  // [word][lane]
+    bool live = in_range && row >= 0 && p.status[m] == 0;
+    const uint32_t nbac = live ? p.bac_bits[m] : 0u;
+    const uint32_t nbyp = live ? p.bypass_bits[m] : 0u;
+    bool retry = false;
+    if (live && (nbac > kBacWindowWords * 32u || nbyp > kBypassWindowWords * 32u)) retry = true;   // longer than the window
+    if (live)
+        for (uint32_t k = 0; k < L; k++) probs[k * 64u + lane] = p.probs[(size_t)row * L + k];
+    // stage the streams of the 64 maps: the wave copies one map per iteration, coalesced
+    for (uint32_t l = 0; l < 64u; l++) {
+        const uint32_t ml = blockIdx.x * 64u + l;
+        if (ml >= p.n_maps) break;
+        const uint32_t bits_b = __shfl(nbac, l, 64), bits_y = __shfl(nbyp, l, 64);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)ml * p.stride);
+        if (lane * 32u < bits_b && lane < kBacWindowWords) wbac[lane * 64u + l] = src[lane];
+        const uint32_t* srcy = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)ml * p.stride + p.stride / 2);
+        if (lane * 32u < bits_y && lane < kBypassWindowWords) wbyp[lane * 64u + l] = srcy[lane];
+    }
+    __syncthreads();
+    int16_t* out = p.decoded + (size_t)(in_range ? m : 0u) * p.map_size;
+    // Bac::start_decoding (BinaryArithmeticCoder.cpp:104-122): 16 bits, the last one repeated once the stream is exhausted
+    uint32_t low = 0, high = kRangeMax, code = 0, ridx = 0, yidx = 0;
+    unsigned long long rwin = 0;          // bits [ridx, ridx + rcount) of the arithmetic-coded stream, bit 0 first
+    uint32_t rcount = 0, rword = 0;       // rword: next dword of the window to load
+    auto refill = [&]() {
+        if (rcount <= 32u) {
+            const uint32_t w = rword < kBacWindowWords && rword * 32u < nbac ? wbac[rword * 64u + lane] : 0u;
+            rwin |= (unsigned long long)w << rcount;
+            rcount += 32u;
+            rword++;
+        }
+    };
+    bool active = live && !retry;
+    if (active) {
+        refill();
+        const uint32_t k = nbac < 16u ? nbac : 16u;
+        uint32_t bits = k ? rev16((uint32_t)rwin & ((1u << k) - 1u)) >> (16u - k) : 0u;
+        const uint32_t sticky = k ? (bits & 1u) : 0u;
+        if (k < 16u) bits = (bits << (16u - k)) | (sticky ? ((1u << (16u - k)) - 1u) : 0u);
+        code = bits;
+        rwin >>= k;
+        rcount -= k;
+        ridx = k;
+    }
+    uint32_t unary = 0, i = 0;
+    const uint32_t size = p.map_size;
+    if (size == 0) active = false;
+    while (active) {
+        refill();
+        const double pk = probs[unary * 64u + lane];
+        // Bac::decode (BinaryArithmeticCoder.cpp:124-134, 254-320) with the closed-form renormalisation of coder_core.h
+        const uint32_t mid = low + (uint32_t)(pk * (double)(high - low));
+        if (!(pk > 0. && pk < 1.)) { retry = true; break; }
+        const uint32_t bit = code > mid ? 1u : 0u;
+        uint32_t nl = bit ? mid + 1u : low;
+        uint32_t nh = bit ? high : mid;
+        const uint32_t diff = (nl ^ nh) & 0xFFFFu;
+        const uint32_t n = diff ? (uint32_t)__builtin_clz(diff) - 16u : 16u;
+        uint32_t sticky = 0;
+        {
+            const uint32_t avail = nbac - ridx;
+            const uint32_t k = n < avail ? n : avail;
+            uint32_t bits = k ? rev16((uint32_t)rwin & ((1u << k) - 1u)) >> (16u - k) : 0u;
+            if (k) sticky = bits & 1u;
+            if (k < n) bits = (bits << (n - k)) | (sticky ? ((1u << (n - k)) - 1u) : 0u);
+            rwin >>= k;
+            rcount -= k;
+            ridx += k;
+            nl = (nl << n) & kRangeMax;
+            nh = ((nh << n) & kRangeMax) | ((1u << n) - 1u);
+            code = ((code << n) & kRangeMax) | bits;
+        }
+        while (nh <= kRangeThreeQuarters && nl > kRangeQuarter && nh > kRangeHalf && nl <= kRangeHalf) {
+            nh -= kRangeQuarter + 1u; nl -= kRangeQuarter + 1u; code -= kRangeQuarter + 1u;
+            if (ridx < nbac) {
+                if (rcount == 0) refill();
+                sticky = (uint32_t)rwin & 1u;
+                rwin >>= 1;
+                rcount--;
+                ridx++;
+            }
+            nh = ((nh << 1) & kRangeMax) | 1u;
+            nl = (nl << 1) & kRangeMax;
+            code = ((code << 1) & kRangeMax) | sticky;
+        }
+        low = nl;
+        high = nh;
+        // binarisation state (LosslessCoder.cpp:193-230, 254-276): a one advances the unary count up to L, a zero ends it
+        bool symbol_done = false;
+        uint32_t a = 0;
+        if (bit) {
+            unary++;
+            if (unary == L) { symbol_done = true; a = L; }
+        } else {
+            symbol_done = true;
+            a = unary;
+        }
+        if (symbol_done) {
+            if (a == L) {
+                // Exp-Golomb suffix from the bypass stream (LosslessCoder.cpp:113-165)
+                uint32_t nn = 0;
+                bool bad = false;
+                for (;;) {
+                    if (yidx >= nbyp) { bad = true; break; }
+                    const uint32_t b = (wbyp[(yidx >> 5) * 64u + lane] >> (yidx & 31u)) & 1u;
+                    yidx++;
+                    if (!b) break;
+                    nn++;
+                    if (nn > 16u) { bad = true; break; }
+                }
+                uint32_t suffix = 0;
+                for (uint32_t q = 0; q < nn && !bad; q++) {
+                    if (yidx >= nbyp) { bad = true; break; }
+                    suffix = (suffix << 1) | ((wbyp[(yidx >> 5) * 64u + lane] >> (yidx & 31u)) & 1u);
+                    yidx++;
+                }
+                if (bad) { retry = true; break; }
+                a = (L + ((suffix + (1u << nn) - 1u) & 0xFFFFu)) & 0xFFFFu;    // uint16 arithmetic of the reference
+            }
+            int v = (int)(int16_t)a;
+            if (v != 0) {
+                if (yidx >= nbyp) { retry = true; break; }       // resource_error -> general kernel for the exact status
+                const uint32_t b = (wbyp[(yidx >> 5) * 64u + lane] >> (yidx & 31u)) & 1u;
+                yidx++;
+                if (!b) v = -v;
+            }
+            out[i] = (int16_t)v;
+            i++;
+            unary = 0;
+            if (i == size) active = false;
+        }
+    }
+    if (live) p.status[m] = retry ? RETRY : 0;
+}
+
+// (4) decoded == encoded, one wavefront per map
+__global__ __launch_bounds__(64) void compare_kernel(const SimdParams p) {
+    const uint32_t m = blockIdx.x, lane = threadIdx.x;
+    const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
+    if (row < 0 || p.status[m] != 0) return;
+    const int16_t* a = p.symbols + (size_t)m * p.map_size;
+    const int16_t* b = p.decoded + (size_t)m * p.map_size;
+    int differ = 0;
+    for (uint32_t i = lane; i < p.map_size; i += 64) differ |= (a[i] != b[i]);
+    if (__any(differ) && lane == 0) p.status[m] = MISMATCH;
+}
+
+// status 0 -> RETRY for the coded maps: hands every map that has not failed to the general kernel
+__global__ void mark_kernel(const SimdParams p) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= p.n_maps) return;
+    const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
+    if (row >= 0 && p.status[m] == 0) p.status[m] = RETRY;
+}
+
+uint32_t decision_capacity(uint32_t map_size, uint8_t L) { return ((map_size * ((uint32_t)L + 1u)) + 7u) & ~7u; }
+bool fast_applies(uint8_t L) { return L >= 1 && L <= kMaxFastL; }
+
+}  // namespace
+
+extern "C" {
+
+// workspace: [per-map decision counts][decisions of an encode | decoded symbols of a verify], 256-byte aligned pieces
+static uint64_t round256(uint64_t v) { return (v + 255u) & ~(uint64_t)255u; }
+uint64_t eae_hip_coder_workspace_bytes(uint32_t n_maps, uint32_t map_size, uint8_t L) {
+    const uint64_t groups = ((uint64_t)n_maps + 63u) / 64u;
+    const uint64_t decisions = fast_applies(L) ? groups * 64u * decision_capacity(map_size, L) : 0u;
+    const uint64_t decoded = (uint64_t)n_maps * map_size * sizeof(int16_t);
+    return 256u + round256((uint64_t)n_maps * sizeof(uint32_t)) + round256(decisions > decoded ? decisions : decoded);
+}
+
+static SimdParams make_params(uint32_t n_maps, uint32_t map_size, uint8_t L, const int16_t* symbols, const double* probs,
+                              const int32_t* prob_row, uint8_t* streams, uint64_t stride, uint32_t* bac_bits,
+                              uint32_t* bypass_bits, int32_t* status, int32_t* stage, void* workspace) {
+    SimdParams p{};
+    p.n_maps = n_maps; p.map_size = map_size; p.L = L; p.dcap = decision_capacity(map_size, L);
+    p.symbols = symbols; p.probs = probs; p.prob_row = prob_row; p.streams = streams; p.stride = stride;
+    p.bac_bits = bac_bits; p.bypass_bits = bypass_bits; p.status = status; p.stage = stage;
+    if (workspace) {
+        uint8_t* ws = reinterpret_cast<uint8_t*>(round256(reinterpret_cast<uintptr_t>(workspace)));
+        p.ndec = reinterpret_cast<uint32_t*>(ws);
+        p.decisions = ws + round256((uint64_t)n_maps * sizeof(uint32_t));
+        p.decoded = reinterpret_cast<int16_t*>(p.decisions);
+    }
+    return p;
+}
+
+static int check_simd_layout(uint32_t map_size, uint8_t L, const uint8_t* streams, uint64_t stride) {
+    const uint64_t half = stride / 2;
+    return (half < (uint64_t)(round_up_to_byte(required_bits(map_size, L)) >> 3) + 16 || (stride & 15u) ||
+            (reinterpret_cast<uintptr_t>(streams) & 7u)) ? 1 : 0;
+}
+
+int eae_hip_coder_encode_batch(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, uint8_t L, const double* probs,
+                               const int32_t* prob_row, uint8_t* streams, uint64_t stride, uint32_t* bac_bits,
+                               uint32_t* bypass_bits, int32_t* status, int32_t* stage, void* workspace,
+                               uint64_t workspace_bytes, void* stream) {
+    if (!symbols || !probs || !streams || !bac_bits || !bypass_bits || !status || !workspace) return -1;
+    if (check_simd_layout(map_size, L, streams, stride)) return 1;
+    if (workspace_bytes < eae_hip_coder_workspace_bytes(n_maps, map_size, L)) return 1;
+    if (n_maps == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (!fast_applies(L) || map_size == 0) {
+        (void)hipMemsetAsync(status, 0, (size_t)n_maps * sizeof(int32_t), s);
+        return eae_coder_generic_encode(n_maps, map_size, symbols, L, probs, prob_row, streams, stride, bac_bits, bypass_bits,
+                                        status, stage, 0, s);
+    }
+    const SimdParams p = make_params(n_maps, map_size, L, symbols, probs, prob_row, streams, stride, bac_bits, bypass_bits,
+                                     status, stage, workspace);
+    hipLaunchKernelGGL(binarise_kernel, dim3(n_maps), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(bac_encode_kernel, dim3((n_maps + 63u) / 64u), dim3(64), (size_t)L * 64u * sizeof(double), s, p);
+    const int rc = eae_coder_generic_encode(n_maps, map_size, symbols, L, probs, prob_row, streams, stride, bac_bits,
+                                            bypass_bits, status, stage, RETRY, s);
+    return rc ? rc : (int)hipGetLastError();
+}
+
+int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symbols_out, const int16_t* expected, uint8_t L,
+                               const double* probs, const int32_t* prob_row, const uint8_t* streams, uint64_t stride,
+                               const uint32_t* bac_bits, const uint32_t* bypass_bits, int32_t* status, int32_t* stage,
+                               void* workspace, uint64_t workspace_bytes, void* stream) {
+    if (!probs || !streams || !bac_bits || !bypass_bits || !status) return -1;
+    if (!symbols_out && (!expected || !workspace)) return -1;
+    if (!symbols_out && workspace_bytes < eae_hip_coder_workspace_bytes(n_maps, map_size, L)) return 1;
+    if (n_maps == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    SimdParams p = make_params(n_maps, map_size, L, expected, probs, prob_row, const_cast<uint8_t*>(streams), stride,
+                               const_cast<uint32_t*>(bac_bits), const_cast<uint32_t*>(bypass_bits), status, stage, workspace);
+    if (symbols_out) p.decoded = symbols_out;
+    if (!expected) (void)hipMemsetAsync(status, 0, (size_t)n_maps * sizeof(int32_t), s);   // a pure decode starts from a clean slate
+    if (fast_applies(L) && map_size) {
+        const size_t lds = (size_t)L * 64u * sizeof(double) + (size_t)(kBacWindowWords + kBypassWindowWords) * 64u * sizeof(uint32_t);
+        hipLaunchKernelGGL(bac_decode_kernel, dim3((n_maps + 63u) / 64u), dim3(64), lds, s, p);
+        const int rc = eae_coder_generic_decode(n_maps, map_size, p.decoded, L, probs, prob_row, streams, stride, bac_bits,
+                                                bypass_bits, status, stage, RETRY, s);
+        if (rc) return rc;
+    } else {
+        // general kernel over every map that has not failed already
+        hipLaunchKernelGGL(mark_kernel, dim3((n_maps + 255u) / 256u), dim3(256), 0, s, p);
+        const int rc = eae_coder_generic_decode(n_maps, map_size, p.decoded, L, probs, prob_row, streams, stride, bac_bits,
+                                                bypass_bits, status, stage, RETRY, s);
+        if (rc) return rc;
+    }
+    if (expected) hipLaunchKernelGGL(compare_kernel, dim3(n_maps), dim3(64), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -21,3 +21,20 @@ extern "C" int eae_hip_device_info(char* name, int name_cap, int* compute_units,
     if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
     return EAE_HIP_OK;
 }
+
+// Results for the host, without hipMemcpyAsync (which was measured to block the calling thread for the whole queue depth
+// of its stream on this platform when the stream is busy): a kernel writes the bytes into pinned, device-mapped host
+// memory; the host reads them after an event on the same stream.
+__global__ void publish_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint64_t words) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+}
+extern "C" int eae_hip_publish_to_host(const void* src_device, void* dst_host_mapped, uint64_t bytes, void* stream) {
+    if (!src_device || !dst_host_mapped || (bytes & 3u)) return -1;
+    if (bytes == 0) return 0;
+    const uint64_t words = bytes / 4;
+    const unsigned blocks = (unsigned)((words + 255) / 256 > 64 ? 64 : (words + 255) / 256);
+    hipLaunchKernelGGL(publish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src_device,
+                       (uint32_t*)dst_host_mapped, words);
+    return (int)hipGetLastError();
+}

@@ -139,11 +139,13 @@ def pack_tconv9x9s4_weights(w_tf):
     return out
 
 
-def quantize_maps(y, bin_widths, map_mean=None, want_cq=False, want_shifted=False, want_symbols=False, want_flags=False):
+def quantize_maps(y, bin_widths, map_mean=None, want_cq=False, want_shifted=False, want_symbols=False, want_flags=False,
+                  out_symbols=None):
     """One pass over y [N,h,w,C] (or [N,hw,C]); see include/eae_hip.h. Returns a dict of the requested device tensors.
 
     `checks` (int32 [3]) always comes back: [0] int16 range violations, [1] "quantization was omitted" count,
-    [2] "lossless compression altered the data" count.
+    [2] "lossless compression altered the data" count. `out_symbols`: a preallocated int16 [N, C, hw] buffer to write
+    the planar symbols into (a caller that hands them to another stream keeps them out of the caching allocator).
     """
     n = y.shape[0]
     c = y.shape[-1]
@@ -151,7 +153,9 @@ def quantize_maps(y, bin_widths, map_mean=None, want_cq=False, want_shifted=Fals
     d = y.device
     cq = torch.empty_like(y) if want_cq else None
     shifted = torch.empty_like(y) if want_shifted else None
-    symbols = torch.empty((n, c, hw), dtype=torch.int16, device=d) if want_symbols else None
+    symbols = (out_symbols if out_symbols is not None else torch.empty((n, c, hw), dtype=torch.int16, device=d)) if want_symbols else None
+    if symbols is not None and (symbols.dtype != torch.int16 or symbols.numel() != n*c*hw):
+        raise TypeError('`out_symbols` must be an int16 tensor of N x C x hw elements.')
     flags = torch.zeros((n, c), dtype=torch.int32, device=d) if want_flags else None
     checks = torch.zeros(3, dtype=torch.int32, device=d)
     _check(_native.hip().eae_hip_quantize_maps(_p(y), _p(map_mean), _p(bin_widths), _p(cq), _p(shifted), _p(symbols), _p(flags),
@@ -185,12 +189,18 @@ def cast_int16(x):
     return out, range_error
 
 
-def symbol_histograms(symbols_planar, radius):
-    """symbols [..., map_size] int16 -> (hist int32 [n_maps, 2*radius+1], overflow int32 [n_maps])."""
+def symbol_histograms(symbols_planar, radius, out=None):
+    """symbols [..., map_size] int16 -> (hist int32 [n_maps, 2*radius+1], overflow int32 [n_maps]); `out` = that pair,
+    preallocated (it is zeroed here)."""
     map_size = symbols_planar.shape[-1]
     n_maps = symbols_planar.numel()//map_size
-    hist = torch.zeros((n_maps, 2*radius + 1), dtype=torch.int32, device=symbols_planar.device)
-    overflow = torch.zeros(n_maps, dtype=torch.int32, device=symbols_planar.device)
+    if out is None:
+        hist = torch.zeros((n_maps, 2*radius + 1), dtype=torch.int32, device=symbols_planar.device)
+        overflow = torch.zeros(n_maps, dtype=torch.int32, device=symbols_planar.device)
+    else:
+        (hist, overflow) = out
+        hist.zero_()
+        overflow.zero_()
     _check(_native.hip().eae_hip_symbol_histograms(_p(symbols_planar), _p(hist), radius, _p(overflow), n_maps, map_size, _stream()),
            'eae_hip_symbol_histograms')
     return hist, overflow
@@ -219,14 +229,16 @@ class CoderStreams(object):
     """Per-map streams of one batch, resident in HBM, in the layout of eae_coder_encode_maps (include/eae_coder.h):
     map m owns `streams[m]` (stride bytes): BAC bytes at +0, bypass bytes at +stride/2."""
 
-    def __init__(self, n_maps, map_size, truncated_unary_length, device):
+    def __init__(self, n_maps, map_size, truncated_unary_length, device, results=None):
         self.n_maps = n_maps
         self.map_size = map_size
         self.truncated_unary_length = truncated_unary_length
         self.stride = int(_native.hip().eae_hip_coder_stream_stride_bytes(map_size, truncated_unary_length))
         self.streams = torch.empty((n_maps, self.stride), dtype=torch.uint8, device=device)
         # one allocation so that a caller can fetch all four per-map results with a single device -> host copy
-        self.results = torch.zeros((4, n_maps), dtype=torch.int32, device=device)
+        self.results = results if results is not None else torch.zeros((4, n_maps), dtype=torch.int32, device=device)
+        if self.results.shape != (4, n_maps) or self.results.dtype != torch.int32 or not self.results.is_contiguous():
+            raise TypeError('`results` must be a contiguous int32 tensor of shape (4, n_maps).')
         (self.bac_bits, self.bypass_bits, self.status, self.stage) = self.results.unbind(0)
 
     def nb_bits(self):
@@ -271,6 +283,58 @@ def coder_verify_maps(streams, expected_symbols, probabilities, prob_row, lanes_
                                                    _p(probabilities), _p(prob_row), _p(streams.streams), streams.stride,
                                                    _p(streams.bac_bits), _p(streams.bypass_bits), _p(streams.status), _p(streams.stage),
                                                    lanes_per_wave, _stream()), 'eae_hip_coder_verify_maps')
+
+
+def publish_to_host(src_device, dst_pinned):
+    """Stream-ordered copy of a small device tensor into a pinned host tensor of the same byte size, done by a kernel
+    (never blocks the calling thread). Synchronise an event recorded after it before reading `dst_pinned`."""
+    nbytes = src_device.numel()*src_device.element_size()
+    if not dst_pinned.is_pinned() or dst_pinned.numel()*dst_pinned.element_size() != nbytes or not dst_pinned.is_contiguous():
+        raise HipError('expected a contiguous pinned host tensor of the same size')
+    _check(_native.hip().eae_hip_publish_to_host(_p(src_device), dst_pinned.data_ptr(), nbytes, _stream()), 'eae_hip_publish_to_host')
+
+
+def coder_workspace(n_maps, map_size, truncated_unary_length, device):
+    """Scratch for coder_encode_batch / coder_decode_batch (one per batch in flight)."""
+    nbytes = int(_native.hip().eae_hip_coder_workspace_bytes(n_maps, map_size, truncated_unary_length))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def coder_encode_batch(symbols_planar, probabilities, prob_row, truncated_unary_length, out=None, workspace=None):
+    """The 64-maps-per-wavefront encoder (include/eae_hip.h). Same results as coder_compress_maps(mode=CODER_ENCODE_ONLY)."""
+    map_size = symbols_planar.shape[-1]
+    n_maps = symbols_planar.numel()//map_size
+    if symbols_planar.dtype != torch.int16 or probabilities.dtype != torch.float64:
+        raise TypeError('`symbols_planar` must be int16 and `probabilities` float64.')
+    if out is None:
+        out = CoderStreams(n_maps, map_size, truncated_unary_length, symbols_planar.device)
+    if workspace is None:
+        workspace = coder_workspace(n_maps, map_size, truncated_unary_length, symbols_planar.device)
+    _check(_native.hip().eae_hip_coder_encode_batch(n_maps, map_size, _p(symbols_planar), truncated_unary_length, _p(probabilities),
+                                                    _p(prob_row), _p(out.streams), out.stride, _p(out.bac_bits), _p(out.bypass_bits),
+                                                    _p(out.status), _p(out.stage), _p(workspace), workspace.numel(), _stream()),
+           'eae_hip_coder_encode_batch')
+    return out
+
+
+def coder_decode_batch(streams, probabilities, prob_row, expected=None, workspace=None):
+    """The 64-maps-per-wavefront decoder. expected=None: returns the decoded symbols [n_maps, map_size] (skipped maps
+    zero). With `expected`: decodes into the workspace and compares on the device; failures land in `streams.status`."""
+    device = streams.streams.device
+    if expected is None:
+        out = torch.zeros((streams.n_maps, streams.map_size), dtype=torch.int16, device=device)
+    else:
+        out = None
+        if expected.dtype != torch.int16 or expected.numel() != streams.n_maps*streams.map_size:
+            raise TypeError('`expected` must hold n_maps x map_size int16 symbols.')
+        if workspace is None:
+            workspace = coder_workspace(streams.n_maps, streams.map_size, streams.truncated_unary_length, device)
+    _check(_native.hip().eae_hip_coder_decode_batch(streams.n_maps, streams.map_size, _p(out), _p(expected), streams.truncated_unary_length,
+                                                    _p(probabilities), _p(prob_row), _p(streams.streams), streams.stride,
+                                                    _p(streams.bac_bits), _p(streams.bypass_bits), _p(streams.status), _p(streams.stage),
+                                                    _p(workspace), workspace.numel() if workspace is not None else 0, _stream()),
+           'eae_hip_coder_decode_batch')
+    return out
 
 
 # ---- SVHN float64 path (include/eae_hip.h, "SVHN path") -------------------------------------------------------------

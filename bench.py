@@ -13,6 +13,7 @@ scaling, no data-path collective); one RCCL all-reduce sums the rate / PSNR stat
 Prints ONE JSON line on rank 0 (see DESIGN.md section 6 for the fields).
 """
 import argparse
+import gc
 import json
 import os
 import queue
@@ -108,12 +109,13 @@ def main():
     parser.add_argument('--no-cpu-baseline', action='store_true')
     parser.add_argument('--coder-streams', type=int, default=int(os.environ.get('EAE_CODER_STREAMS', '2')),
                         help='batches whose entropy coding may be in flight at once (each on its own HIP stream)')
-    parser.add_argument('--coder-lanes', type=int, default=int(os.environ.get('EAE_CODER_LANES', '8')),
-                        help='maps per 64-thread block of the device coder (0 = one wavefront per map)')
+    parser.add_argument('--coder-lanes', type=int, default=int(os.environ.get('EAE_CODER_LANES', '-1')),
+                        help='-1: 64 maps per wavefront in step (default); >= 0: the per-lane kernels with that many maps per block')
     args = parser.parse_args()
 
     # two Python threads share the GIL (kernel launches; rate bookkeeping): hand it over quickly
     sys.setswitchinterval(1e-4)
+    tracing = bool(os.environ.get('EAE_BENCH_TRACE'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -149,10 +151,19 @@ def main():
     prob_row = prob_row.to(device)
     n_maps = args.batch*128
     nb_slots = args.coder_streams + 2
-    streams = [dev.CoderStreams(n_maps, map_size, TRUNCATED_UNARY_LENGTH, device) for _ in range(nb_slots)]
-    pinned_results = [torch.empty((4, n_maps), dtype=torch.int32).pin_memory() for _ in range(nb_slots)]
-    pinned_hist = [(torch.empty((args.batch, 511), dtype=torch.int32).pin_memory(), torch.empty(args.batch, dtype=torch.int32).pin_memory())
-                   for _ in range(nb_slots)]
+    # everything the host needs from one batch, contiguous on the device: [coder results 4 x n_maps | histograms | overflow]
+    nb_host_words = 4*n_maps + args.batch*511 + args.batch
+    slot_out = [torch.zeros(nb_host_words, dtype=torch.int32, device=device) for _ in range(nb_slots)]
+    pinned_out = [torch.zeros(nb_host_words, dtype=torch.int32).pin_memory() for _ in range(nb_slots)]
+
+    def views(t):
+        return (t[:4*n_maps].view(4, n_maps), t[4*n_maps:4*n_maps + args.batch*511].view(args.batch, 511), t[4*n_maps + args.batch*511:])
+
+    streams = [dev.CoderStreams(n_maps, map_size, TRUNCATED_UNARY_LENGTH, device, results=views(slot_out[i])[0]) for i in range(nb_slots)]
+    slot_hist = [views(slot_out[i])[1:] for i in range(nb_slots)]
+    pinned_views = [views(pinned_out[i]) for i in range(nb_slots)]
+    slot_symbols = [torch.empty((args.batch, 128, map_size), dtype=torch.int16, device=device) for _ in range(nb_slots)]
+    workspaces = [dev.coder_workspace(n_maps, map_size, TRUNCATED_UNARY_LENGTH, device) for _ in range(nb_slots)]
     slot_free = [threading.Event() for _ in range(nb_slots)]
     for e in slot_free:
         e.set()
@@ -173,41 +184,59 @@ def main():
         gemm_events.append((a, b, name))
         return out
 
+    host_marks = []
+
+    def mark(tag):
+        if tracing:
+            host_marks.append((tag, time.perf_counter()))
+
     def step(index, record):
+        mark('begin')
         v = encoder.v
         gdn_1 = dev.conv9x9s4_u8(images, encoder.w1, v['encoder/biases_1'], encoder.g[1], v['encoder/beta_1'])
         gdn_2 = timed_launch('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, encoder.w2, v['encoder/biases_2'], dev.NORM_GDN,
                                                                  encoder.g[2], v['encoder/beta_2']), record)
         y = timed_launch('conv3_gdn3', lambda: dev.conv5x5s2(gdn_2, encoder.w3, v['encoder/biases_3'], dev.NORM_GDN,
                                                              encoder.g[3], v['encoder/beta_3']), record)
-        q = dev.quantize_maps(y, bin_widths, map_mean, want_shifted=True, want_symbols=True, want_flags=True)
+        mark('encoder')
         slot = index % nb_slots
         slot_free[slot].wait()
         slot_free[slot].clear()
+        mark('slot')
+        # buffers that cross to the coder streams are per-slot and preallocated (no caching-allocator traffic across streams)
+        q = dev.quantize_maps(y, bin_widths, map_mean, want_shifted=True, want_symbols=True, want_flags=True,
+                              out_symbols=slot_symbols[slot])
         # exception map: exact histogram on the device; its entropy is formed on the host by the rate worker
-        (hist, overflow) = dev.symbol_histograms(q['symbols'][:, IDX_MAP_EXCEPTION:IDX_MAP_EXCEPTION + 1].contiguous(), 255)
+        (hist, overflow) = dev.symbol_histograms(q['symbols'][:, IDX_MAP_EXCEPTION:IDX_MAP_EXCEPTION + 1].contiguous(), 255,
+                                                 out=slot_hist[slot])
         quantized = torch.cuda.Event()
         quantized.record()
         # entropy coding off the transform stream, concurrent with the transforms of this and the next batches: every map
         # is encoded (streams left in HBM), then decoded back and compared in a second launch (what compress_lossless +
         # the assert of compression.py:146-153 do); then ONE small device -> host copy of the per-map bit counts /
         # statuses. The coder is a few latency-bound waves: several batches are kept in flight on separate streams.
+        mark('quantize')
         symbols = q['symbols'].view(n_maps, map_size)
         coder_stream = coder_streams[index % len(coder_streams)]
         with torch.cuda.stream(coder_stream):
             coder_stream.wait_event(quantized)
             if not os.environ.get('EAE_BENCH_NO_CODER'):      # diagnostic only: transforms without the coder
-                dev.coder_compress_maps(symbols, probabilities_dev, prob_row, TRUNCATED_UNARY_LENGTH,
-                                        mode=dev.CODER_ENCODE_ONLY, out=streams[slot], lanes_per_wave=args.coder_lanes)
-                dev.coder_verify_maps(streams[slot], symbols, probabilities_dev, prob_row, args.coder_lanes)
-            pinned_results[slot].copy_(streams[slot].results, non_blocking=True)
-            pinned_hist[slot][0].copy_(hist, non_blocking=True)
-            pinned_hist[slot][1].copy_(overflow, non_blocking=True)
+                if args.coder_lanes >= 0:                     # per-lane kernels (coder_device.hip), for comparison
+                    dev.coder_compress_maps(symbols, probabilities_dev, prob_row, TRUNCATED_UNARY_LENGTH,
+                                            mode=dev.CODER_ENCODE_ONLY, out=streams[slot], lanes_per_wave=args.coder_lanes)
+                    dev.coder_verify_maps(streams[slot], symbols, probabilities_dev, prob_row, args.coder_lanes)
+                else:                                         # 64 maps per wavefront in step (coder_simd.hip)
+                    dev.coder_encode_batch(symbols, probabilities_dev, prob_row, TRUNCATED_UNARY_LENGTH, out=streams[slot],
+                                           workspace=workspaces[slot])
+                    mark('c_encode')
+                    dev.coder_decode_batch(streams[slot], probabilities_dev, prob_row, expected=symbols, workspace=workspaces[slot])
+                    mark('c_decode')
+            dev.publish_to_host(slot_out[slot], pinned_out[slot])
+            mark('c_copies')
             copied = torch.cuda.Event()
             copied.record()
-        for t_ in (q['symbols'], hist, overflow):
-            t_.record_stream(coder_stream)
-        worker.jobs.put((copied, pinned_results[slot], pinned_hist[slot][0], pinned_hist[slot][1], slot_free[slot]))
+        mark('coder')
+        worker.jobs.put((copied,) + pinned_views[slot] + (slot_free[slot],))
         dead_total.add_((q['nonzero_flags'] == 0).sum())
         d = decoder.v
         t = dev.gdn(q['shifted'], decoder.g[4], d['decoder/beta_4'], inverse=True)
@@ -216,6 +245,7 @@ def main():
         t = timed_launch('tconv2_igdn6', lambda: dev.tconv5x5s2(t, decoder.w5, d['decoder/biases_5'], dev.NORM_IGDN,
                                                                 decoder.g[6], d['decoder/beta_6']), record)
         dev.tconv9x9s4_luma(t, decoder.w6, want_f32=False, want_u8=True, ref_u8=images, sse=sse_total)
+        mark('decoder')
 
     def drain():
         torch.cuda.synchronize()
@@ -238,11 +268,14 @@ def main():
     dead_total.zero_()
     worker.busy_s = 0.
 
+    # the launch thread allocates only short-lived wrappers: keep the cyclic collector (a 30 ms pause every ~75 steps) out of it
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     step_marks = []
     for i in range(args.steps):
-        if os.environ.get('EAE_BENCH_TRACE'):
+        if tracing:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             step_marks.append((time.perf_counter() - t0, ev))
@@ -256,6 +289,7 @@ def main():
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -292,7 +326,7 @@ def main():
                    'truncated_unary_length': TRUNCATED_UNARY_LENGTH, 'idx_map_exception': IDX_MAP_EXCEPTION,
                    'weights': 'random-init fixed-bin-width architecture (trained checkpoints absent from the reference)',
                    'parallelism': 'image shards, one process per GPU' if world > 1 else 'single GPU',
-                   'coder': 'device, one map per lane, encode + decode + compare'},
+                   'coder': 'device, 64 maps per wavefront, encode + decode + compare'},
         'images_per_s': round(nb_images_total/elapsed, 2),
         'rate_bpp': round(bpp, 5), 'psnr_db_pooled': round(mean_psnr, 4), 'dead_maps_per_image': round(stats[2].item()/nb_images_total, 3),
         'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_wave_kernel (conv2+GDN2, conv3+GDN3, tconv1+IGDN5, tconv2+IGDN6)',
@@ -303,9 +337,20 @@ def main():
                      'algorithmic_flop_per_launch': {k: flops[k]*pixels_per_step for k in flops}},
     }
     if step_marks:
+        sections = {}
+        slow = []
+        for ((tag_a, t_a), (tag_b, t_b)) in zip(host_marks[:-1], host_marks[1:]):
+            if tag_b == 'begin':
+                continue
+            sections.setdefault(tag_b, []).append((t_b - t_a)*1e3)
+            if (t_b - t_a) > 4e-3:
+                slow.append((tag_b, len(sections[tag_b]) - 1, round((t_b - t_a)*1e3, 1)))
+        sys.stderr.write('TRACE host sections mean ms: {}\nTRACE host sections > 4 ms (section, step, ms): {}\n'.format(
+            {k: round(sum(v_)/len(v_), 3) for (k, v_) in sections.items()}, slow))
         host = [round(m[0]*1e3, 2) for m in step_marks]
         gpu = [round(step_marks[0][1].elapsed_time(m[1]), 2) for m in step_marks]
-        sys.stderr.write('TRACE host enqueue start (ms): {}\nTRACE gpu step start (ms): {}\nTRACE total ms {}\n'.format(host, gpu, round(elapsed*1e3, 2)))
+        sys.stderr.write('TRACE host enqueue deltas (ms): {}\nTRACE gpu step deltas (ms): {}\nTRACE total ms {}\n'.format(
+            [round(b - a, 1) for (a, b) in zip(host[:-1], host[1:])], [round(b - a, 1) for (a, b) in zip(gpu[:-1], gpu[1:])], round(elapsed*1e3, 2)))
     worker.jobs.put(None)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

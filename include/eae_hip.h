@@ -39,6 +39,11 @@ const char* eae_hip_version(void);
 /* Fills name (e.g. "gfx950:sramecc+:xnack-"), CU count; returns 0, or a hipError_t when no device is usable. */
 int eae_hip_device_info(char* name, int name_cap, int* compute_units, int* clock_mhz, int64_t* hbm_bytes);
 
+/* Small results for the host (bit counts, statuses, histograms): a kernel copies `bytes` (multiple of 4) from device
+ * memory into PINNED, device-mapped host memory (hipHostMalloc / torch pin_memory) in stream order; the host reads them
+ * after synchronising an event recorded behind it. Unlike hipMemcpyAsync this never blocks the calling thread. */
+int eae_hip_publish_to_host(const void* src_device, void* dst_host_mapped, uint64_t bytes, void* stream);
+
 /* ---- analysis transform (eae/graph/components.py:86-142) ---------------------------------------------------------*/
 
 /* conv_1 + bias_add + gdn_1  (components.py:119-125; tf.nn.conv2d 9x9, 1->128, stride 4, 'SAME' = pad 2/3;
@@ -172,6 +177,28 @@ int eae_hip_coder_verify_maps(uint32_t n_maps, uint32_t map_size, const int16_t*
                               const double* probabilities, const int32_t* prob_row, const uint8_t* streams,
                               uint64_t stream_stride_bytes, const uint32_t* bac_bits, const uint32_t* bypass_bits,
                               int32_t* status, int32_t* stage, int lanes_per_wave, void* stream);
+
+/* ---- the same coder, 64 maps per wavefront in step (csrc/hip/coder_simd.hip) -----------------------------------------
+ * Same arguments, stream layout and results as the entry points above, organised for the machine: binarisation and the
+ * bypass stream are computed in parallel over the symbols, the arithmetic coder runs decision-synchronously with one
+ * map per lane, and every map the fast kernels cannot finish (any error, exotic lengths) is recoded by the general
+ * kernel, so statuses, stages, bit counts and bytes are identical in every case. These are the launches bench.py times.
+ *   workspace: device scratch of eae_hip_coder_workspace_bytes(n_maps, map_size, L) bytes, private to the call chain
+ *   (encode_batch followed by decode_batch of the same maps may share it; concurrent batches need their own).
+ *   encode_batch: symbols -> streams + bac_bits/bypass_bits/status/stage (all written for every map).
+ *   decode_batch: streams -> symbols_out (expected == NULL; status/stage written for every map; skipped maps are left
+ *   untouched), or, with expected != NULL, decode into the workspace (symbols_out may be NULL) and compare: maps whose
+ *   status is already non-zero are left alone, a difference gives status 6 (EAE_ROUNDTRIP_MISMATCH). */
+uint64_t eae_hip_coder_workspace_bytes(uint32_t n_maps, uint32_t map_size, uint8_t truncated_unary_length);
+int eae_hip_coder_encode_batch(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, uint8_t truncated_unary_length,
+                               const double* probabilities, const int32_t* prob_row, uint8_t* streams,
+                               uint64_t stream_stride_bytes, uint32_t* bac_bits, uint32_t* bypass_bits, int32_t* status,
+                               int32_t* stage, void* workspace, uint64_t workspace_bytes, void* stream);
+int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symbols_out, const int16_t* expected,
+                               uint8_t truncated_unary_length, const double* probabilities, const int32_t* prob_row,
+                               const uint8_t* streams, uint64_t stream_stride_bytes, const uint32_t* bac_bits,
+                               const uint32_t* bypass_bits, int32_t* status, int32_t* stage, void* workspace,
+                               uint64_t workspace_bytes, void* stream);
 
 /* Diagnostic hook (not part of the path): when given a device buffer of grid * waves * 8 uint64, the conv GEMM kernel
  * records s_memtime stamps per wave (start, loop start, loop end, GDN end, end, K-steps, XCC id, HW id). NULL disables. */

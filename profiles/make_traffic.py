@@ -4,7 +4,7 @@ MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass).
 usage: python profiles/make_traffic.py <dir with pmc_fetch/ pmc_write/ pmc_mfma/ sub-directories> <batch>
 
 FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled (gfx950 tallies 128-B requests of 16-B/lane loads at 64 B).
-The four conv GEMM launches of a step are told apart by their grid size and order inside the step."""
+The four conv GEMM launches of a step are told apart by their template instance."""
 import collections
 import csv
 import glob
@@ -23,11 +23,16 @@ def rows_of(directory):
     return rows
 
 
-def per_kernel(directory, counter):
-    """Counter value per dispatch of the conv GEMM wave kernel, in dispatch order."""
+# template arguments <waves per block, epilogue> of the four launches at Kodak batch sizes (conv_gemm.hip, launch())
+INSTANCES = {'conv2_gdn2': 'conv_gemm_wave_kernel<2, 1>', 'conv3_gdn3': 'conv_gemm_wave_kernel<1, 1>',
+             'tconv1_igdn5': 'conv_gemm_wave_kernel<1, 2>', 'tconv2_igdn6': 'conv_gemm_wave_kernel<2, 2>'}
+
+
+def per_kernel(directory, counter, name):
+    """Counter values of every dispatch of one conv GEMM instance."""
     out = collections.OrderedDict()
     for r in rows_of(directory):
-        if r['Counter_Name'] != counter or 'conv_gemm_wave_kernel' not in r['Kernel_Name']:
+        if r['Counter_Name'] != counter or INSTANCES[name] not in r['Kernel_Name']:
             continue
         out[int(r['Dispatch_Id'])] = out.get(int(r['Dispatch_Id']), 0.) + float(r['Counter_Value'])
     return [out[k] for k in sorted(out)]
@@ -42,19 +47,18 @@ def main():
     act = {4: pixels//16*128*4, 8: pixels//64*128*4, 16: pixels//256*128*4}
     algorithmic = {'conv2_gdn2': act[4] + act[8], 'conv3_gdn3': act[8] + act[16], 'tconv1_igdn5': act[16] + act[8],
                    'tconv2_igdn6': act[8] + act[4]}
-    fetch = per_kernel(os.path.join(root, 'pmc_fetch'), 'FETCH_SIZE')
-    write = per_kernel(os.path.join(root, 'pmc_write'), 'WRITE_SIZE')
-    busy = per_kernel(os.path.join(root, 'pmc_mfma'), 'SQ_VALU_MFMA_BUSY_CYCLES')
-    active = per_kernel(os.path.join(root, 'pmc_mfma'), 'GRBM_GUI_ACTIVE')
     result = {}
-    for (i, name) in enumerate(names):
-        sel = slice(i, None, 4)
-        n = len(fetch[sel])
+    for name in names:
+        fetch = per_kernel(os.path.join(root, 'pmc_fetch'), 'FETCH_SIZE', name)
+        write = per_kernel(os.path.join(root, 'pmc_write'), 'WRITE_SIZE', name)
+        busy = per_kernel(os.path.join(root, 'pmc_mfma'), 'SQ_VALU_MFMA_BUSY_CYCLES', name)
+        active = per_kernel(os.path.join(root, 'pmc_mfma'), 'GRBM_GUI_ACTIVE', name)
         result[name] = {
-            'hbm_read_bytes': 2.*1024.*sum(fetch[sel])/n,
-            'hbm_write_bytes': 1024.*sum(write[sel])/len(write[sel]),
+            'dispatches': len(fetch),
+            'hbm_read_bytes': 2.*1024.*sum(fetch)/len(fetch),
+            'hbm_write_bytes': 1024.*sum(write)/len(write),
             'algorithmic_bytes': algorithmic[name],
-            'mfma_busy_fraction_of_kernel_cycles': round((sum(busy[sel])/1024.)/(sum(active[sel])/8.), 3) if active else None,
+            'mfma_busy_fraction_of_kernel_cycles': round((sum(busy)/1024.)/(sum(active)/8.), 3) if active else None,
         }
     result['hbm_bytes_per_launch'] = sum(result[n]['hbm_read_bytes'] + result[n]['hbm_write_bytes'] for n in names)/4.
     result['algorithmic_bytes_per_launch'] = sum(algorithmic.values())/4.

@@ -20,15 +20,20 @@ rows = torch.arange(128, dtype=torch.int32).repeat(24)
 rows[67::128] = -1
 rows = rows.cuda()
 print('abs mean', sym.abs().float().mean().item(), 'max', sym.abs().max().item())
-for mode in (1, 2, 3):
-    for lanes in (0, 1, 8):
-        (s, _) = dev.coder_compress_maps(sym, p, rows, 10, mode=min(mode, 2), lanes_per_wave=lanes)
+for mode in (1, 3, 4, 5):
+    for lanes in ((0, 1, 8) if mode < 4 else (64,)):
+        (s, _) = dev.coder_compress_maps(sym, p, rows, 10, mode=min(mode, 2) if mode < 4 else 1, lanes_per_wave=lanes)
+        ws = dev.coder_workspace(sym.shape[0], 1536, 10, sym.device)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(5):
             if mode == 3:
                 dev.coder_verify_maps(s, sym, p, rows, lanes)
+            elif mode == 4:
+                dev.coder_encode_batch(sym, p, rows, 10, out=s, workspace=ws)
+            elif mode == 5:
+                dev.coder_decode_batch(s, p, rows, expected=sym, workspace=ws)
             else:
                 dev.coder_compress_maps(sym, p, rows, 10, mode=mode, out=s, lanes_per_wave=lanes)
         b.record(); torch.cuda.synchronize()
@@ -62,7 +67,7 @@ rows = rows[:64].contiguous()
 print('64 maps only: encode', timeit(few, 1), 'verify', timeit(few, 3))
 if os.environ.get('EAE_CODER_DEBUG_CLOCKS'):
     rows = torch.arange(128, dtype=torch.int32).repeat(24).cuda()
-    for lanes in (0, 1, 8):
+    for lanes in ((0, 1, 8) if mode < 4 else (64,)):
         (s3, _) = dev.coder_compress_maps(sym, p, rows, 10, mode=1, lanes_per_wave=lanes)
         (s3, _) = dev.coder_compress_maps(sym, p, rows, 10, mode=1, lanes_per_wave=lanes, out=s3)
         torch.cuda.synchronize()

@@ -198,6 +198,128 @@ def test_verify_launch_detects_a_corrupted_stream(gold, dev):
     assert int(streams.status[9].item()) == 1
 
 
+# ---- the 64-maps-per-wavefront organisation (eae_hip_coder_encode_batch / decode_batch) ----------------------------------
+
+def batch_code(dev, planar, probs, prob_row):
+    sym = torch.from_numpy(planar).cuda()
+    p = torch.from_numpy(numpy.ascontiguousarray(probs, dtype=numpy.float64)).cuda()
+    rows = torch.from_numpy(numpy.ascontiguousarray(prob_row, dtype=numpy.int32)).cuda()
+    streams = dev.coder_encode_batch(sym, p, rows, probs.shape[1])
+    torch.cuda.synchronize()
+    return streams, sym, p, rows
+
+
+def assert_equals_host(streams, planar, probs, prob_row, tag=''):
+    (h_streams, h_bac, h_byp, h_status, h_stage) = host_encode_maps(planar, probs, prob_row)
+    status = streams.status.cpu().numpy()
+    assert numpy.array_equal(status, h_status), (tag, status, h_status)
+    assert numpy.array_equal(streams.stage.cpu().numpy(), h_stage), tag
+    ok = status == 0
+    assert numpy.array_equal(streams.bac_bits.cpu().numpy()[ok], h_bac[ok].astype(numpy.int32)), tag
+    assert numpy.array_equal(streams.bypass_bits.cpu().numpy()[ok], h_byp[ok].astype(numpy.int32)), tag
+    d = streams.streams.cpu().numpy()
+    half = streams.stride//2
+    for m in numpy.nonzero(ok)[0]:
+        assert valid_bytes_equal(d[m], h_streams[m], h_bac[m]), (tag, m)
+        assert valid_bytes_equal(d[m, half:], h_streams[m, half:], h_byp[m]), (tag, m)
+    return ok
+
+
+@pytest.mark.parametrize('scale', [0.3, 2., 40., 3000.])
+def test_batch_encoder_and_decoder_equal_the_host_coder(gold, dev, scale):
+    """Sparse maps, dense maps (streams longer than the decoder's LDS window -> general kernel), Exp-Golomb escapes."""
+    rng = numpy.random.RandomState(int(scale*10))
+    probs = gold['real_probabilities_1']
+    n = 3*128 + 5                                               # a ragged last group of 64
+    planar = numpy.clip(numpy.round(rng.laplace(size=(n, 96))*rng.uniform(0.1, 1., size=(n, 1))*scale), -32768, 32767).astype(numpy.int16)
+    planar[7] = 0                                               # a dead map: a stream of a few bits
+    prob_row = (numpy.arange(n) % 128).astype(numpy.int32)
+    prob_row[67::128] = -1
+    (streams, sym, p, rows) = batch_code(dev, planar, probs, prob_row)
+    ok = assert_equals_host(streams, planar, probs, prob_row, scale)
+    assert ok.all()
+    out = dev.coder_decode_batch(streams, p, rows).cpu().numpy()
+    keep = prob_row >= 0
+    assert not streams.status.cpu().numpy().any()
+    assert numpy.array_equal(out[keep], planar[keep]) and not out[~keep].any()
+    dev.coder_decode_batch(streams, p, rows, expected=sym)
+    assert not streams.status.cpu().numpy().any()
+    # a flipped bit in one arithmetic-coded stream is found by the comparison, and only there
+    streams.streams[5, 1] ^= 0x04
+    dev.coder_decode_batch(streams, p, rows, expected=sym)
+    status = streams.status.cpu().numpy()
+    assert status[5] != 0 and not numpy.delete(status, 5).any()
+
+
+def test_batch_golden_streams_of_the_reference_build(gold, dev):
+    for i in range(int(gold['nb_cases'])):
+        x = numpy.ascontiguousarray(gold['case{}_in'.format(i)]).reshape(1, -1)
+        p = gold['case{}_p'.format(i)].reshape(1, -1)
+        if x.size == 0:
+            continue
+        (streams, sym, pd, rows) = batch_code(dev, x, p, numpy.zeros(1, dtype=numpy.int32))
+        assert int(streams.status.item()) == 0, i
+        assert (int(streams.bac_bits.item()), int(streams.bypass_bits.item())) == (int(gold['case{}_bac_bits'.format(i)]),
+                                                                                  int(gold['case{}_byp_bits'.format(i)])), i
+        d = streams.streams.cpu().numpy()[0]
+        (bac, byp) = (gold['case{}_bac'.format(i)], gold['case{}_byp'.format(i)])
+        assert numpy.array_equal(d[:bac.size], bac) and numpy.array_equal(d[streams.stride//2:streams.stride//2 + byp.size], byp), i
+        assert numpy.array_equal(dev.coder_decode_batch(streams, pd, rows).cpu().numpy(), x), i
+
+
+def test_batch_fuzz_against_host_coder_including_errors(gold, dev):
+    """Random sizes, L (including L > 32, which the fast kernels hand to the general one), magnitudes and a few invalid
+    probabilities: statuses, stages, bits and bytes equal the host library's; what encodes also decodes."""
+    rng = numpy.random.RandomState(123)
+    seen = set()
+    for t in range(150):
+        n_maps = int(rng.randint(1, 140))
+        size = int(rng.randint(1, 200))
+        L = int(rng.choice([1, 2, 5, 10, 31, 32, 33, 60]))
+        scale = rng.choice([0.2, 1, 3, 10, 100, 5000], size=(n_maps, 1))
+        planar = numpy.clip(numpy.round(rng.laplace(size=(n_maps, size))*scale), -32768, 32767).astype(numpy.int16)
+        probs = numpy.clip(rng.rand(n_maps, L), 0.005, 0.995)
+        if t % 5 == 0:
+            probs[rng.randint(n_maps), rng.randint(L)] = rng.choice([0., 1., numpy.nan, -0.2])
+        rows = numpy.arange(n_maps, dtype=numpy.int32)
+        if t % 7 == 0:
+            rows[rng.randint(n_maps)] = -1
+        (streams, sym, p, r) = batch_code(dev, planar, probs, rows)
+        ok = assert_equals_host(streams, planar, probs, rows, t)
+        seen.update(int(v) for v in streams.status.cpu().numpy())
+        encode_status = streams.status.clone()
+        dev.coder_decode_batch(streams, p, r, expected=sym)
+        assert torch.equal(streams.status, encode_status), t          # nothing new: every encoded map decodes to its input
+        out = dev.coder_decode_batch(streams, p, r).cpu().numpy()     # pure decode rewrites every status
+        good = ok & (rows >= 0)
+        assert numpy.array_equal(out[good], planar[good]), t
+    assert {0, 1, 4} <= seen
+
+
+def test_batch_full_kodak_batch(gold, dev):
+    from autoencoder_based_image_compression_amd.kodak.lossless import compression
+    rng = numpy.random.RandomState(11)
+    probs = gold['real_probabilities_1']
+    planar = numpy.round(rng.laplace(size=(24, 128, 1536))*rng.uniform(0.05, 6., size=(1, 128, 1))).astype(numpy.int16)
+    prob_row = numpy.tile(numpy.arange(128, dtype=numpy.int32), 24)
+    prob_row[67::128] = -1
+    (_, nb_bits) = compression.code_planar_symbols(planar, probs, idx_map_exception=67, nb_threads=8, roundtrip=False)
+    (streams, sym, p, rows) = batch_code(dev, planar.reshape(-1, 1536), probs, prob_row)
+    assert not streams.status.cpu().numpy().any()
+    assert numpy.array_equal(streams.nb_bits().cpu().numpy().reshape(24, 128), nb_bits.astype(numpy.int32))
+    dev.coder_decode_batch(streams, p, rows, expected=sym)
+    assert not streams.status.cpu().numpy().any()
+    # and the per-lane kernels agree byte for byte
+    (ref_streams, _, _, _) = device_code(dev, planar.reshape(-1, 1536), probs, prob_row, dev.CODER_ENCODE_ONLY)
+    half = streams.stride//2
+    a = streams.streams.cpu().numpy()
+    b = ref_streams.streams.cpu().numpy()
+    bac = streams.bac_bits.cpu().numpy()
+    byp = streams.bypass_bits.cpu().numpy()
+    for m in range(0, a.shape[0], 37):
+        assert valid_bytes_equal(a[m], b[m], bac[m]) and valid_bytes_equal(a[m, half:], b[m, half:], byp[m]), m
+
+
 def test_argument_checks(dev):
     lib = _native.hip()
     assert lib.eae_hip_coder_compress_maps(1, 4, None, None, 3, None, None, None, 64, None, None, None, None, 1, 0, None) == -1

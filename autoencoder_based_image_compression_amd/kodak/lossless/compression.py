@@ -1,9 +1,11 @@
 """Per-image lossless coding of the quantized latent variables; mirrors kodak_tensorflow/lossless/compression.py.
 
 `compress_lossless_maps` :11-82 and `rescale_compress_lossless_maps` :84-154, same signatures, return values and
-exceptions. Differences in HOW: the float -> int16 symbol conversion and the exception map's histogram run on the
-MI355X (one kernel, symbols land map-major so that ONE device -> host copy feeds the coder); the 127 coder calls of
-the reference's Python loop (:67-81) become one threaded `eae_coder_compress_maps` call (include/eae_coder.h).
+exceptions. Differences in HOW: the float -> int16 symbol conversion, the exception map's histogram AND the coder run on
+the MI355X: the 127 coder calls of the reference's Python loop (:67-81) become the launches of
+`eae_hip_coder_encode_batch` / `eae_hip_coder_decode_batch` (include/eae_hip.h) over symbols that never leave HBM; only
+the per-map bit counts and statuses come back. `code_planar_symbols` is the same thing on the host cores through
+`eae_coder_compress_maps` (include/eae_coder.h) for callers whose symbols live in host memory.
 """
 import ctypes
 import os
@@ -72,6 +74,48 @@ def code_planar_symbols(symbols_planar, binary_probabilities, idx_map_exception=
     return (reconstruction, nb_bits.reshape(nb_images, nb_maps))
 
 
+def code_planar_symbols_device(symbols_planar, binary_probabilities, idx_map_exception=-1, want_reconstruction=False):
+    """`code_planar_symbols` for symbols that are already on the device (torch int16 (nb_images, nb_maps, map_size)):
+    encode, decode and compare without leaving HBM. Returns (reconstruction device tensor or None, nb_bits uint32 numpy
+    (nb_images, nb_maps)); raises exactly like `code_planar_symbols`."""
+    import torch
+    (nb_images, nb_maps, map_size) = symbols_planar.shape
+    probabilities = numpy.ascontiguousarray(binary_probabilities, dtype=numpy.float64)
+    truncated_unary_length = probabilities.shape[1]
+    if truncated_unary_length > 255:
+        raise OverflowError('value too large to convert to numpy.uint8_t')   # interface_cython.pyx:49
+    device = symbols_planar.device
+    prob_row = numpy.tile(numpy.arange(nb_maps, dtype=numpy.int32), nb_images)
+    if idx_map_exception >= 0:
+        prob_row[idx_map_exception::nb_maps] = -1
+    symbols = symbols_planar.reshape(nb_images*nb_maps, map_size)
+    probabilities_device = torch.from_numpy(probabilities).to(device)
+    prob_row_device = torch.from_numpy(prob_row).to(device)
+    streams = dev.coder_encode_batch(symbols, probabilities_device, prob_row_device, truncated_unary_length)
+    encode_results = streams.results.clone()
+    reconstruction = None
+    if want_reconstruction:
+        reconstruction = dev.coder_decode_batch(streams, probabilities_device, prob_row_device)
+        skipped = prob_row_device < 0
+        reconstruction[skipped] = symbols[skipped]              # the exception map is passed through (compression.py:68-75)
+        reconstruction = reconstruction.reshape(nb_images, nb_maps, map_size)
+        decode_status = streams.status.clone()
+        mismatch = ((reconstruction.reshape(-1, map_size) != symbols).any(dim=1) & (decode_status == 0)).to(torch.int32)*6
+        final = torch.where(encode_results[2] != 0, encode_results[2], torch.where(decode_status != 0, decode_status, mismatch))
+        stage = torch.where(encode_results[2] != 0, encode_results[3], streams.stage)
+    else:
+        dev.coder_decode_batch(streams, probabilities_device, prob_row_device, expected=symbols)
+        (final, stage) = (streams.status, streams.stage)
+    host = torch.stack([encode_results[0], encode_results[1], final, stage]).cpu().numpy()      # the one device -> host copy
+    bad = numpy.flatnonzero(host[2])
+    if bad.size and int(host[2, bad[0]]) == 6:
+        raise AssertionError('\nArrays are not equal\nThe lossless compression has altered the centered quantized data.')
+    if bad.size:
+        interface_cython.raise_for_status(int(host[2, bad[0]]), int(host[3, bad[0]]))
+    nb_bits = (host[0].astype(numpy.int64) + host[1].astype(numpy.int64)).astype(numpy.uint32)
+    return (reconstruction, nb_bits.reshape(nb_images, nb_maps))
+
+
 def exception_map_nb_bits(hist_row, map_size):
     """compression.py:73-74: ceil(h*w*discrete_entropy(map, 1.)) from the map's exact symbol histogram."""
     occupied = numpy.flatnonzero(hist_row)
@@ -101,13 +145,13 @@ def compress_lossless_maps(ref_int16, path_to_binary_probabilities, idx_map_exce
         raise ValueError('`binary_probabilities.ndim` is not equal to 2.')
     if binary_probabilities.shape[0] != nb_maps:
         raise ValueError('`binary_probabilities.shape[0]` is not equal to `ref_int16.shape[2]`.')
-    planar = numpy.ascontiguousarray(ref_int16.reshape(height_map*width_map, nb_maps).T)[None]
-    (rec_planar, nb_bits) = code_planar_symbols(planar, binary_probabilities, idx_map_exception)
+    planar = bk.to_device(numpy.ascontiguousarray(ref_int16.reshape(height_map*width_map, nb_maps).T)[None])
+    (rec_planar, nb_bits) = code_planar_symbols_device(planar, binary_probabilities, idx_map_exception, want_reconstruction=True)
     nb_bits_each_map = nb_bits[0].copy()
     if 0 <= idx_map_exception < nb_maps:
-        (hist, radius) = tls._symbol_histograms(bk.to_device(planar[0, idx_map_exception:idx_map_exception + 1]))
+        (hist, radius) = tls._symbol_histograms(planar[0, idx_map_exception:idx_map_exception + 1].contiguous())
         nb_bits_each_map[idx_map_exception] = exception_map_nb_bits(hist[0], height_map*width_map)
-    rec_int16 = numpy.ascontiguousarray(rec_planar[0].T).reshape(height_map, width_map, nb_maps)
+    rec_int16 = numpy.ascontiguousarray(bk.to_host(rec_planar[0]).T).reshape(height_map, width_map, nb_maps)
     return (rec_int16, nb_bits_each_map)
 
 
@@ -140,12 +184,13 @@ def rescale_compress_lossless_maps(centered_quantized_data, bin_widths_test, pat
     checks = res['checks'].cpu().tolist()
     if checks[0] != 0:
         raise AssertionError('The rounded array elements cannot be represented as 16-bit signed integers.')
-    symbols_planar = bk.to_host(res['symbols'])                      # the single device -> host copy
-    (rec_planar, nb_bits) = code_planar_symbols(symbols_planar, binary_probabilities, idx_map_exception)
+    # encode + decode + compare on the device (the decoded-equals-input half of the assert of compression.py:146-153
+    # is status 6 of the coder; checks[2] is its symbol*bw == cq half)
+    (_, nb_bits) = code_planar_symbols_device(res['symbols'], binary_probabilities, idx_map_exception)
     nb_bits_each_map = nb_bits[0]
     if 0 <= idx_map_exception < nb_maps:
         (hist, radius) = tls._symbol_histograms(res['symbols'][:, idx_map_exception:idx_map_exception + 1].contiguous())
         nb_bits_each_map[idx_map_exception] = exception_map_nb_bits(hist[0], height_map*width_map)
-    if checks[2] != 0 or not numpy.array_equal(rec_planar, symbols_planar):
+    if checks[2] != 0:
         raise AssertionError('\nArrays are not equal\nThe lossless compression has altered the centered quantized data.')
     return numpy.sum(nb_bits_each_map).item()

@@ -209,6 +209,56 @@ extern "C" int eae_hip_nonzero_flags(const float* x, uint32_t* nonzero_flags, in
     return EAE_HIP_OK;
 }
 
+// ---- statistics for lossless/stats.py:197-241 (find_index_map_exception) ---------------------------------------------
+// Per-map minimum / maximum (numpy.amin / amax of stats.py:103-104) through order-preserving uint keys and integer atomics.
+__device__ __forceinline__ unsigned int float_key(float f) {
+    const unsigned int b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned int k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+__global__ void minmax_init_kernel(unsigned int* __restrict__ keys, int c_count) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < c_count) { keys[c] = 0xFFFFFFFFu; keys[c_count + c] = 0u; }
+}
+__global__ __launch_bounds__(256) void map_minmax_kernel(const float* __restrict__ y, unsigned int* __restrict__ keys, long rows,
+                                                         int c_count) {
+    const int c = threadIdx.x % c_count;
+    const int lanes_per_c = 256 / c_count;
+    const int sub = threadIdx.x / c_count;
+    if (sub >= lanes_per_c) return;
+    unsigned int lo = 0xFFFFFFFFu, hi = 0u;
+    for (long r = (long)blockIdx.x * lanes_per_c + sub; r < rows; r += (long)gridDim.x * lanes_per_c) {
+        const unsigned int k = float_key(y[r * c_count + c]);
+        lo = k < lo ? k : lo;
+        hi = k > hi ? k : hi;
+    }
+    atomicMin(&keys[c], lo);
+    atomicMax(&keys[c_count + c], hi);
+}
+__global__ void minmax_final_kernel(const unsigned int* __restrict__ keys, float* __restrict__ out, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = key_float(keys[i]);
+}
+// Per-map histogram of floor(y) (the unit-width intervals of compute_probabilities_intervals, stats.py:70-134):
+// hist[c][floor(y) + radius] += 1; values outside [-radius, radius] are counted in overflow[c].
+__global__ __launch_bounds__(256) void floor_hist_kernel(const float* __restrict__ y, unsigned int* __restrict__ hist, int radius,
+                                                         unsigned int* __restrict__ overflow, long rows, int c_count) {
+    const int c = threadIdx.x % c_count;
+    const int lanes_per_c = 256 / c_count;
+    const int sub = threadIdx.x / c_count;
+    if (sub >= lanes_per_c) return;
+    const int nb = 2 * radius + 1;
+    unsigned int over = 0;
+    for (long r = (long)blockIdx.x * lanes_per_c + sub; r < rows; r += (long)gridDim.x * lanes_per_c) {
+        const float f = floorf(y[r * c_count + c]);
+        if (f >= (float)-radius && f <= (float)radius) atomicAdd(&hist[(size_t)c * nb + ((int)f + radius)], 1u);
+        else over++;                                                   // also NaN
+    }
+    if (over) atomicAdd(&overflow[c], over);
+}
+
 extern "C" int eae_hip_map_sums(const float* y, double* sums, int64_t rows, int c, void* stream) {
     if (!y || !sums || rows <= 0 || c <= 0 || c > 256) return EAE_HIP_BAD_ARGUMENT;
     const long per_block = 256 / c;
@@ -254,6 +304,31 @@ extern "C" int eae_hip_sse_u8(const uint8_t* a, const uint8_t* b, uint64_t* sse,
     if (bpi > 64) bpi = 64;
     hipLaunchKernelGGL(sse_kernel, dim3((unsigned)(n * bpi)), dim3(256), 0, (hipStream_t)stream, a, b,
                        reinterpret_cast<unsigned long long*>(sse), (long)pixels_per_image, (int)bpi);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}
+
+extern "C" int eae_hip_map_minmax(const float* y, float* minmax, uint32_t* scratch_keys, int64_t rows, int c, void* stream) {
+    if (!y || !minmax || !scratch_keys || rows <= 0 || c <= 0 || c > 256) return EAE_HIP_BAD_ARGUMENT;
+    hipStream_t s = (hipStream_t)stream;
+    const long per_block = 256 / c;
+    long blocks = (rows + per_block * 64 - 1) / (per_block * 64);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(256), 0, s, scratch_keys, c);
+    hipLaunchKernelGGL(map_minmax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y, scratch_keys, (long)rows, c);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(2), dim3(256), 0, s, scratch_keys, minmax, 2 * c);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}
+
+extern "C" int eae_hip_floor_histograms(const float* y, uint32_t* hist, int radius, uint32_t* overflow, int64_t rows, int c,
+                                        void* stream) {
+    if (!y || !hist || !overflow || rows <= 0 || c <= 0 || c > 256 || radius < 0 || radius > (1 << 20)) return EAE_HIP_BAD_ARGUMENT;
+    const long per_block = 256 / c;
+    long blocks = (rows + per_block * 64 - 1) / (per_block * 64);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(floor_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, hist, radius, overflow,
+                       (long)rows, c);
     EAE_HIP_CHECK_LAUNCH();
     return EAE_HIP_OK;
 }

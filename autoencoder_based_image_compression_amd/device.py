@@ -172,6 +172,25 @@ def map_means(y):
     return (sums/rows).to(torch.float32)
 
 
+def map_minmax(y):
+    """Per-map minimum and maximum over every other axis of y [..., C]: float32 [2, C]."""
+    c = y.shape[-1]
+    out = torch.empty((2, c), dtype=torch.float32, device=y.device)
+    keys = torch.empty(2*c, dtype=torch.int32, device=y.device)
+    _check(_native.hip().eae_hip_map_minmax(_p(y), _p(out), _p(keys), y.numel()//c, c, _stream()), 'eae_hip_map_minmax')
+    return out
+
+
+def floor_histograms(y, radius):
+    """Per-map histogram of floor(y) for y [..., C]: (hist int32 [C, 2*radius+1] with bin floor(y)+radius, overflow int32 [C])."""
+    c = y.shape[-1]
+    hist = torch.zeros((c, 2*radius + 1), dtype=torch.int32, device=y.device)
+    overflow = torch.zeros(c, dtype=torch.int32, device=y.device)
+    _check(_native.hip().eae_hip_floor_histograms(_p(y), _p(hist), radius, _p(overflow), y.numel()//c, c, _stream()),
+           'eae_hip_floor_histograms')
+    return hist, overflow
+
+
 def nonzero_flags(x):
     """x [N, ..., C] -> int32 [N, C], 1 where map (n, c) has a non-zero element."""
     n = x.shape[0]

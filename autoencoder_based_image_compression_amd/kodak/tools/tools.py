@@ -143,6 +143,31 @@ def float_to_str(float_in):
     return str_in.replace('-', 'minus')
 
 
+def jensen_shannon_divergence(probs_0, probs_1):
+    """Jensen-Shannon divergence between two probability distributions (tools.py:615-666), float64 on the host.
+
+    Raises
+    ------
+    ValueError
+        If a probability does not belong to ]0.0, 1.0[, a distribution does not sum to 1.0, or the divergence leaves [0, 1].
+    """
+    if numpy.any(probs_0 <= 0.) or numpy.any(probs_0 >= 1.):
+        raise ValueError('A probability in `probs_0` does not belong to ]0.0, 1.0[.')
+    if numpy.any(probs_1 <= 0.) or numpy.any(probs_1 >= 1.):
+        raise ValueError('A probability in `probs_1` does not belong to ]0.0, 1.0[.')
+    if abs(numpy.sum(probs_0).item() - 1.) >= 1.e-9:
+        raise ValueError('The probabilities in `probs_0` do not sum to 1.0.')
+    if abs(numpy.sum(probs_1).item() - 1.) >= 1.e-9:
+        raise ValueError('The probabilities in `probs_1` do not sum to 1.0.')
+    denominator = 0.5*(probs_0 + probs_1)
+    divergence = 0.5*numpy.sum(probs_0*numpy.log2(probs_0/denominator) + probs_1*numpy.log2(probs_1/denominator))
+    if divergence < 0.:
+        raise ValueError('The Jensen-Shannon divergence is not positive.')
+    if divergence > 1.:
+        raise ValueError('The Jensen-Shannon divergence is not smaller than 1.0.')
+    return divergence
+
+
 def psnr_2d(reference_uint8, reconstruction_uint8):
     """PSNR between the luminance image and its reconstruction (tools.py:831-881)."""
     if reference_uint8.dtype != numpy.uint8:

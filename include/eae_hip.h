@@ -11,9 +11,10 @@
  * Launches are asynchronous on `stream`.
  *
  * NUMERICS CONTRACT (mirrored by oracle/transforms_oracle.c, checked bit-for-bit in tests):
- *  - every dot product is ONE f32 fused-multiply-add chain in a fixed order (conv: taps row-major, then input
- *    channel; GDN: channel ascending), started from +0, bias/beta added afterwards -- this is what
- *    v_mfma_f32_32x32x2_f32 / 16x16x4_f32 compute (exact f32 FMA chain, k ascending);
+ *  - every dot product is ONE f32 fused-multiply-add chain in a fixed order (conv / transposed conv: input channels in
+ *    blocks of 32 (outer), then the taps row-major, then the channel inside the block; GDN: channel ascending),
+ *    started from +0, bias/beta added afterwards -- this is what v_mfma_f32_32x32x2_f32 / 16x16x4_f32 compute
+ *    (exact f32 FMA chain, k ascending);
  *  - division, sqrt are correctly rounded; rounding to integer is round-half-to-even (numpy.round).
  */
 #ifndef EAE_HIP_H
@@ -126,6 +127,16 @@ int eae_hip_quantize_maps(const float* y, const float* map_mean, const float* bi
  * The reference's float32 accumulation is not reproduced (it carries ~1e-6 relative error itself): the result is the
  * exact mean rounded to float32, within 1e-5 relative of numpy's float32 `mean`. */
 int eae_hip_map_sums(const float* y, double* sums, int64_t rows, int c, void* stream);
+
+/* The two device passes of lossless/stats.py:197-241 (find_index_map_exception), whose per-map loop calls
+ * compute_probabilities_intervals(map, 1.) (stats.py:70-134): numpy.amin / amax per map, then a histogram over the
+ * unit-width intervals [floor(min), ceil(max)].
+ *   map_minmax: minmax[0][c] = min, minmax[1][c] = max over rows of y[row][c]; scratch_keys: 2*c uint32 of scratch.
+ *   floor_histograms: hist[c][floor(y) + radius] += 1 for |floor(y)| <= radius, else overflow[c] += 1 (caller zeroes both;
+ *   hist is [c][2*radius+1]). The closed last interval of numpy.histogram (values equal to the right edge) is folded in
+ *   by the host, which also forms the probabilities and the Jensen-Shannon divergences in float64 like the reference. */
+int eae_hip_map_minmax(const float* y, float* minmax, uint32_t* scratch_keys, int64_t rows, int c, void* stream);
+int eae_hip_floor_histograms(const float* y, uint32_t* hist, int radius, uint32_t* overflow, int64_t rows, int c, void* stream);
 
 /* tls.count_nb_deads (tools.py:294-320) for an arbitrary stack x [N][hw][C]: nonzero_flags[n][c] = 1 when some
  * element of map (n, c) is != 0 (caller zeroes); the number of dead maps of image n is the number of zero flags. */

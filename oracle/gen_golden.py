@@ -227,8 +227,29 @@ def tools_golden(tls, ref_compression, ref_stats, g_coder_dir):
     sym = tls.cast_float_to_int16(ccq[0]/numpy.tile(bw2.reshape(1, 1, 128), (8, 12, 1)))
     (rec, nb_each) = ref_compression.compress_lossless_maps(sym, probs_path, 67)
     g.update(lossless_symbols=sym, lossless_rec=rec, lossless_bits_each_map=nb_each)
+    # find_index_map_exception (stats.py:197-241) and its pieces, on latents with a near-uniform map (index 41), a map
+    # whose values all fall into one unit interval (index 7 -> divergence 1), integer-valued extrema (closed last interval)
+    rng2 = numpy.random.RandomState(21)
+    ys = (rng2.laplace(size=(3, 6, 8, 128))*rng2.uniform(0.4, 5., size=128)).astype(numpy.float32)
+    ys[:, :, :, 41] = rng2.uniform(-6., 6., size=(3, 6, 8)).astype(numpy.float32)
+    ys[:, :, :, 7] = rng2.uniform(0.05, 0.95, size=(3, 6, 8)).astype(numpy.float32)
+    ys[:, :, :, 12] = rng2.laplace(size=(3, 6, 8)).astype(numpy.float32).clip(-6.5, 8.5)
+    ys[0, 0, 0, 12] = numpy.float32(9.)          # max of map 12 is an integer: it belongs to the last interval
+    ys[1, 2, 3, 12] = numpy.float32(-7.)         # min of map 12 is an integer
+    divergences = numpy.zeros(128)
+    for i in range(128):
+        probs = ref_stats.compute_probabilities_intervals(ys[:, :, :, i], 1.)[1]
+        nz = numpy.extract(probs != 0., probs)
+        divergences[i] = tls.jensen_shannon_divergence(nz, (1./nz.size)*numpy.ones(nz.size)) if nz.size > 1 else 1.
+    (edges12, probs12) = ref_stats.compute_probabilities_intervals(ys[:, :, :, 12], 1.)
+    (edges_h, probs_h) = ref_stats.compute_probabilities_intervals(ys[:, :, :, 3], 0.5)
+    p0 = numpy.array([0.1, 0.2, 0.3, 0.4])
+    p1 = numpy.array([0.25, 0.25, 0.25, 0.25])
+    g.update(stats_y=ys, stats_divergences=divergences, stats_idx=numpy.int64(ref_stats.find_index_map_exception(ys)),
+             stats_edges12=edges12, stats_probs12=probs12, stats_edges_half=edges_h, stats_probs_half=probs_h,
+             js_p0=p0, js_p1=p1, js_out=numpy.float64(tls.jensen_shannon_divergence(p0, p1)))
     numpy.savez_compressed(os.path.join(OUT, 'tools_golden.npz'), **g)
-    print('tools_golden.npz: rate', g['lat_rate'], 'bits', g['lossless_bits'], 'psnr', g['psnr_known'])
+    print('tools_golden.npz: rate', g['lat_rate'], 'bits', g['lossless_bits'], 'psnr', g['psnr_known'], 'idx exception', g['stats_idx'])
 
 
 def svhn_golden():

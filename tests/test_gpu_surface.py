@@ -223,3 +223,61 @@ def test_vary_gamma_and_batching_errors(tmp_path, tls, cgold):
             batching.encode_mini_batches(x, sess, ae, 2)                   # ndim != 4
         y = batching.encode_mini_batches(x[..., None], sess, ae, 2)
         assert y.shape == (2, 1, 2, 128) and y.dtype == numpy.float32
+
+
+def test_find_index_map_exception_and_divergences(gold):
+    """lossless/stats.py:197-241 on the device (per-map min / max + floor histograms) against the reference's own
+    compute_probabilities_intervals + jensen_shannon_divergence run on the same latents: float64 values equal exactly."""
+    from autoencoder_based_image_compression_amd.kodak.lossless import stats
+    y = gold['stats_y']
+    divergences = stats.map_divergences(y)
+    assert numpy.array_equal(divergences, gold['stats_divergences'])
+    assert divergences[7] == 1.                                   # every value of map 7 sits in one unit interval
+    assert stats.find_index_map_exception(y) == int(gold['stats_idx']) == 41
+    # the closed last interval: the maximum of map 12 is the integer 9 (and -7 sits exactly on an edge)
+    counts = stats._unit_interval_counts(y)[12]
+    edges = gold['stats_edges12']
+    assert (counts[0], counts[1]) == (int(edges[0]), int(edges[-1])) == (-7, 9) and counts[2].sum() == 3*6*8
+    assert numpy.array_equal(counts[2]/numpy.ones(counts[2].size)/counts[2].sum()*1., gold['stats_probs12'])
+    # a map whose values are all the same integer has no interval: ValueError like the reference (stats.py:106-107)
+    z = y.copy()
+    z[:, :, :, 3] = 2.
+    with pytest.raises(ValueError) as info:
+        stats.find_index_map_exception(z)
+    assert str(info.value) == 'The interval size exceeds the range of the data values.'
+
+
+def test_save_statistics_writes_the_three_kinds_of_files(tmp_path, capsys):
+    """lossless/stats.py:243-320: map means (.npy), exception index (.pkl, protocol 2), one probability table per
+    multiplier; nothing is recomputed when every file exists."""
+    from autoencoder_based_image_compression_amd.kodak import tf_shim as tf
+    from autoencoder_based_image_compression_amd.kodak.eae import batching
+    from autoencoder_based_image_compression_amd.kodak.eae.graph.EntropyAutoencoder import EntropyAutoencoder
+    from autoencoder_based_image_compression_amd.kodak.lossless import stats
+    x = numpy.random.RandomState(5).randint(16, 236, size=(4, 32, 48, 1)).astype(numpy.uint8)
+    multipliers = numpy.array([1., 1.5], dtype=numpy.float32)
+    paths = [str(tmp_path/'binary_probabilities_{}.npy'.format(tls_name)) for tls_name in ('1', '1dot5')]
+    (path_mean, path_idx) = (str(tmp_path/'map_mean.npy'), str(tmp_path/'idx_map_exception.pkl'))
+    ae = EntropyAutoencoder(2, 32, 48, 1., 10000., '', False)
+    with tf.Session() as sess:
+        ae.initialization(sess, '', seed=3)
+        with pytest.raises(ValueError):
+            stats.save_statistics(x, sess, ae, 2, multipliers, 10, path_mean, path_idx, paths[:1])
+        stats.save_statistics(x, sess, ae, 2, multipliers, 10, path_mean, path_idx, paths)
+        y = batching.encode_mini_batches(x, sess, ae, 2)
+        bin_widths = ae.get_bin_widths()
+    map_mean = numpy.load(path_mean)
+    assert map_mean.shape == (128,) and map_mean.dtype == numpy.float32
+    assert numpy.allclose(map_mean, y.astype(numpy.float64).mean(axis=(0, 1, 2)), rtol=1e-6, atol=1e-7)
+    with open(path_idx, 'rb') as f:
+        idx = pickle.load(f)
+    assert isinstance(idx, int) and idx == stats.find_index_map_exception(y)
+    for (m, path) in zip(multipliers, paths):
+        table = numpy.load(path)
+        assert table.shape == (128, 10) and table.dtype == numpy.float64
+        assert numpy.array_equal(table, stats.compute_binary_probabilities(y, m*bin_widths, map_mean, 10))
+    capsys.readouterr()
+    with tf.Session() as sess:
+        ae.initialization(sess, '', seed=3)
+        stats.save_statistics(x, sess, ae, 2, multipliers, 10, path_mean, path_idx, paths)
+    assert 'already exist' in capsys.readouterr().out

@@ -195,3 +195,27 @@ def test_dropin_directory_shadows_the_reference_imports():
             'print("dropin ok")').format(root, os.path.join(root, 'autoencoder_based_image_compression_amd', 'dropin'))
     out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
     assert out.returncode == 0 and 'dropin ok' in out.stdout, out.stdout
+
+
+def test_jensen_shannon_divergence_and_probability_intervals_against_the_reference():
+    """tools.py:615-666 and stats.py:70-134 (host numpy in the reference too): values from the reference's own functions
+    (tests/golden/tools_golden.npz), and their ValueErrors."""
+    import os
+    from autoencoder_based_image_compression_amd.kodak.lossless import stats
+    from autoencoder_based_image_compression_amd.kodak.tools import tools as tls
+    with numpy.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tools_golden.npz')) as g:
+        assert tls.jensen_shannon_divergence(g['js_p0'], g['js_p1']) == g['js_out']
+        y = g['stats_y']
+        (edges, probs) = stats.compute_probabilities_intervals(y[:, :, :, 12], 1.)
+        assert numpy.array_equal(edges, g['stats_edges12']) and numpy.array_equal(probs, g['stats_probs12'])
+        (edges, probs) = stats.compute_probabilities_intervals(y[:, :, :, 3], 0.5)
+        assert numpy.array_equal(edges, g['stats_edges_half']) and numpy.array_equal(probs, g['stats_probs_half'])
+    assert tls.jensen_shannon_divergence(numpy.array([0.5, 0.5]), numpy.array([0.5, 0.5])) == 0.
+    with pytest.raises(ValueError):
+        tls.jensen_shannon_divergence(numpy.array([0., 1.]), numpy.array([0.5, 0.5]))
+    with pytest.raises(ValueError):
+        tls.jensen_shannon_divergence(numpy.array([0.5, 0.5]), numpy.array([0.3, 0.3]))
+    with pytest.raises(ValueError):
+        stats.compute_probabilities_intervals(numpy.zeros(4, dtype=numpy.float32), 1.)        # range 0 < interval
+    with pytest.raises(ValueError):
+        stats.compute_probabilities_intervals(numpy.array([0.2, 2.7], dtype=numpy.float32), 0.7)   # 3 / 0.7 not an integer

@@ -356,6 +356,36 @@ def coder_decode_batch(streams, probabilities, prob_row, expected=None, workspac
     return out
 
 
+def coder_pack_streams(streams, offsets, payload_bytes):
+    """Gathers the valid stream bytes of every map into one uint8 device tensor; `offsets` int64 [n_maps, 2] (device)."""
+    payload = torch.zeros(max(int(payload_bytes), 1), dtype=torch.uint8, device=streams.streams.device)
+    _check(_native.hip().eae_hip_coder_pack_streams(streams.n_maps, _p(streams.streams), streams.stride, _p(streams.bac_bits),
+                                                    _p(streams.bypass_bits), _p(offsets), _p(payload), _stream()),
+           'eae_hip_coder_pack_streams')
+    return payload
+
+
+def coder_unpack_streams(payload, offsets, bac_bits, bypass_bits, map_size, truncated_unary_length):
+    """The inverse: a CoderStreams whose regions hold the bytes of `payload` (bit counts int32 [n_maps], device)."""
+    n_maps = bac_bits.numel()
+    streams = CoderStreams(n_maps, map_size, truncated_unary_length, payload.device)
+    streams.bac_bits.copy_(bac_bits)
+    streams.bypass_bits.copy_(bypass_bits)
+    _check(_native.hip().eae_hip_coder_unpack_streams(n_maps, _p(payload), _p(offsets), _p(streams.bac_bits), _p(streams.bypass_bits),
+                                                      _p(streams.streams), streams.stride, _stream()), 'eae_hip_coder_unpack_streams')
+    return streams
+
+
+def dequantize_maps(symbols_planar, bin_widths, map_mean=None, want_cq=False, want_shifted=True):
+    """int16 symbols [N, 128, hw] -> float32 [N, hw, 128]: bw * symbol (and + map_mean), the arrays quantize_maps produced."""
+    (n, c, hw) = symbols_planar.shape
+    cq = torch.empty((n, hw, c), dtype=torch.float32, device=symbols_planar.device) if want_cq else None
+    shifted = torch.empty((n, hw, c), dtype=torch.float32, device=symbols_planar.device) if want_shifted else None
+    _check(_native.hip().eae_hip_dequantize_maps(_p(symbols_planar), _p(bin_widths), _p(map_mean), _p(cq), _p(shifted), n, hw, c, _stream()),
+           'eae_hip_dequantize_maps')
+    return {'cq': cq, 'shifted': shifted}
+
+
 # ---- SVHN float64 path (include/eae_hip.h, "SVHN path") -------------------------------------------------------------
 
 def svhn_dense(x, w, b, leaky_relu):

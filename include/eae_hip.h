@@ -211,6 +211,20 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
                                const uint32_t* bypass_bits, int32_t* status, int32_t* stage, void* workspace,
                                uint64_t workspace_bytes, void* stream);
 
+/* ---- container support (the reference never serialises, compression.cpp:27-64) ------------------
+ * pack_streams: gathers the valid bytes of every map's two streams (layout above) into `payload`: the arithmetic-coded
+ * bytes of map m at offsets[2m], its bypass bytes at offsets[2m+1] (uint64 byte offsets, device memory, chosen by the
+ * caller from the bit counts); unpack_streams is the inverse, into a stream region a decoder can read.
+ * dequantize_maps: the inverse of the symbol conversion of lossless/compression.py:142 followed by the de-centring of
+ * reconstructing_eae_kodak.py:192: symbols_planar [N][128][hw] int16 -> cq_out = bin_widths[c] * symbol (the exact value
+ * tools.py:929 produced) and shifted_out = cq + map_mean[c], both f32 [N][hw][128], each nullable. */
+int eae_hip_coder_pack_streams(uint32_t n_maps, const uint8_t* streams, uint64_t stream_stride_bytes, const uint32_t* bac_bits,
+                               const uint32_t* bypass_bits, const uint64_t* offsets, uint8_t* payload, void* stream);
+int eae_hip_coder_unpack_streams(uint32_t n_maps, const uint8_t* payload, const uint64_t* offsets, const uint32_t* bac_bits,
+                                 const uint32_t* bypass_bits, uint8_t* streams, uint64_t stream_stride_bytes, void* stream);
+int eae_hip_dequantize_maps(const int16_t* symbols_planar, const float* bin_widths, const float* map_mean, float* cq_out,
+                            float* shifted_out, int n, int hw, int c, void* stream);
+
 /* Diagnostic hook (not part of the path): when given a device buffer of grid * waves * 8 uint64, the conv GEMM kernel
  * records s_memtime stamps per wave (start, loop start, loop end, GDN end, end, K-steps, XCC id, HW id). NULL disables. */
 int eae_hip_debug_set_stamp_buffer(uint64_t* device_buffer);

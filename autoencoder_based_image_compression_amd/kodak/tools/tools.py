@@ -56,6 +56,37 @@ def cast_float_to_int16(array_float):
     return bk.to_host(out).reshape(array_float.shape)
 
 
+def compute_bjontegaard(rates_0, psnrs_0, rates_1, psnrs_1):
+    """Bjontegaard's metric: average per cent saving in bitrate of curve 1 over curve 0 (tools.py:157-263). Host float64:
+    cubic fit of log-rate against PSNR for each curve, integrated over the common PSNR range.
+
+    Raises
+    ------
+    ValueError
+        If a rate array is not 1D or a PSNR array does not have the shape of its rate array.
+    AssertionError
+        If a rate or a PSNR is not strictly positive.
+    """
+    curves = ((rates_0, psnrs_0, '0'), (rates_1, psnrs_1, '1'))
+    for (rates, _, tag) in curves:
+        if rates.ndim != 1:
+            raise ValueError('`rates_{}.ndim` is not equal to 1.'.format(tag))
+    for (rates, psnrs, tag) in curves:
+        if psnrs.shape != rates.shape:
+            raise ValueError('`psnrs_{0}.shape` is not equal to `rates_{0}.shape`.'.format(tag))
+    for (name, values) in (('rates_0', rates_0), ('rates_1', rates_1), ('psnrs_0', psnrs_0), ('psnrs_1', psnrs_1)):
+        numpy.testing.assert_array_less(0., values, err_msg='An element of `{}` is not strictly positive.'.format(name))
+    minimum = max(numpy.amin(psnrs_0).item(), numpy.amin(psnrs_1).item())
+    maximum = min(numpy.amax(psnrs_0).item(), numpy.amax(psnrs_1).item())
+
+    def integral_of_log_rate(rates, psnrs):
+        antiderivative = numpy.polyint(numpy.polyfit(psnrs, numpy.log(rates), 3))
+        return numpy.polyval(antiderivative, maximum) - numpy.polyval(antiderivative, minimum)
+
+    difference = integral_of_log_rate(rates_1, psnrs_1) - integral_of_log_rate(rates_0, psnrs_0)
+    return 100.*(numpy.exp(difference/(maximum - minimum)).item() - 1.)
+
+
 def count_nb_deads(array_4d):
     """Number of dead feature maps (sum of absolute values exactly 0) per first-axis component (tools.py:294-320)."""
     if array_4d.ndim != 4:

@@ -248,6 +248,10 @@ def tools_golden(tls, ref_compression, ref_stats, g_coder_dir):
     g.update(stats_y=ys, stats_divergences=divergences, stats_idx=numpy.int64(ref_stats.find_index_map_exception(ys)),
              stats_edges12=edges12, stats_probs12=probs12, stats_edges_half=edges_h, stats_probs_half=probs_h,
              js_p0=p0, js_p1=p1, js_out=numpy.float64(tls.jensen_shannon_divergence(p0, p1)))
+    # compute_bjontegaard (tools.py:157-263) on two rate-distortion curves
+    bd_r0 = numpy.array([0.12, 0.25, 0.48, 0.91, 1.43]); bd_p0 = numpy.array([27.1, 29.8, 32.6, 35.9, 38.2])
+    bd_r1 = numpy.array([0.10, 0.22, 0.41, 0.80, 1.31, 1.9]); bd_p1 = numpy.array([27.4, 30.1, 32.7, 36.0, 38.6, 40.3])
+    g.update(bd_r0=bd_r0, bd_p0=bd_p0, bd_r1=bd_r1, bd_p1=bd_p1, bd_out=numpy.float64(tls.compute_bjontegaard(bd_r0, bd_p0, bd_r1, bd_p1)))
     numpy.savez_compressed(os.path.join(OUT, 'tools_golden.npz'), **g)
     print('tools_golden.npz: rate', g['lat_rate'], 'bits', g['lossless_bits'], 'psnr', g['psnr_known'], 'idx exception', g['stats_idx'])
 

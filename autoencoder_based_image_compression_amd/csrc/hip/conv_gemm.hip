@@ -261,8 +261,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 //     registers into the MFMA in ascending k with no LDS round trip; gamma streams through the same register ring;
 //   * each lane ends up with 4 consecutive channels per register quad -> 16-byte output stores.
 // Same per-element FMA chain (k ascending) as the cooperative kernel and the CPU oracle -> same bits.
-template <int WAVES, int NORM>
+// NT = 32-channel output tiles per wave: 4 (all 128 channels, epilogue fused) or, for layers too small to fill the
+// machine with 32-position x 128-channel waves (conv_3 at Kodak batch sizes: 1152 waves on 1024 SIMDs ran as two rounds),
+// 2 or 1: the channel tiles of one position tile are then spread over 4 / NT blocks of the same XCD, the epilogue is the
+// bias only (NORM must be NONE) and launch() runs the GDN as its own pass over the output. Same per-element FMA chain.
+template <int WAVES, int NORM, int NT = 4>
 __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const ConvGemmParams p) {
+    static_assert(NT == 4 || NORM == EAE_NORM_NONE, "partial channel tiles carry no normalisation");
+    constexpr int PARTS = 4 / NT;
     constexpr int TM = WAVES * 32;
     constexpr int TILE_W = TM / TILE_H;
     constexpr int RING = 8;
@@ -287,8 +293,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
     // Blocks b and b + 8 share an XCD (round-robin over the 8 XCDs): XCD x = b % 8 owns a contiguous range of tiles_x
     // tiles (shared halos stay in its L2) and walks them once per phase, longest phase first. The grid is padded to
     // 8 * tiles_x tiles per phase; the (< 8 per phase) surplus blocks exit at once.
-    const int tiles_x = (int)gridDim.x / (8 * p.n_phases);
-    const int seq = (int)blockIdx.x >> 3;
+    const int tiles_x = (int)gridDim.x / (8 * p.n_phases * PARTS);
+    const int part = ((int)blockIdx.x >> 3) % PARTS;          // which NT channel tiles (neighbouring blocks of one XCD)
+    const int seq = ((int)blockIdx.x >> 3) / PARTS;
     const int ph = seq / tiles_x;
     int b = ((int)blockIdx.x & 7) * tiles_x + seq % tiles_x;
     if (b >= p.n * p.tiles_r * p.tiles_c) return;
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
     // weights / gamma: lane reads 16 bytes at row (k = 2 kk + hi), packed column lj*4
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.w), 0, (int)((size_t)MAX_TAPS * EAE_C * EAE_C * sizeof(float)), 0x00020000);
-    const int w_lane = (hi * EAE_C + lj * 4) * 4;            // byte offset inside a k-pair
+    const int w_lane = (hi * EAE_C + lj * 4 + part * NT) * 4;   // byte offset inside a k-pair (+ this block's channel tiles)
 
     float4 a_reg[4];
 #define EAE_W_PREFETCH_A(step_)                                                                                      \
@@ -344,14 +351,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
 #define EAE_W_SLAB(step_) ((((pd.tap[(step_) % pd.ntaps] >> 16) * EAE_C + ((step_) / pd.ntaps) * KC) * EAE_C) * 4)
 #define EAE_W_LOAD(dst_, rsrc_, slab_, kk_)                                                                          \
     {                                                                                                                \
-        const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, w_lane + (kk_) * 2 * EAE_C * 4, (slab_), 0);   \
-        dst_ = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z),                      \
-                           __uint_as_float(v_.w));                                                                   \
+        if constexpr (NT == 4) {                                                                                     \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, w_lane + (kk_) * 2 * EAE_C * 4, (slab_), 0); \
+            dst_ = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z),                  \
+                               __uint_as_float(v_.w));                                                               \
+        } else if constexpr (NT == 2) {                                                                              \
+            const u32x2 v_ = __builtin_amdgcn_raw_buffer_load_b64(rsrc_, w_lane + (kk_) * 2 * EAE_C * 4, (slab_), 0);  \
+            dst_ = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), 0.f, 0.f);                              \
+        } else {                                                                                                     \
+            const unsigned v_ = __builtin_amdgcn_raw_buffer_load_b32(rsrc_, w_lane + (kk_) * 2 * EAE_C * 4, (slab_), 0); \
+            dst_ = make_float4(__uint_as_float(v_), 0.f, 0.f, 0.f);                                                  \
+        }                                                                                                            \
     }
 
-    f32x16 acc[4];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -382,13 +397,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
         for (int kk = 0; kk < KC / 2; ++kk) {
             const float4 wq = ring[kk % RING];
             acc[0] = mfma32(wq.x, av[kk], acc[0]);      // A = W^T[co = 32 t + lj][k], B = X^T[k][pos = lj]
-            acc[1] = mfma32(wq.y, av[kk], acc[1]);
-            acc[2] = mfma32(wq.z, av[kk], acc[2]);
-            acc[3] = mfma32(wq.w, av[kk], acc[3]);
+            if constexpr (NT >= 2) acc[1] = mfma32(wq.y, av[kk], acc[1]);
+            if constexpr (NT == 4) {
+                acc[2] = mfma32(wq.z, av[kk], acc[2]);
+                acc[3] = mfma32(wq.w, av[kk], acc[3]);
+            }
             // refill this ring slot with the k-pair RING ahead in the K stream (next step's slab once kk + RING >= 16)
             if (kk + RING < KC / 2) { EAE_W_LOAD(ring[kk % RING], w_rsrc, slab_cur, kk + RING) }
             else { EAE_W_LOAD(ring[kk % RING], w_rsrc, slab_nxt, kk + RING - KC / 2) }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -402,7 +419,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
     const bool valid = pr < p.hp && pc < p.wp;
     float* o = p.out + (size_t)img * p.hout * p.wout * EAE_C +
                ((size_t)(pr * p.out_stride + pd.out_a) * p.wout + (pc * p.out_stride + pd.out_b)) * EAE_C;
-    wave_epilogue<NORM>(acc, vec_lds, p.bias != nullptr, p.gamma, o, valid, lane);
+    if constexpr (NT == 4) {
+        wave_epilogue<NORM>(acc, vec_lds, p.bias != nullptr, p.gamma, o, valid, lane);
+    } else if (valid) {
+        // channel of (tile t, group g, q) = 32 t + 8 g + 4 hi + q (common.h wave_epilogue); bias only
+        float* oo = o + 4 * hi + 32 * NT * part;
+        const float* bias_lds = vec_lds + 4 * hi + 32 * NT * part;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = p.bias ? *reinterpret_cast<const float4*>(bias_lds + 32 * t + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 y = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+                if (p.bias) y = make_float4(y.x + bv.x, y.y + bv.y, y.z + bv.z, y.w + bv.w);
+                *reinterpret_cast<float4*>(oo + 32 * t + 8 * g) = y;
+            }
+    }
     if (p.stamps) t_gdn_end = __builtin_amdgcn_s_memtime();
     if (p.stamps && lane == 0) {
         unsigned long long* st = p.stamps + ((size_t)blockIdx.x * WAVES + wave) * 8;
@@ -443,7 +475,22 @@ int launch(ConvGemmParams& p, hipStream_t stream) {
     p.tiles_r = (p.hp + TILE_H - 1) / TILE_H;
     p.tiles_c = (p.wp + tile_w - 1) / tile_w;
     const int tiles = p.n * p.tiles_r * p.tiles_c;
-    const int grid = ((tiles + 7) / 8) * 8 * p.n_phases;     // padded: see the block decode in the kernel
+    int grid = ((tiles + 7) / 8) * 8 * p.n_phases;           // padded: see the block decode in the kernel
+    // A layer with fewer waves than ~2 per SIMD runs in coarse rounds (conv_3 at Kodak batch 24: 1152 waves on 1024 SIMDs
+    // = two rounds, 48 % MFMA utilisation). Spread the output channels of each position tile over 2 (or 4) blocks and run
+    // the normalisation as its own small pass over the output (gdn_kernel, in place: same arithmetic, same bits).
+    int nt = 4;
+    if (waves == 1 && (long)tiles * p.n_phases < 2048) nt = 2;
+    if (const char* force = std::getenv("EAE_HIP_FORCE_NT")) nt = std::atoi(force) == 1 ? 1 : (std::atoi(force) == 2 ? 2 : 4);
+    if (nt != 4 && waves == 1) {
+        grid *= 4 / nt;
+        if (nt == 2) hipLaunchKernelGGL((conv_gemm_wave_kernel<1, EAE_NORM_NONE, 2>), dim3(grid), dim3(64), 0, stream, p);
+        else hipLaunchKernelGGL((conv_gemm_wave_kernel<1, EAE_NORM_NONE, 1>), dim3(grid), dim3(64), 0, stream, p);
+        EAE_HIP_CHECK_LAUNCH();
+        if (p.norm != EAE_NORM_NONE)
+            return eae_hip_gdn(p.out, p.gamma, p.beta, p.norm == EAE_NORM_IGDN ? 1 : 0, p.out, (int64_t)p.n * p.hout * p.wout, stream);
+        return EAE_HIP_OK;
+    }
 #define EAE_LAUNCH_WAVE(W_, N_) hipLaunchKernelGGL((conv_gemm_wave_kernel<W_, N_>), dim3(grid), dim3(W_ * 64), 0, stream, p)
 #define EAE_LAUNCH_NORM(W_)                                                   \
     if (p.norm == EAE_NORM_GDN) EAE_LAUNCH_WAVE(W_, EAE_NORM_GDN);            \

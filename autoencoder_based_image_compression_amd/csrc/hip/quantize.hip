@@ -130,10 +130,11 @@ __global__ __launch_bounds__(256) void map_sums_kernel(const float* __restrict__
 // One block per map. LDS histogram when the bins fit, global atomics otherwise (caller zeroed hist/overflow).
 constexpr int LDS_BINS = 8192;
 __global__ __launch_bounds__(256) void hist_kernel(const int16_t* __restrict__ symbols, unsigned int* __restrict__ hist,
-                                                   int radius, unsigned int* __restrict__ overflow, int map_size) {
+                                                   int radius, unsigned int* __restrict__ overflow, int map_size,
+                                                   long first_map, long map_step) {
     __shared__ unsigned int bins[LDS_BINS];
     const int nb = 2 * radius + 1;
-    const int16_t* s = symbols + (size_t)blockIdx.x * map_size;
+    const int16_t* s = symbols + (size_t)(first_map + (long)blockIdx.x * map_step) * map_size;
     unsigned int* h = hist + (size_t)blockIdx.x * nb;
     unsigned int over = 0;
     if (nb <= LDS_BINS) {
@@ -283,7 +284,18 @@ extern "C" int eae_hip_symbol_histograms(const int16_t* symbols_planar, uint32_t
     if (!symbols_planar || !hist || !overflow || n_maps <= 0 || map_size <= 0) return EAE_HIP_BAD_ARGUMENT;
     if (hist_radius < 0 || hist_radius > 32768) return EAE_HIP_BAD_ARGUMENT;
     hipLaunchKernelGGL(hist_kernel, dim3(n_maps), dim3(256), 0, (hipStream_t)stream, symbols_planar, hist, hist_radius,
-                       overflow, map_size);
+                       overflow, map_size, 0L, 1L);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}
+
+extern "C" int eae_hip_symbol_histograms_strided(const int16_t* symbols_planar, uint32_t* hist, int hist_radius,
+                                                 uint32_t* overflow, int n_maps, int map_size, int64_t first_map,
+                                                 int64_t map_step, void* stream) {
+    if (!symbols_planar || !hist || !overflow || n_maps <= 0 || map_size <= 0 || first_map < 0 || map_step <= 0) return EAE_HIP_BAD_ARGUMENT;
+    if (hist_radius < 0 || hist_radius > 32768) return EAE_HIP_BAD_ARGUMENT;
+    hipLaunchKernelGGL(hist_kernel, dim3(n_maps), dim3(256), 0, (hipStream_t)stream, symbols_planar, hist, hist_radius,
+                       overflow, map_size, (long)first_map, (long)map_step);
     EAE_HIP_CHECK_LAUNCH();
     return EAE_HIP_OK;
 }

@@ -140,7 +140,7 @@ def pack_tconv9x9s4_weights(w_tf):
 
 
 def quantize_maps(y, bin_widths, map_mean=None, want_cq=False, want_shifted=False, want_symbols=False, want_flags=False,
-                  out_symbols=None):
+                  out_symbols=None, out_flags=None, out_checks=None):
     """One pass over y [N,h,w,C] (or [N,hw,C]); see include/eae_hip.h. Returns a dict of the requested device tensors.
 
     `checks` (int32 [3]) always comes back: [0] int16 range violations, [1] "quantization was omitted" count,
@@ -156,8 +156,9 @@ def quantize_maps(y, bin_widths, map_mean=None, want_cq=False, want_shifted=Fals
     symbols = (out_symbols if out_symbols is not None else torch.empty((n, c, hw), dtype=torch.int16, device=d)) if want_symbols else None
     if symbols is not None and (symbols.dtype != torch.int16 or symbols.numel() != n*c*hw):
         raise TypeError('`out_symbols` must be an int16 tensor of N x C x hw elements.')
-    flags = torch.zeros((n, c), dtype=torch.int32, device=d) if want_flags else None
-    checks = torch.zeros(3, dtype=torch.int32, device=d)
+    # out_flags / out_checks: preallocated int32 buffers ALREADY ZEROED by the caller (the kernel only sets / adds)
+    flags = (out_flags if out_flags is not None else torch.zeros((n, c), dtype=torch.int32, device=d)) if want_flags else None
+    checks = out_checks if out_checks is not None else torch.zeros(3, dtype=torch.int32, device=d)
     _check(_native.hip().eae_hip_quantize_maps(_p(y), _p(map_mean), _p(bin_widths), _p(cq), _p(shifted), _p(symbols), _p(flags),
                                                _p(checks), n, hw, c, _stream()), 'eae_hip_quantize_maps')
     return {'cq': cq, 'shifted': shifted, 'symbols': symbols, 'nonzero_flags': flags, 'checks': checks}
@@ -208,20 +209,22 @@ def cast_int16(x):
     return out, range_error
 
 
-def symbol_histograms(symbols_planar, radius, out=None):
+def symbol_histograms(symbols_planar, radius, out=None, first_map=0, map_step=1, zero=True):
     """symbols [..., map_size] int16 -> (hist int32 [n_maps, 2*radius+1], overflow int32 [n_maps]); `out` = that pair,
-    preallocated (it is zeroed here)."""
+    preallocated (zeroed here unless zero=False: the kernel accumulates). first_map / map_step: only every map_step-th
+    map starting at first_map (e.g. the exception map of every image of a batch)."""
     map_size = symbols_planar.shape[-1]
-    n_maps = symbols_planar.numel()//map_size
+    n_maps = (symbols_planar.numel()//map_size - first_map + map_step - 1)//map_step
     if out is None:
         hist = torch.zeros((n_maps, 2*radius + 1), dtype=torch.int32, device=symbols_planar.device)
         overflow = torch.zeros(n_maps, dtype=torch.int32, device=symbols_planar.device)
     else:
         (hist, overflow) = out
-        hist.zero_()
-        overflow.zero_()
-    _check(_native.hip().eae_hip_symbol_histograms(_p(symbols_planar), _p(hist), radius, _p(overflow), n_maps, map_size, _stream()),
-           'eae_hip_symbol_histograms')
+        if zero:
+            hist.zero_()
+            overflow.zero_()
+    _check(_native.hip().eae_hip_symbol_histograms_strided(_p(symbols_planar), _p(hist), radius, _p(overflow), n_maps, map_size,
+                                                           first_map, map_step, _stream()), 'eae_hip_symbol_histograms_strided')
     return hist, overflow
 
 

@@ -81,6 +81,7 @@ class RateWorker(threading.Thread):
         self.jobs = queue.Queue()
         self.coder_bits = 0
         self.exception_bits = 0
+        self.dead_maps = 0
         self.error = None
         self.busy_s = 0.
 
@@ -89,7 +90,7 @@ class RateWorker(threading.Thread):
             job = self.jobs.get()
             if job is None:
                 return
-            (event, results_host, hist_host, overflow_host, slot_free) = job
+            (event, results_host, hist_host, overflow_host, flags_host, checks_host, slot_free) = job
             try:
                 event.synchronize()
                 t0 = time.perf_counter()
@@ -104,6 +105,9 @@ class RateWorker(threading.Thread):
                     sys.stderr.write('CLOCKS shader-cycles mean {:.0f} max {} refclk-ticks mean {:.0f} -> MHz {:.0f}\n'.format(
                         results[3][keep].mean(), results[3][keep].max(), results[1][keep].mean(),
                         100.*results[3][keep].mean()/results[1][keep].mean()))
+                if int(checks_host[0]) != 0:
+                    raise AssertionError('The rounded array elements cannot be represented as 16-bit signed integers.')
+                self.dead_maps += int((flags_host.numpy() == 0).sum())        # tls.count_nb_deads (tools.py:294-320)
                 self.coder_bits += int(results[0].astype(numpy.int64).sum()) + int(results[1].astype(numpy.int64).sum())
                 self.exception_bits += sum(int(lossless_compression.exception_map_nb_bits(row, self.map_size))
                                            for row in hist_host.numpy().astype(numpy.int64))
@@ -117,8 +121,8 @@ class RateWorker(threading.Thread):
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
-    parser.add_argument('--steps', type=int, default=30)
-    parser.add_argument('--warmup', type=int, default=5)
+    parser.add_argument('--steps', type=int, default=100)
+    parser.add_argument('--warmup', type=int, default=10)
     parser.add_argument('--batch', type=int, default=24, help='Kodak-sized images per GPU per step')
     parser.add_argument('--no-cpu-baseline', action='store_true')
     parser.add_argument('--coder-streams', type=int, default=int(os.environ.get('EAE_CODER_STREAMS', '2')),
@@ -166,16 +170,20 @@ def main():
     prob_row = prob_row.to(device)
     n_maps = args.batch*128
     nb_slots = args.coder_streams + 2
-    # everything the host needs from one batch, contiguous on the device: [coder results 4 x n_maps | histograms | overflow]
-    nb_host_words = 4*n_maps + args.batch*511 + args.batch
+    # everything the host needs from one batch, contiguous on the device:
+    # [coder results 4 x n_maps | exception-map histograms | their overflow counts | non-zero flags of every map | 3 checks]
+    nb_host_words = 4*n_maps + args.batch*511 + args.batch + n_maps + 3
     slot_out = [torch.zeros(nb_host_words, dtype=torch.int32, device=device) for _ in range(nb_slots)]
     pinned_out = [torch.zeros(nb_host_words, dtype=torch.int32).pin_memory() for _ in range(nb_slots)]
 
     def views(t):
-        return (t[:4*n_maps].view(4, n_maps), t[4*n_maps:4*n_maps + args.batch*511].view(args.batch, 511), t[4*n_maps + args.batch*511:])
+        (a, b) = (4*n_maps, 4*n_maps + args.batch*511)
+        return (t[:a].view(4, n_maps), t[a:b].view(args.batch, 511), t[b:b + args.batch],
+                t[b + args.batch:b + args.batch + n_maps].view(args.batch, 128), t[b + args.batch + n_maps:])
 
     streams = [dev.CoderStreams(n_maps, map_size, TRUNCATED_UNARY_LENGTH, device, results=views(slot_out[i])[0]) for i in range(nb_slots)]
-    slot_hist = [views(slot_out[i])[1:] for i in range(nb_slots)]
+    slot_hist = [views(slot_out[i])[1:3] for i in range(nb_slots)]
+    slot_flags = [views(slot_out[i])[3:] for i in range(nb_slots)]
     pinned_views = [views(pinned_out[i]) for i in range(nb_slots)]
     slot_symbols = [torch.empty((args.batch, 128, map_size), dtype=torch.int16, device=device) for _ in range(nb_slots)]
     workspaces = [dev.coder_workspace(n_maps, map_size, TRUNCATED_UNARY_LENGTH, device) for _ in range(nb_slots)]
@@ -186,7 +194,6 @@ def main():
     worker.start()
     coder_streams = [torch.cuda.Stream() for _ in range(args.coder_streams)]
     sse_total = torch.zeros(args.batch, dtype=torch.int64, device=device)
-    dead_total = torch.zeros(1, dtype=torch.int64, device=device)
     gemm_events = []            # (start, stop, launch name) around every conv_gemm launch of the timed region
 
     def timed_launch(name, fn, record):
@@ -219,11 +226,12 @@ def main():
         slot_free[slot].clear()
         mark('slot')
         # buffers that cross to the coder streams are per-slot and preallocated (no caching-allocator traffic across streams)
+        slot_out[slot][4*n_maps:].zero_()            # histograms, overflow, flags, checks: the kernels below accumulate into them
         q = dev.quantize_maps(y, bin_widths, map_mean, want_shifted=True, want_symbols=True, want_flags=True,
-                              out_symbols=slot_symbols[slot])
-        # exception map: exact histogram on the device; its entropy is formed on the host by the rate worker
-        (hist, overflow) = dev.symbol_histograms(q['symbols'][:, IDX_MAP_EXCEPTION:IDX_MAP_EXCEPTION + 1].contiguous(), 255,
-                                                 out=slot_hist[slot])
+                              out_symbols=slot_symbols[slot], out_flags=slot_flags[slot][0], out_checks=slot_flags[slot][1])
+        # exception map of every image: exact histogram on the device; its entropy is formed on the host by the rate worker
+        dev.symbol_histograms(q['symbols'].view(n_maps, map_size), 255, out=slot_hist[slot], first_map=IDX_MAP_EXCEPTION,
+                              map_step=128, zero=False)
         quantized = torch.cuda.Event()
         quantized.record()
         # entropy coding off the transform stream, concurrent with the transforms of this and the next batches: every map
@@ -252,7 +260,6 @@ def main():
             copied.record()
         mark('coder')
         worker.jobs.put((copied,) + pinned_views[slot] + (slot_free[slot],))
-        dead_total.add_((q['nonzero_flags'] == 0).sum())
         d = decoder.v
         t = dev.gdn(q['shifted'], decoder.g[4], d['decoder/beta_4'], inverse=True)
         t = timed_launch('tconv1_igdn5', lambda: dev.tconv5x5s2(t, decoder.w4, d['decoder/biases_4'], dev.NORM_IGDN,
@@ -279,8 +286,8 @@ def main():
     drain()
     worker.coder_bits = 0
     worker.exception_bits = 0
+    worker.dead_maps = 0
     sse_total.zero_()
-    dead_total.zero_()
     worker.busy_s = 0.
 
     # the launch thread allocates only short-lived wrappers: keep the cyclic collector (a 30 ms pause every ~75 steps) out of it
@@ -298,7 +305,7 @@ def main():
     drain()
     # the path's only exchange step: sum the rate / PSNR accumulators over ranks
     coder_bits = float(worker.coder_bits) + float(worker.exception_bits)
-    stats = torch.tensor([coder_bits, float(sse_total.sum().item()), float(dead_total.item()), float(args.steps*args.batch)],
+    stats = torch.tensor([coder_bits, float(sse_total.sum().item()), float(worker.dead_maps), float(args.steps*args.batch)],
                          dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)

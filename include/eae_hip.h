@@ -153,6 +153,10 @@ int eae_hip_cast_int16(const float* x, int16_t* out, int64_t count, uint32_t* ra
  * int16). hist and overflow are ACCUMULATED into: the caller zeroes them. */
 int eae_hip_symbol_histograms(const int16_t* symbols_planar, uint32_t* hist, int hist_radius, uint32_t* overflow,
                               int n_maps, int map_size, void* stream);
+/* Same over every map_step-th map starting at first_map (row i of hist = map first_map + i * map_step): the exception
+ * map of every image of a batch (first_map = idx_map_exception, map_step = 128) without gathering it first. */
+int eae_hip_symbol_histograms_strided(const int16_t* symbols_planar, uint32_t* hist, int hist_radius, uint32_t* overflow,
+                                      int n_maps, int map_size, int64_t first_map, int64_t map_step, void* stream);
 
 /* ---- lossless coder on the device: one feature map per lane --------------------------------------------------------
  * Replaces the per-map compress_lossless loop of lossless/compression.py:76-81 (and, underneath it,

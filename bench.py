@@ -75,9 +75,11 @@ class RateWorker(threading.Thread):
     coder's per-map results and of the exception-map histograms, checks every status, sums the bit counts and forms the
     exception map's ceil(h*w*entropy) (compression.py:68-75) in numpy float64 like the reference."""
 
-    def __init__(self, map_size):
+    def __init__(self, map_size, host_probabilities=None, host_threads=0):
         super(RateWorker, self).__init__(daemon=True)
         self.map_size = map_size
+        self.host_probabilities = host_probabilities      # --coder host: the C-ABI host coder runs here
+        self.host_threads = host_threads
         self.jobs = queue.Queue()
         self.coder_bits = 0
         self.exception_bits = 0
@@ -90,11 +92,19 @@ class RateWorker(threading.Thread):
             job = self.jobs.get()
             if job is None:
                 return
-            (event, results_host, hist_host, overflow_host, flags_host, checks_host, slot_free) = job
+            (event, results_host, hist_host, overflow_host, flags_host, checks_host, symbols_host, slot_free) = job
             try:
                 event.synchronize()
                 t0 = time.perf_counter()
                 results = results_host.numpy()
+                if symbols_host is not None:
+                    # the north star's shape: ONE device -> host copy of the symbols, then the host C-ABI coder (encode +
+                    # decode + compare per map like compress_lossless), threaded over maps
+                    (_, nb_bits) = lossless_compression.code_planar_symbols(symbols_host.numpy(), self.host_probabilities,
+                                                                           IDX_MAP_EXCEPTION, nb_threads=self.host_threads,
+                                                                           roundtrip=True, verify_only=True)
+                    results = numpy.zeros_like(results)
+                    results[0] = nb_bits.reshape(-1)
                 if results[2].any():
                     bad = int(numpy.flatnonzero(results[2])[0])
                     raise RuntimeError('device coder: map {0} failed with status {1} at stage {2}'.format(bad, results[2, bad], results[3, bad]))
@@ -125,6 +135,10 @@ def main():
     parser.add_argument('--warmup', type=int, default=10)
     parser.add_argument('--batch', type=int, default=24, help='Kodak-sized images per GPU per step')
     parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--coder', choices=('device', 'host'), default='device',
+                        help='device: the coder kernels on side streams (default). host: one device -> host copy of the symbols '
+                             'per batch and the host C-ABI coder on a thread pool (the shape BASELINE.json sketches)')
+    parser.add_argument('--coder-threads', type=int, default=0, help='host coder threads (0 = usable CPUs - 2)')
     parser.add_argument('--coder-streams', type=int, default=int(os.environ.get('EAE_CODER_STREAMS', '2')),
                         help='batches whose entropy coding may be in flight at once (each on its own HIP stream)')
     parser.add_argument('--coder-lanes', type=int, default=int(os.environ.get('EAE_CODER_LANES', '-1')),
@@ -190,7 +204,10 @@ def main():
     slot_free = [threading.Event() for _ in range(nb_slots)]
     for e in slot_free:
         e.set()
-    worker = RateWorker(map_size)
+    host_coder = args.coder == 'host'
+    coder_threads = args.coder_threads if args.coder_threads > 0 else max(1, cores//max(world, 1) - 2)
+    worker = RateWorker(map_size, probabilities if host_coder else None, coder_threads)
+    pinned_symbols = [torch.empty((args.batch, 128, map_size), dtype=torch.int16).pin_memory() if host_coder else None for _ in range(nb_slots)]
     worker.start()
     coder_streams = [torch.cuda.Stream() for _ in range(args.coder_streams)]
     sse_total = torch.zeros(args.batch, dtype=torch.int64, device=device)
@@ -243,7 +260,9 @@ def main():
         coder_stream = coder_streams[index % len(coder_streams)]
         with torch.cuda.stream(coder_stream):
             coder_stream.wait_event(quantized)
-            if not os.environ.get('EAE_BENCH_NO_CODER'):      # diagnostic only: transforms without the coder
+            if host_coder:
+                pinned_symbols[slot].copy_(q['symbols'], non_blocking=True)
+            elif not os.environ.get('EAE_BENCH_NO_CODER'):    # diagnostic only: transforms without the coder
                 if args.coder_lanes >= 0:                     # per-lane kernels (coder_device.hip), for comparison
                     dev.coder_compress_maps(symbols, probabilities_dev, prob_row, TRUNCATED_UNARY_LENGTH,
                                             mode=dev.CODER_ENCODE_ONLY, out=streams[slot], lanes_per_wave=args.coder_lanes)
@@ -259,7 +278,7 @@ def main():
             copied = torch.cuda.Event()
             copied.record()
         mark('coder')
-        worker.jobs.put((copied,) + pinned_views[slot] + (slot_free[slot],))
+        worker.jobs.put((copied,) + pinned_views[slot] + (pinned_symbols[slot], slot_free[slot]))
         d = decoder.v
         t = dev.gdn(q['shifted'], decoder.g[4], d['decoder/beta_4'], inverse=True)
         t = timed_launch('tconv1_igdn5', lambda: dev.tconv5x5s2(t, decoder.w4, d['decoder/biases_4'], dev.NORM_IGDN,
@@ -348,7 +367,8 @@ def main():
                    'truncated_unary_length': TRUNCATED_UNARY_LENGTH, 'idx_map_exception': IDX_MAP_EXCEPTION,
                    'weights': 'random-init fixed-bin-width architecture (trained checkpoints absent from the reference)',
                    'parallelism': 'image shards, one process per GPU' if world > 1 else 'single GPU',
-                   'coder': 'device, 64 maps per wavefront, encode + decode + compare'},
+                   'coder': 'device, 64 maps per wavefront, encode + decode + compare' if not host_coder else
+                            'host C-ABI coder, {} threads, after one device -> host copy of the symbols'.format(coder_threads)},
         'images_per_s': round(nb_images_total/elapsed, 2),
         'rate_bpp': round(bpp, 5), 'psnr_db_pooled': round(mean_psnr, 4), 'dead_maps_per_image': round(stats[2].item()/nb_images_total, 3),
         'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_wave_kernel (conv2+GDN2, conv3+GDN3, tconv1+IGDN5, tconv2+IGDN6)',

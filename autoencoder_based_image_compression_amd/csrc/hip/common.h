@@ -70,9 +70,11 @@ __device__ __forceinline__ void gdn_denominator(const float* Xs, int wm, int lan
         if constexpr (NT == 4) {
             const float4 gv = *reinterpret_cast<const float4*>(g_rd + (size_t)2 * kk * EAE_C);
             g[0] = gv.x; g[1] = gv.y; g[2] = gv.z; g[3] = gv.w;
-        } else {
+        } else if constexpr (NT == 2) {
             const float2 gv = *reinterpret_cast<const float2*>(g_rd + (size_t)2 * kk * EAE_C);
             g[0] = gv.x; g[1] = gv.y;
+        } else {
+            g[0] = g_rd[(size_t)2 * kk * EAE_C];
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) d[t] = mfma32(x2, g[t], d[t]);

@@ -1,0 +1,128 @@
+// latent.hip -- everything between the last analysis convolution and the first synthesis convolution in ONE pass over the
+// latent variables (fixed-bin-width model; the learned-bin-width model has neither normalisation):
+//   gdn_3                                           eae/graph/components.py:139-142, tfutils.py:393-397
+//   y - map_mean, quantize_per_map, int16 symbols   reconstructing_eae_kodak.py:170-178, tools.py:883-929, compression.py:142
+//   count_nb_deads flags, the three data checks     tools.py:294-320, 130-132, 372-375, compression.py:149-153
+//   + map_mean, inverse_gdn_4                       reconstructing_eae_kodak.py:192, components.py:53-58, tfutils.py:505-509
+// The separate kernels (conv epilogue / gdn_kernel, quantize_kernel, gdn_kernel) each stream the 128-channel latents
+// through HBM; here a block keeps 128 positions x 128 channels in LDS and runs both 128 x 128 contractions on the MFMA.
+// Arithmetic, operation by operation, is that of gdn.hip and quantize.hip (same helpers), so the results are the same bits.
+#include "common.h"
+
+namespace {
+// 64 positions per block (2 waves x 32 positions x 128 channels): 50 KB of LDS, three blocks per CU. Measured at Kodak batch
+// 24 (36,864 positions): 131 us, against 188 us for 128-position blocks and 162 us for 32 positions with one channel tile
+// per wave; the three separate kernels take 25 + 75 + 45 us plus two launch gaps.
+constexpr int WAVES = 2;
+constexpr int TM = WAVES * 32;
+constexpr int SYM_STRIDE = TM + 2;
+
+template <bool GDN_IN, bool IGDN_OUT>
+__global__ __launch_bounds__(WAVES * 64) void latent_kernel(const float* __restrict__ x, const float* __restrict__ gamma_in,
+                                                     const float* __restrict__ beta_in, const float* __restrict__ map_mean,
+                                                     const float* __restrict__ bin_widths, const float* __restrict__ gamma_out,
+                                                     const float* __restrict__ beta_out, float* __restrict__ y_out,
+                                                     float* __restrict__ shifted_out, float* __restrict__ t_out,
+                                                     int16_t* __restrict__ symbols, unsigned int* __restrict__ nonzero,
+                                                     unsigned int* __restrict__ checks, long rows, int hw) {
+    __shared__ __attribute__((aligned(16))) float Xs[TM * EAE_XS_STRIDE];   // [TM][129]: x, then y / shifted in place
+    __shared__ int16_t Sy[EAE_C * SYM_STRIDE];                              // [128 maps][TM + 2]: symbols, for the planar write
+    const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+    const long row0 = (long)blockIdx.x * TM;
+    for (int i = tid; i < TM * (EAE_C / 4); i += WAVES * 64) {
+        const int r = i >> 5, q = i & 31;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < rows) v = *reinterpret_cast<const float4*>(x + (size_t)(row0 + r) * EAE_C + 4 * q);
+        float* dst = Xs + r * EAE_XS_STRIDE + 4 * q;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    __syncthreads();
+    const int col0 = lane & 31;
+    f32x16 d[4];
+    if (GDN_IN) {
+        gdn_denominator<4>(Xs, wm, lane, gamma_in, 0, d);
+        __syncthreads();                    // every wave is done reading x of every row before y overwrites it
+    }
+    unsigned int bad = 0, not_quantized = 0, altered = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int c = col0 + 32 * t;
+        const float m = map_mean ? map_mean[c] : 0.f;
+        const float bw = bin_widths[c];
+        const float bt = GDN_IN ? beta_in[c] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mrow = wm * 32 + acc_row32(r, lane);
+            const long row = row0 + mrow;
+            float yv = Xs[mrow * EAE_XS_STRIDE + c];
+            if (GDN_IN) yv = gdn_apply(yv, d[t][r], bt, false);
+            // quantize.hip, statement for statement
+            const float centered = yv - m;
+            const float rr = round_half_even(centered / bw);
+            const float cq = bw * rr;
+            const float rs = round_half_even(cq / bw);
+            const float shifted = cq + m;
+            if (row < rows) {
+                if (!(fabsf(rs) < 32768.f)) bad++;
+                if (!(fabs((double)cq - (double)centered) < 1.5e-10)) not_quantized++;
+                if (!((float)(int16_t)(int)rs * bw == centered)) altered++;
+                if (y_out) y_out[(size_t)row * EAE_C + c] = yv;
+                if (shifted_out) shifted_out[(size_t)row * EAE_C + c] = shifted;
+                if (cq != 0.f && nonzero) nonzero[(row / hw) * EAE_C + c] = 1u;     // benign race: every writer stores 1
+            }
+            Xs[mrow * EAE_XS_STRIDE + c] = shifted;
+            Sy[c * SYM_STRIDE + mrow] = (int16_t)(int)rs;
+        }
+    }
+    if (checks) {
+        if (bad) atomicAdd(&checks[0], bad);
+        if (not_quantized) atomicAdd(&checks[1], not_quantized);
+        if (altered) atomicAdd(&checks[2], altered);
+    }
+    __syncthreads();
+    if (symbols) {
+        // planar write: consecutive threads cover consecutive positions of one map
+        for (int i = tid; i < EAE_C * TM; i += WAVES * 64) {
+            const int ch = i / TM, px = i % TM;
+            const long row = row0 + px;
+            if (row < rows) symbols[((size_t)(row / hw) * EAE_C + ch) * hw + (row % hw)] = Sy[ch * SYM_STRIDE + px];
+        }
+    }
+    if (IGDN_OUT) {
+        gdn_denominator<4>(Xs, wm, lane, gamma_out, 0, d);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = col0 + 32 * t;
+            const float bt = beta_out[c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mrow = wm * 32 + acc_row32(r, lane);
+                if (row0 + mrow < rows)
+                    t_out[(size_t)(row0 + mrow) * EAE_C + c] = gdn_apply(Xs[mrow * EAE_XS_STRIDE + c], d[t][r], bt, true);
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int eae_hip_latent_stage(const float* x, const float* gamma_in_packed, const float* beta_in, const float* map_mean,
+                                    const float* bin_widths, const float* gamma_out_packed, const float* beta_out, float* y_out,
+                                    float* shifted_out, float* t_out, int16_t* symbols_planar, uint32_t* nonzero_flags,
+                                    uint32_t* checks, int n, int hw, void* stream) {
+    if (!x || !bin_widths || n <= 0 || hw <= 0) return EAE_HIP_BAD_ARGUMENT;
+    if ((gamma_in_packed == nullptr) != (beta_in == nullptr)) return EAE_HIP_BAD_ARGUMENT;
+    if ((gamma_out_packed == nullptr) != (beta_out == nullptr) || (gamma_out_packed && !t_out)) return EAE_HIP_BAD_ARGUMENT;
+    const long rows = (long)n * hw;
+    const unsigned grid = (unsigned)((rows + TM - 1) / TM);
+    hipStream_t s = (hipStream_t)stream;
+#define EAE_LATENT(A_, B_)                                                                                               \
+    hipLaunchKernelGGL((latent_kernel<A_, B_>), dim3(grid), dim3(WAVES * 64), 0, s, x, gamma_in_packed, beta_in, map_mean, bin_widths, \
+                       gamma_out_packed, beta_out, y_out, shifted_out, t_out, symbols_planar, nonzero_flags, checks, rows, hw)
+    if (gamma_in_packed && gamma_out_packed) EAE_LATENT(true, true);
+    else if (gamma_in_packed) EAE_LATENT(true, false);
+    else if (gamma_out_packed) EAE_LATENT(false, true);
+    else EAE_LATENT(false, false);
+#undef EAE_LATENT
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}

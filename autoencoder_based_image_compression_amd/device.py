@@ -164,6 +164,29 @@ def quantize_maps(y, bin_widths, map_mean=None, want_cq=False, want_shifted=Fals
     return {'cq': cq, 'shifted': shifted, 'symbols': symbols, 'nonzero_flags': flags, 'checks': checks}
 
 
+def latent_stage(x, bin_widths, map_mean=None, gdn_in=None, igdn_out=None, want_y=False, want_shifted=False, want_symbols=True,
+                 want_flags=False, out_symbols=None, out_flags=None, out_checks=None):
+    """conv_3 output x [N,h,w,128] (bias added, not normalised) -> gdn_3 -> quantiser -> (+mean) inverse_gdn_4, one kernel.
+    gdn_in / igdn_out: (gamma_packed, beta) pairs or None. Returns a dict like quantize_maps plus 'y' and 't' (the input of
+    transpose_conv_1). out_* buffers: preallocated, flags / checks already zeroed (see quantize_maps)."""
+    n = x.shape[0]
+    c = x.shape[-1]
+    hw = x.numel()//(n*c)
+    d = x.device
+    y = torch.empty_like(x) if want_y else None
+    shifted = torch.empty_like(x) if want_shifted else None
+    t = torch.empty_like(x) if igdn_out is not None else None
+    symbols = (out_symbols if out_symbols is not None else torch.empty((n, c, hw), dtype=torch.int16, device=d)) if want_symbols else None
+    flags = (out_flags if out_flags is not None else torch.zeros((n, c), dtype=torch.int32, device=d)) if want_flags else None
+    checks = out_checks if out_checks is not None else torch.zeros(3, dtype=torch.int32, device=d)
+    (g_in, b_in) = gdn_in if gdn_in is not None else (None, None)
+    (g_out, b_out) = igdn_out if igdn_out is not None else (None, None)
+    _check(_native.hip().eae_hip_latent_stage(_p(x), _p(g_in), _p(b_in), _p(map_mean), _p(bin_widths), _p(g_out), _p(b_out), _p(y),
+                                              _p(shifted), _p(t), _p(symbols), _p(flags), _p(checks), n, hw, _stream()),
+           'eae_hip_latent_stage')
+    return {'y': y, 'shifted': shifted, 't': t, 'symbols': symbols, 'nonzero_flags': flags, 'checks': checks}
+
+
 def map_means(y):
     """float32 per-map means over every other axis of y [..., C] (lossless/stats.py:306), float64 accumulation."""
     c = y.shape[-1]

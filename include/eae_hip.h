@@ -122,6 +122,18 @@ int eae_hip_quantize_maps(const float* y, const float* map_mean, const float* bi
                           float* cq_out, float* shifted_out, int16_t* symbols_planar,
                           uint32_t* nonzero_flags, uint32_t* checks, int n, int hw, int c, void* stream);
 
+/* The whole latent stage of the fixed-bin-width model in one pass (csrc/hip/latent.hip): x = conv_3 + bias (NORM_NONE)
+ *   -> gdn_3 (gamma_in_packed/beta_in; both NULL = no normalisation, the learned-bin-width model, components.py:137-138)
+ *   -> the quantiser exactly as eae_hip_quantize_maps (symbols_planar, nonzero_flags, checks: same meaning, caller zeroes
+ *      flags and checks; map_mean nullable)
+ *   -> + map_mean -> inverse_gdn_4 (gamma_out_packed/beta_out; both NULL = none) into t_out, the input of transpose_conv_1.
+ * y_out (the latents after gdn_3), shifted_out (quantised + mean) are optional f32 [N][hw][128] outputs.
+ * Same arithmetic as eae_hip_gdn + eae_hip_quantize_maps + eae_hip_gdn: identical bits (tests/test_gpu_latent.py). */
+int eae_hip_latent_stage(const float* x, const float* gamma_in_packed, const float* beta_in, const float* map_mean,
+                         const float* bin_widths, const float* gamma_out_packed, const float* beta_out, float* y_out,
+                         float* shifted_out, float* t_out, int16_t* symbols_planar, uint32_t* nonzero_flags, uint32_t* checks,
+                         int n, int hw, void* stream);
+
 /* Per-map sums for the map means of lossless/stats.py:306 (`numpy.mean(y_float32, axis=(0, 1, 2))`): sums[c] += sum over
  * rows of y[row][c], accumulated in float64 (caller zeroes; the mean is sums / rows, rounded to float32 by the caller).
  * The reference's float32 accumulation is not reproduced (it carries ~1e-6 relative error itself): the result is the

@@ -129,46 +129,19 @@ class RateWorker(threading.Thread):
                 slot_free.set()
 
 
-def main():
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--gpus', type=int, default=1)
-    parser.add_argument('--steps', type=int, default=100)
-    parser.add_argument('--warmup', type=int, default=10)
-    parser.add_argument('--batch', type=int, default=24, help='Kodak-sized images per GPU per step')
-    parser.add_argument('--no-cpu-baseline', action='store_true')
-    parser.add_argument('--coder', choices=('device', 'host'), default='device',
-                        help='device: the coder kernels on side streams (default). host: one device -> host copy of the symbols '
-                             'per batch and the host C-ABI coder on a thread pool (the shape BASELINE.json sketches)')
-    parser.add_argument('--coder-threads', type=int, default=0, help='host coder threads (0 = usable CPUs - 2)')
-    parser.add_argument('--coder-streams', type=int, default=int(os.environ.get('EAE_CODER_STREAMS', '2')),
-                        help='batches whose entropy coding may be in flight at once (each on its own HIP stream)')
-    parser.add_argument('--coder-lanes', type=int, default=int(os.environ.get('EAE_CODER_LANES', '-1')),
-                        help='-1: 64 maps per wavefront in step (default); >= 0: the per-lane kernels with that many maps per block')
-    args = parser.parse_args()
+_STREAM_POOL = []
 
-    # two Python threads share the GIL (kernel launches; rate bookkeeping): hand it over quickly
-    sys.setswitchinterval(1e-4)
-    tracing = bool(os.environ.get('EAE_BENCH_TRACE'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the product path.')
-    torch.cuda.set_device(local_rank)
+
+def run_pipeline(args, batch, steps, warmup, device, world, rank, cores, tracing, variables, coder_streams=None):
+    """Builds the resident state for `batch` images per step, runs `warmup` untimed and `steps` timed steps, and returns
+    what the report needs. Everything in here up to the first barrier is outside the timed region."""
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world)
-    device = torch.device('cuda', local_rank)
-    cores = usable_cpus()
-    os.environ.setdefault('OMP_NUM_THREADS', str(cores))      # the oracle's OpenMP transforms (cpu_baseline only)
-
     # ---- model, inputs, coder tables (outside the timed region) ---------------------------------------------------
-    variables = synthetic_model(1.)
     encoder = pipeline.DeviceEncoder(variables, False, device)
     decoder = pipeline.DeviceDecoder(variables, False, device)
     bin_widths = torch.from_numpy(variables[var.BIN_WIDTHS_NAME]).to(device)
-    images = torch.from_numpy(synthetic_images(1000 + rank, args.batch, H_IN, W_IN)).to(device)
+    images = torch.from_numpy(synthetic_images(1000 + rank, batch, H_IN, W_IN)).to(device)
     (h_map, w_map) = (H_IN//16, W_IN//16)
     map_size = h_map*w_map
     # statistics that feed the coder, from this build's own a26/a27 path on the first batch (lossless/stats.py:306, :13-68)
@@ -180,27 +153,28 @@ def main():
     del y0
     probabilities_dev = torch.from_numpy(numpy.ascontiguousarray(probabilities, dtype=numpy.float64)).to(device)
     # row of `probabilities` per map of the batch; -1 = the exception map, costed from its histogram (compression.py:68-75)
-    prob_row = torch.arange(128, dtype=torch.int32).repeat(args.batch)
+    prob_row = torch.arange(128, dtype=torch.int32).repeat(batch)
     prob_row[IDX_MAP_EXCEPTION::128] = -1
     prob_row = prob_row.to(device)
-    n_maps = args.batch*128
-    nb_slots = args.coder_streams + 2
+    n_maps = batch*128
+    nb_coder_streams = coder_streams or args.coder_streams
+    nb_slots = nb_coder_streams + 2
     # everything the host needs from one batch, contiguous on the device:
     # [coder results 4 x n_maps | exception-map histograms | their overflow counts | non-zero flags of every map | 3 checks]
-    nb_host_words = 4*n_maps + args.batch*511 + args.batch + n_maps + 3
+    nb_host_words = 4*n_maps + batch*511 + batch + n_maps + 3
     slot_out = [torch.zeros(nb_host_words, dtype=torch.int32, device=device) for _ in range(nb_slots)]
     pinned_out = [torch.zeros(nb_host_words, dtype=torch.int32).pin_memory() for _ in range(nb_slots)]
 
     def views(t):
-        (a, b) = (4*n_maps, 4*n_maps + args.batch*511)
-        return (t[:a].view(4, n_maps), t[a:b].view(args.batch, 511), t[b:b + args.batch],
-                t[b + args.batch:b + args.batch + n_maps].view(args.batch, 128), t[b + args.batch + n_maps:])
+        (a, b) = (4*n_maps, 4*n_maps + batch*511)
+        return (t[:a].view(4, n_maps), t[a:b].view(batch, 511), t[b:b + batch],
+                t[b + batch:b + batch + n_maps].view(batch, 128), t[b + batch + n_maps:])
 
     streams = [dev.CoderStreams(n_maps, map_size, TRUNCATED_UNARY_LENGTH, device, results=views(slot_out[i])[0]) for i in range(nb_slots)]
     slot_hist = [views(slot_out[i])[1:3] for i in range(nb_slots)]
     slot_flags = [views(slot_out[i])[3:] for i in range(nb_slots)]
     pinned_views = [views(pinned_out[i]) for i in range(nb_slots)]
-    slot_symbols = [torch.empty((args.batch, 128, map_size), dtype=torch.int16, device=device) for _ in range(nb_slots)]
+    slot_symbols = [torch.empty((batch, 128, map_size), dtype=torch.int16, device=device) for _ in range(nb_slots)]
     workspaces = [dev.coder_workspace(n_maps, map_size, TRUNCATED_UNARY_LENGTH, device) for _ in range(nb_slots)]
     slot_free = [threading.Event() for _ in range(nb_slots)]
     for e in slot_free:
@@ -208,10 +182,14 @@ def main():
     host_coder = args.coder == 'host'
     coder_threads = args.coder_threads if args.coder_threads > 0 else max(1, cores//max(world, 1) - 2)
     worker = RateWorker(map_size, probabilities if host_coder else None, coder_threads)
-    pinned_symbols = [torch.empty((args.batch, 128, map_size), dtype=torch.int16).pin_memory() if host_coder else None for _ in range(nb_slots)]
+    pinned_symbols = [torch.empty((batch, 128, map_size), dtype=torch.int16).pin_memory() if host_coder else None for _ in range(nb_slots)]
     worker.start()
-    coder_streams = [torch.cuda.Stream() for _ in range(args.coder_streams)]
-    sse_total = torch.zeros(args.batch, dtype=torch.int64, device=device)
+    # HIP multiplexes streams onto 4 hardware queues: streams are reused across runs of this function so that a coder
+    # stream never ends up sharing a queue with the transform stream
+    while len(_STREAM_POOL) < nb_coder_streams:
+        _STREAM_POOL.append(torch.cuda.Stream())
+    coder_streams = _STREAM_POOL[:nb_coder_streams]
+    sse_total = torch.zeros(batch, dtype=torch.int64, device=device)
     gemm_events = []            # (start, stop, launch name) around every conv_gemm launch of the timed region
 
     def timed_launch(name, fn, record):
@@ -301,7 +279,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i, False)
     drain()
     worker.coder_bits = 0
@@ -316,7 +294,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     step_marks = []
-    for i in range(args.steps):
+    for i in range(steps):
         if tracing:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
@@ -325,7 +303,7 @@ def main():
     drain()
     # the path's only exchange step: sum the rate / PSNR accumulators over ranks
     coder_bits = float(worker.coder_bits) + float(worker.exception_bits)
-    stats = torch.tensor([coder_bits, float(sse_total.sum().item()), float(worker.dead_maps), float(args.steps*args.batch)],
+    stats = torch.tensor([coder_bits, float(sse_total.sum().item()), float(worker.dead_maps), float(steps*batch)],
                          dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
@@ -336,6 +314,53 @@ def main():
         te = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
+
+    worker.jobs.put(None)
+    return {'elapsed': elapsed, 'stats': stats, 'gemm_events': gemm_events, 'probabilities': probabilities,
+            'map_mean_host': map_mean_host, 'host_coder': host_coder, 'coder_threads': coder_threads,
+            'step_marks': step_marks, 'host_marks': host_marks}
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--gpus', type=int, default=1)
+    parser.add_argument('--steps', type=int, default=100)
+    parser.add_argument('--warmup', type=int, default=10)
+    parser.add_argument('--batch', type=int, default=24, help='Kodak-sized images per GPU per step')
+    parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--no-single-image', action='store_true', help='skip the one-image-per-step side measurement')
+    parser.add_argument('--coder', choices=('device', 'host'), default='device',
+                        help='device: the coder kernels on side streams (default). host: one device -> host copy of the symbols '
+                             'per batch and the host C-ABI coder on a thread pool (the shape BASELINE.json sketches)')
+    parser.add_argument('--coder-threads', type=int, default=0, help='host coder threads (0 = usable CPUs - 2)')
+    parser.add_argument('--coder-streams', type=int, default=int(os.environ.get('EAE_CODER_STREAMS', '2')),
+                        help='batches whose entropy coding may be in flight at once (each on its own HIP stream)')
+    parser.add_argument('--coder-lanes', type=int, default=int(os.environ.get('EAE_CODER_LANES', '-1')),
+                        help='-1: 64 maps per wavefront in step (default); >= 0: the per-lane kernels with that many maps per block')
+    args = parser.parse_args()
+
+    # two Python threads share the GIL (kernel launches; rate bookkeeping): hand it over quickly
+    sys.setswitchinterval(1e-4)
+    tracing = bool(os.environ.get('EAE_BENCH_TRACE'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the product path.')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world)
+    device = torch.device('cuda', local_rank)
+    cores = usable_cpus()
+    os.environ.setdefault('OMP_NUM_THREADS', str(cores))      # the oracle's OpenMP transforms (cpu_baseline only)
+
+    variables = synthetic_model(1.)
+    run = run_pipeline(args, args.batch, args.steps, args.warmup, device, world, rank, cores, tracing, variables)
+    (elapsed, stats, gemm_events, probabilities, map_mean_host) = (run['elapsed'], run['stats'], run['gemm_events'],
+                                                                    run['probabilities'], run['map_mean_host'])
+    (host_coder, coder_threads, step_marks, host_marks) = (run['host_coder'], run['coder_threads'], run['step_marks'], run['host_marks'])
 
     # ---- derived figures (outside the timed region) ------------------------------------------------------------------
     pixels_per_step = args.batch*H_IN*W_IN
@@ -394,7 +419,13 @@ def main():
         gpu = [round(step_marks[0][1].elapsed_time(m[1]), 2) for m in step_marks]
         sys.stderr.write('TRACE host enqueue deltas (ms): {}\nTRACE gpu step deltas (ms): {}\nTRACE total ms {}\n'.format(
             [round(b - a, 1) for (a, b) in zip(host[:-1], host[1:])], [round(b - a, 1) for (a, b) in zip(gpu[:-1], gpu[1:])], round(elapsed*1e3, 2)))
-    worker.jobs.put(None)
+    if rank == 0 and world == 1 and args.batch != 1 and not args.no_single_image:
+        # BASELINE.json configs[1] is ONE Kodak image: the same path with one image per step (launch-bound, not the headline)
+        del run, gemm_events
+        one = run_pipeline(args, 1, 300, 30, device, world, rank, cores, False, variables, coder_streams=3)
+        line['single_image'] = {'ms_per_image': round(one['elapsed']/300*1e3, 4),
+                                'mpixels_per_s': round(300*H_IN*W_IN/one['elapsed']/1e6, 2), 'steps': 300, 'warmup': 30,
+                                'note': 'one 512x768 image per step, steps pipelined back to back; host launch overhead dominates'}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(variables, probabilities, map_mean_host, cores)

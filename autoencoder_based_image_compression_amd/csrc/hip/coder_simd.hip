@@ -45,8 +45,11 @@ using namespace eae_core;
 
 constexpr int32_t RETRY = -100;           // internal: recode this map with the general kernel
 constexpr uint32_t kMaxFastL = 32;        // contexts staged in LDS: 32 x 64 lanes x 8 B = 16 KB
-constexpr uint32_t kBacWindowWords = 64;  // LDS window per lane, arithmetic-coded stream: 64 dwords = 2048 bits
-constexpr uint32_t kBypassWindowWords = 16;   // bypass stream: 512 bits
+// LDS windows per lane of the decoder, in dwords (arithmetic-coded stream, bypass stream). First pass: 2048 + 512 bits,
+// 20 KB per block, small enough to sit next to the transform kernels' blocks. Second pass, only for the maps the first
+// one found too long: 14336 + 3072 bits, 136 KB per block (one block per CU).
+constexpr uint32_t kBacWindowWords = 64, kBypassWindowWords = 16;
+constexpr uint32_t kBacWindowWordsBig = 448, kBypassWindowWordsBig = 96;
 
 struct SimdParams {
     uint32_t n_maps, map_size, L, dcap;   // dcap: bytes of decision storage per map (multiple of 8)
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // (3) 64 maps per wavefront: decode, streams staged in LDS
 // ---------------------------------------------------------------------------------------------------------------------
+template <uint32_t WB, uint32_t WY, bool SECOND>
 __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
     __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
     const uint32_t lane = threadIdx.x;
@@ -260,12 +264,13 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
     const uint32_t L = p.L;
     double* probs = lds_dyn;                                                        // [context][lane]
     uint32_t* wbac = reinterpret_cast<uint32_t*>(lds_dyn + (size_t)L * 64u);        // [word][lane]
-    uint32_t* wbyp = wbac + kBacWindowWords * 64u;                                  // [word][lane]
-    bool live = in_range && row >= 0 && p.status[m] == 0;
+    uint32_t* wbyp = wbac + WB * 64u;                                               // [word][lane]
+    bool live = in_range && row >= 0 && p.status[m] == (SECOND ? RETRY : 0);
+    if (SECOND && !__any(live)) return;                  // nothing was handed on to this pass in this group of 64 maps
     const uint32_t nbac = live ? p.bac_bits[m] : 0u;
     const uint32_t nbyp = live ? p.bypass_bits[m] : 0u;
     bool retry = false;
-    if (live && (nbac > kBacWindowWords * 32u || nbyp > kBypassWindowWords * 32u)) retry = true;   // longer than the window
+    if (live && (nbac > WB * 32u || nbyp > WY * 32u)) retry = true;   // longer than the window: next pass
     if (live)
         for (uint32_t k = 0; k < L; k++) probs[k * 64u + lane] = p.probs[(size_t)row * L + k];
     // stage the streams of the 64 maps: the wave copies one map per iteration, coalesced
@@ -274,9 +279,9 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
         if (ml >= p.n_maps) break;
         const uint32_t bits_b = __shfl(nbac, l, 64), bits_y = __shfl(nbyp, l, 64);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)ml * p.stride);
-        if (lane * 32u < bits_b && lane < kBacWindowWords) wbac[lane * 64u + l] = src[lane];
+        for (uint32_t w = lane; w < WB && w * 32u < bits_b; w += 64u) wbac[w * 64u + l] = src[w];
         const uint32_t* srcy = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)ml * p.stride + p.stride / 2);
-        if (lane * 32u < bits_y && lane < kBypassWindowWords) wbyp[lane * 64u + l] = srcy[lane];
+        for (uint32_t w = lane; w < WY && w * 32u < bits_y; w += 64u) wbyp[w * 64u + l] = srcy[w];
     }
     __syncthreads();
     int16_t* out = p.decoded + (size_t)(in_range ? m : 0u) * p.map_size;
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
     uint32_t rcount = 0, rword = 0;       // rword: next dword of the window to load
     auto refill = [&]() {
         if (rcount <= 32u) {
-            const uint32_t w = rword < kBacWindowWords && rword * 32u < nbac ? wbac[rword * 64u + lane] : 0u;
+            const uint32_t w = rword < WB && rword * 32u < nbac ? wbac[rword * 64u + lane] : 0u;
             rwin |= (unsigned long long)w << rcount;
             rcount += 32u;
             rword++;
@@ -491,7 +496,15 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
     if (!expected) (void)hipMemsetAsync(status, 0, (size_t)n_maps * sizeof(int32_t), s);   // a pure decode starts from a clean slate
     if (fast_applies(L) && map_size) {
         const size_t lds = (size_t)L * 64u * sizeof(double) + (size_t)(kBacWindowWords + kBypassWindowWords) * 64u * sizeof(uint32_t);
-        hipLaunchKernelGGL(bac_decode_kernel, dim3((n_maps + 63u) / 64u), dim3(64), lds, s, p);
+        hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, false>), dim3((n_maps + 63u) / 64u), dim3(64), lds, s, p);
+        // maps whose streams did not fit the small windows: same kernel, big windows (waves with no such map exit at once)
+        const size_t lds_big = (size_t)L * 64u * sizeof(double) + (size_t)(kBacWindowWordsBig + kBypassWindowWordsBig) * 64u * sizeof(uint32_t);
+        static const hipError_t big_ok = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsBig, kBypassWindowWordsBig, true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (big_ok == hipSuccess)
+            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsBig, kBypassWindowWordsBig, true>), dim3((n_maps + 63u) / 64u), dim3(64),
+                               lds_big, s, p);
         const int rc = eae_coder_generic_decode(n_maps, map_size, p.decoded, L, probs, prob_row, streams, stride, bac_bits,
                                                 bypass_bits, status, stage, RETRY, s);
         if (rc) return rc;

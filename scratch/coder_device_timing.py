@@ -73,3 +73,21 @@ if os.environ.get('EAE_CODER_DEBUG_CLOCKS'):
         torch.cuda.synchronize()
         cyc = s3.stage.cpu().numpy().astype(numpy.float64); ref = s3.bypass_bits.cpu().numpy().astype(numpy.float64)
         print('standalone lanes', lanes, 'cycles/map mean', cyc.mean(), 'max', cyc.max(), 'refclk ticks', ref.mean(), 'MHz', 100*cyc.mean()/ref.mean())
+print('--- denser symbols (as with half the bin width): batch kernels')
+rows = torch.arange(128, dtype=torch.int32).repeat(24); rows[67::128] = -1; rows = rows.cuda()
+for mul in (1, 2, 4):
+    dense = (sym.to(torch.int32)*mul + (torch.randint(0, mul, sym.shape, device='cuda', dtype=torch.int32) if mul > 1 else 0)).to(torch.int16)
+    ws = dev.coder_workspace(dense.shape[0], 1536, 10, dense.device)
+    s4 = dev.coder_encode_batch(dense, p, rows, 10, workspace=ws)
+    torch.cuda.synchronize()
+    a_, b_, c_ = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    a_.record()
+    for _ in range(5):
+        dev.coder_encode_batch(dense, p, rows, 10, out=s4, workspace=ws)
+    b_.record()
+    for _ in range(5):
+        dev.coder_decode_batch(s4, p, rows, expected=dense, workspace=ws)
+    c_.record(); torch.cuda.synchronize()
+    nb = s4.bac_bits.cpu().numpy()
+    print('x%d: bits/map mean %.0f max %d  maps beyond the 2048-bit window %d  encode %.3f ms  decode+compare %.3f ms  errors %d' % (
+        mul, nb[nb > 0].mean(), nb.max(), int((nb > 2048).sum()), a_.elapsed_time(b_)/5, b_.elapsed_time(c_)/5, int((s4.status != 0).sum().item())))

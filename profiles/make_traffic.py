@@ -24,8 +24,9 @@ def rows_of(directory):
 
 
 # template arguments <waves per block, epilogue> of the four launches at Kodak batch sizes (conv_gemm.hip, launch())
-INSTANCES = {'conv2_gdn2': 'conv_gemm_wave_kernel<2, 1>', 'conv3_gdn3': 'conv_gemm_wave_kernel<1, 1>',
-             'tconv1_igdn5': 'conv_gemm_wave_kernel<1, 2>', 'tconv2_igdn6': 'conv_gemm_wave_kernel<2, 2>'}
+# <waves per block, epilogue (0 none / 1 GDN / 2 IGDN), 32-channel tiles per wave>
+INSTANCES = {'conv2_gdn2': 'conv_gemm_wave_kernel<2, 1, 4>', 'conv3': 'conv_gemm_wave_kernel<1, 0, 2>',
+             'tconv1_igdn5': 'conv_gemm_wave_kernel<1, 2, 4>', 'tconv2_igdn6': 'conv_gemm_wave_kernel<2, 2, 4>'}
 
 
 def per_kernel(directory, counter, name):
@@ -40,12 +41,12 @@ def per_kernel(directory, counter, name):
 
 def main():
     (root, batch) = (sys.argv[1], int(sys.argv[2]))
-    names = ['conv2_gdn2', 'conv3_gdn3', 'tconv1_igdn5', 'tconv2_igdn6']     # launch order inside one step
+    names = ['conv2_gdn2', 'conv3', 'tconv1_igdn5', 'tconv2_igdn6']     # launch order inside one step
     pixels = batch*512*768
     # algorithmic bytes per launch: input activations + output activations, float32, each read / written once
     # (DESIGN.md section 5): conv2 128ch at /4 -> /8, conv3 /8 -> /16, tconv1 /16 -> /8, tconv2 /8 -> /4
     act = {4: pixels//16*128*4, 8: pixels//64*128*4, 16: pixels//256*128*4}
-    algorithmic = {'conv2_gdn2': act[4] + act[8], 'conv3_gdn3': act[8] + act[16], 'tconv1_igdn5': act[16] + act[8],
+    algorithmic = {'conv2_gdn2': act[4] + act[8], 'conv3': act[8] + act[16], 'tconv1_igdn5': act[16] + act[8],
                    'tconv2_igdn6': act[8] + act[4]}
     result = {}
     for name in names:

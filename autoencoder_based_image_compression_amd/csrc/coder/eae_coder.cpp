@@ -10,6 +10,7 @@
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -17,6 +18,10 @@
 #include <new>
 #include <thread>
 #include <vector>
+
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 #include "coder_core.h"
 
@@ -62,6 +67,29 @@ inline void init_external(eae_core::LosslessCoder& c, uint8_t* bac, uint8_t* byp
     c.probabilities = p;
 }
 
+// CPUs this process may really use: the affinity mask capped by the cgroup-v2 CPU quota (a container may see 256 hardware
+// threads behind a 16-CPU quota; a pool sized for 256 only thrashes). Falls back to hardware_concurrency().
+static int usable_cpus() {
+    static const int cached = [] {
+        int n = (int)std::thread::hardware_concurrency();
+#if defined(__linux__)
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char quota[32] = {0};
+            long period = 0;
+            if (std::fscanf(f, "%31s %ld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+                const long q = std::atol(quota) / period;
+                if (q >= 1 && q < n) n = (int)q;
+            }
+            std::fclose(f);
+        }
+#endif
+        return n > 0 ? n : 1;
+    }();
+    return cached;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Persistent thread pool: parallel_for over independent maps with dynamic (atomic counter) scheduling.
 // ---------------------------------------------------------------------------------------------------------------
@@ -71,8 +99,7 @@ public:
 
     void parallel_for(uint32_t n_items, int n_threads, const std::function<void(uint32_t, int)>& fn) {
         if (n_items == 0) return;
-        int hw = (int)std::thread::hardware_concurrency();
-        if (hw <= 0) hw = 1;
+        const int hw = usable_cpus();
         if (n_threads <= 0 || n_threads > hw) n_threads = hw;
         if ((uint32_t)n_threads > n_items) n_threads = (int)n_items;
         if (n_threads <= 1) {
@@ -89,7 +116,6 @@ public:
             wanted_ = n_threads - 1;
             running_ = wanted_;
             generation_++;
-            generation_pub_.store(generation_, std::memory_order_release);
         }
         cv_.notify_all();
         work(0);
@@ -104,7 +130,6 @@ private:
         {
             std::lock_guard<std::mutex> lk(m_);
             stop_ = true;
-            stop_pub_.store(true);
         }
         cv_.notify_all();
         for (auto& t : workers_) t.join();
@@ -146,8 +171,6 @@ private:
     uint32_t n_items_ = 0;
     int wanted_ = 0, running_ = 0;
     uint64_t generation_ = 0;
-    std::atomic<uint64_t> generation_pub_{0};
-    std::atomic<bool> stop_pub_{false};
     bool stop_ = false;
 };
 
@@ -231,8 +254,7 @@ int eae_coder_compress_maps(uint32_t n_maps, uint32_t map_size, const int16_t* s
     const bool verify = mode == EAE_MODE_ROUNDTRIP_VERIFY;
     const uint32_t req = required_bits(map_size, L);
     const size_t cap_bytes = (size_t)(round_up_to_byte(req) >> 3) + 16;
-    int hw = (int)std::thread::hardware_concurrency();
-    if (hw <= 0) hw = 1;
+    const int hw = usable_cpus();
     const int nt = (n_threads <= 0 || n_threads > hw) ? hw : n_threads;
     std::vector<Scratch> scratch((size_t)nt);
     std::atomic<int> first_error{0};

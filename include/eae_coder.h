@@ -85,7 +85,7 @@ int eae_coder_decode(uint32_t size, int16_t* array_output, uint8_t truncated_una
  *          EAE_MODE_ROUNDTRIP_VERIFY = encode + decode + compare with the input inside the worker threads
  *          (`reconstruction` may be NULL; status EAE_ROUNDTRIP_MISMATCH on a difference).
  * nb_bits[m], status[m], stage[m]: per-map results. Return value: 0, or the first non-zero status encountered.
- * n_threads <= 0 -> all hardware threads (capped at n_maps). */
+ * n_threads <= 0 -> every CPU the process may use (affinity mask capped by the cgroup CPU quota; capped at n_maps). */
 enum { EAE_MODE_ROUNDTRIP = 0, EAE_MODE_ENCODE_ONLY = 1, EAE_MODE_ROUNDTRIP_VERIFY = 2 };
 int eae_coder_compress_maps(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, int16_t* reconstruction,
                             uint8_t truncated_unary_length, const double* probabilities, const int32_t* prob_row,

@@ -21,14 +21,22 @@
 
 namespace {
 constexpr int TH = 4, TW = 16;
-constexpr int PS = 152;                       // floats per site: 4 regions of 32 (+4 pad) = 144, rounded so that
-constexpr int REGION = 36;                    //   PS/4 = 38 = 6 (mod 16), REGION/4 = 9 -> conflict-free b128 reads
-constexpr int PATCH_R = TH + 2, PATCH_C = TW + 2;
-constexpr int PATCH_FLOATS = PATCH_R * PATCH_C * PS;   // 16416 floats = 65,664 B -> 2 blocks / CU
+#ifndef EAE_T3_PASSES
+#define EAE_T3_PASSES 2
+#endif
+constexpr int PASSES = EAE_T3_PASSES;         // the input patch is staged PASSES times, 128 / PASSES channels at a time
+constexpr int HALF_C = EAE_C / PASSES;
+constexpr int REGION = HALF_C / 4 + 4;        // floats per (site, ci mod 4): HALF_C / 4 used + 4 pad (20 or 12)
+constexpr int PS = PASSES == 2 ? 88 : 56;     // floats per site: 4 regions, rounded so that 8 consecutive sites hit 8 distinct
+constexpr int PATCH_R = TH + 2, PATCH_C = TW + 2;     //   16-byte bank groups (PS/4 = 22 or 14) -> conflict-free b128 reads
+constexpr int PATCH_FLOATS = PATCH_R * PATCH_C * PS;   // 38,016 B (4 blocks = 8 waves per CU) or 24,192 B (6 blocks)
+constexpr int Q = HALF_C / 4;                 // float4 per site per pass
+constexpr int LOADS = (PATCH_R * PATCH_C * Q + 127) / 128;   // per thread per pass (14 or 7)
+constexpr int BATCHES = LOADS / 7;
 constexpr int STEPS = 4 * 9;                  // (channel block, neighbour)
 constexpr int RING = 4;                       // steps of weights in flight (2 float4 each)
 
-__global__ __launch_bounds__(128, 1) void tconv3_kernel(const float* __restrict__ x, const float* __restrict__ wq,
+__global__ __launch_bounds__(128, 2) void tconv3_kernel(const float* __restrict__ x, const float* __restrict__ wq,
                                                         float* __restrict__ out_f32, uint8_t* __restrict__ out_u8,
                                                         const uint8_t* __restrict__ ref, unsigned long long* sse,
                                                         int h, int win, int tiles_r, int tiles_c) {
@@ -57,53 +65,60 @@ __global__ __launch_bounds__(128, 1) void tconv3_kernel(const float* __restrict_
     }
 #pragma unroll
     for (int i = 0; i < RING; ++i) EAE_T3_LOAD(i, i)
-    // patch: 108 sites x 32 float4; zero outside the image (zero-fill at THIS layer, appendix C.3);
-    // channel ci of a site lands at (ci & 3) * REGION + (ci >> 2)
-    // 3456 float4 = 27 per thread, in 3 batches of 9 loads kept in flight together (a load-then-store loop would pay
-    // one global latency per iteration)
-    static_assert(PATCH_R * PATCH_C * 32 == 27 * 128, "patch staging assumes 27 float4 per thread");
-#pragma unroll
-    for (int batch = 0; batch < 3; ++batch) {
-        float4 v[9];
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const int i = tid + 128 * (9 * batch + j);
-            const int site = i >> 5, q = i & 31;
-            const int r = r0 + site / PATCH_C, c = c0 + site % PATCH_C;
-            const bool ok = (unsigned)r < (unsigned)h && (unsigned)c < (unsigned)win;
-            const float4* src = reinterpret_cast<const float4*>(x_img + ((size_t)(ok ? r : 0) * win + (ok ? c : 0)) * EAE_C + 4 * q);
-            const float4 t = *src;
-            v[j] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const int i = tid + 128 * (9 * batch + j);
-            float* dst = patch + (i >> 5) * PS + (i & 31);
-            dst[0] = v[j].x; dst[REGION] = v[j].y; dst[2 * REGION] = v[j].z; dst[3 * REGION] = v[j].w;
-        }
-    }
-    __syncthreads();
-
+    // The patch is staged in two passes of 64 channels (the K order is channel-block outer anyway): 38 KB of LDS per block
+    // instead of 66 KB, so four blocks = eight waves share a CU and cover each other's staging and MFMA latencies (with the
+    // whole patch resident only two blocks fitted: one wave per SIMD, MFMA issue stalls fully exposed).
+    // Pass p: 108 sites x 16 float4, zero outside the image (zero-fill at THIS layer, appendix C.3); channel ci of the
+    // pass lands at (ci & 3) * REGION + (ci >> 2). 1728 float4 = 13.5 per thread, two batches of 7 loads in flight.
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15, kq = lane >> 4;
     const float* a_base = patch + ((2 * wave + 1) * PATCH_C + (i16 + 1)) * PS + kq * REGION;   // site (row 2w, col i16)
 #pragma unroll
-    for (int step = 0; step < STEPS; ++step) {
-        const int cb = step / 9, nb = step % 9;
-        const int dr = 1 - nb / 3, dc = 1 - nb % 3;     // (+1,+1), (+1,0), ... (-1,-1)
-        const float* a0p = a_base + (dr * PATCH_C + dc) * PS + 8 * cb;
-        const float4 a00 = *reinterpret_cast<const float4*>(a0p), a01 = *reinterpret_cast<const float4*>(a0p + 4);
-        const float4 a10 = *reinterpret_cast<const float4*>(a0p + PATCH_C * PS), a11 = *reinterpret_cast<const float4*>(a0p + PATCH_C * PS + 4);
-        const float4 w0 = ring[step % RING][0], w1 = ring[step % RING][1];
-        acc0 = mfma16(a00.x, w0.x, acc0); acc1 = mfma16(a10.x, w0.x, acc1);
-        acc0 = mfma16(a00.y, w0.y, acc0); acc1 = mfma16(a10.y, w0.y, acc1);
-        acc0 = mfma16(a00.z, w0.z, acc0); acc1 = mfma16(a10.z, w0.z, acc1);
-        acc0 = mfma16(a00.w, w0.w, acc0); acc1 = mfma16(a10.w, w0.w, acc1);
-        acc0 = mfma16(a01.x, w1.x, acc0); acc1 = mfma16(a11.x, w1.x, acc1);
-        acc0 = mfma16(a01.y, w1.y, acc0); acc1 = mfma16(a11.y, w1.y, acc1);
-        acc0 = mfma16(a01.z, w1.z, acc0); acc1 = mfma16(a11.z, w1.z, acc1);
-        acc0 = mfma16(a01.w, w1.w, acc0); acc1 = mfma16(a11.w, w1.w, acc1);
-        if (step + RING < STEPS) EAE_T3_LOAD(step % RING, step + RING)
+    for (int pass = 0; pass < PASSES; ++pass) {
+        if (pass) __syncthreads();                     // both waves are done with the previous 64 channels
+#pragma unroll
+        for (int batch = 0; batch < BATCHES; ++batch) {
+            float4 v[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int i = tid + 128 * (7 * batch + j);
+                const int site = i / Q, q = i % Q;
+                const int r = r0 + site / PATCH_C, c = c0 + site % PATCH_C;
+                const bool ok = i < PATCH_R * PATCH_C * Q && (unsigned)r < (unsigned)h && (unsigned)c < (unsigned)win;
+                const float4* src = reinterpret_cast<const float4*>(x_img + ((size_t)(ok ? r : 0) * win + (ok ? c : 0)) * EAE_C +
+                                                                    HALF_C * pass + 4 * q);
+                const float4 t = *src;
+                v[j] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int i = tid + 128 * (7 * batch + j);
+                if (i < PATCH_R * PATCH_C * Q) {
+                    float* dst = patch + (i / Q) * PS + (i % Q);
+                    dst[0] = v[j].x; dst[REGION] = v[j].y; dst[2 * REGION] = v[j].z; dst[3 * REGION] = v[j].w;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ls = 0; ls < STEPS / PASSES; ++ls) {
+            const int step = pass * (STEPS / PASSES) + ls;
+            const int cbl = ls / 9, nb = ls % 9;            // channel block inside the pass, neighbour
+            const int dr = 1 - nb / 3, dc = 1 - nb % 3;     // (+1,+1), (+1,0), ... (-1,-1)
+            const float* a0p = a_base + (dr * PATCH_C + dc) * PS + 8 * cbl;
+            const float4 a00 = *reinterpret_cast<const float4*>(a0p), a01 = *reinterpret_cast<const float4*>(a0p + 4);
+            const float4 a10 = *reinterpret_cast<const float4*>(a0p + PATCH_C * PS), a11 = *reinterpret_cast<const float4*>(a0p + PATCH_C * PS + 4);
+            const float4 w0 = ring[step % RING][0], w1 = ring[step % RING][1];
+            acc0 = mfma16(a00.x, w0.x, acc0); acc1 = mfma16(a10.x, w0.x, acc1);
+            acc0 = mfma16(a00.y, w0.y, acc0); acc1 = mfma16(a10.y, w0.y, acc1);
+            acc0 = mfma16(a00.z, w0.z, acc0); acc1 = mfma16(a10.z, w0.z, acc1);
+            acc0 = mfma16(a00.w, w0.w, acc0); acc1 = mfma16(a10.w, w0.w, acc1);
+            acc0 = mfma16(a01.x, w1.x, acc0); acc1 = mfma16(a11.x, w1.x, acc1);
+            acc0 = mfma16(a01.y, w1.y, acc0); acc1 = mfma16(a11.y, w1.y, acc1);
+            acc0 = mfma16(a01.z, w1.z, acc0); acc1 = mfma16(a11.z, w1.z, acc1);
+            acc0 = mfma16(a01.w, w1.w, acc0); acc1 = mfma16(a11.w, w1.w, acc1);
+            if (step + RING < STEPS) EAE_T3_LOAD(step % RING, step + RING)
+        }
     }
     __syncthreads();                                   // both waves are done reading the patch
     // ---- epilogue: 16 x 64 pixel tile through LDS, then 8 consecutive pixels per thread ----------------------------

@@ -1,0 +1,267 @@
+"""The whole hot path for a batch of images as one asynchronous call: what the body of `fix_gamma`
+(kodak_tensorflow/reconstructing_eae_kodak.py:144-147, 170-225) does per image with `sess.run`, numpy and 127 Cython
+calls, issued here as a dozen launches over arrays that stay in HBM:
+
+    conv1+GDN1 -> conv2+GDN2 -> conv3 -> [GDN3 -> centre / quantise / int16 symbols / dead-map flags -> IGDN4]
+    -> exception-map histograms
+    -> (side stream) lossless coder: encode every map, decode it back, compare                 lossless/compression.py:84-154
+    -> tconv1+IGDN5 -> tconv2+IGDN6 -> tconv3 + BT.601 cast + squared error against the input  tools.py:61-93, 831-881
+
+`BatchCodec.submit` only enqueues; `Ticket.result()` returns, per image, the quantities `fix_gamma` stores: the number
+of bits of the lossless code (coder bits of the 127 ordinary maps + ceil(h*w*entropy) of the exception map,
+compression.py:68-81), the squared error (-> `tls.psnr_2d`), the number of dead maps (`tls.count_nb_deads`), and, on
+request, the uint8 reconstruction. The values equal those of the reference-shaped functions of `kodak/` on the same
+inputs (tests/test_gpu_codec.py); `bench.py` times exactly this class.
+
+Concurrency: the coder is a few latency-bound wavefronts, so its launches go to side streams and overlap the synthesis
+transforms of the same batch and the analysis transforms of the next ones; `nb_in_flight` batches of coder work may be
+pending. Buffers that cross streams are preallocated per slot; results reach the host through a kernel that writes pinned
+memory (no hipMemcpyAsync on the launch thread) and a worker thread turns them into per-image numbers.
+"""
+import queue
+import threading
+
+import numpy
+import torch
+
+from . import device as dev
+from . import pipeline
+from .kodak.eae.graph import constants as csts
+from .kodak.eae.graph import variables as var
+from .kodak.lossless import compression as lossless_compression
+
+# HIP multiplexes streams onto 4 hardware queues: side streams are shared by every codec of the process so that a coder
+# stream never ends up on the hardware queue of the stream the transforms run on.
+_SIDE_STREAMS = []
+_HIST_RADIUS = 255
+
+
+def _side_streams(count):
+    while len(_SIDE_STREAMS) < count:
+        _SIDE_STREAMS.append(torch.cuda.Stream())
+    return _SIDE_STREAMS[:count]
+
+
+class Ticket(object):
+    """Handle on one submitted batch."""
+
+    def __init__(self, nb_images):
+        self.nb_images = nb_images
+        self._done = threading.Event()
+        self._error = None
+        self._values = None
+        self.reconstruction_uint8 = None      # device tensor when the codec keeps reconstructions
+
+    def result(self):
+        """Blocks until the batch is through; dict of numpy arrays, one entry per image:
+        'nb_bits' int64 (lossless code incl. the exception map's entropy cost), 'coder_bits' int64, 'exception_bits' int64,
+        'sse' int64 (sum of squared uint8 differences), 'nb_deads' int64."""
+        self._done.wait()
+        if self._error is not None:
+            raise self._error
+        return self._values
+
+
+class _Worker(threading.Thread):
+    def __init__(self, map_size, nb_maps, host_probabilities, idx_map_exception, host_threads):
+        super(_Worker, self).__init__(daemon=True)
+        self.map_size = map_size
+        self.nb_maps = nb_maps
+        self.host_probabilities = host_probabilities
+        self.idx_map_exception = idx_map_exception
+        self.host_threads = host_threads
+        self.jobs = queue.Queue()
+
+    def run(self):
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            (ticket, events, views, symbols_host, slot_free) = job
+            try:
+                for event in events:
+                    event.synchronize()
+                (results, hist, overflow, flags, checks, sse) = [v.numpy() for v in views]
+                if symbols_host is not None:
+                    # encode + decode + compare per map on the host cores, like compress_lossless + the caller's assert
+                    (_, nb_bits) = lossless_compression.code_planar_symbols(symbols_host.numpy(), self.host_probabilities,
+                                                                           self.idx_map_exception, nb_threads=self.host_threads,
+                                                                           roundtrip=True, verify_only=True)
+                    results = numpy.zeros_like(results)
+                    results[0] = nb_bits.reshape(-1)
+                if results[2].any():
+                    bad = int(numpy.flatnonzero(results[2])[0])
+                    if int(results[2, bad]) == 6:
+                        raise AssertionError('\nArrays are not equal\nThe lossless compression has altered the centered quantized data.')
+                    from .kodak.lossless import interface_cython
+                    interface_cython.raise_for_status(int(results[2, bad]), int(results[3, bad]))
+                if int(checks[0]) != 0:
+                    raise AssertionError('The rounded array elements cannot be represented as 16-bit signed integers.')
+                n = ticket.nb_images
+                coder_bits = (results[0].astype(numpy.int64) + results[1].astype(numpy.int64)).reshape(n, self.nb_maps).sum(axis=1)
+                exception_bits = numpy.zeros(n, dtype=numpy.int64)
+                if hist.size:
+                    if int(overflow.sum()) != 0:
+                        raise RuntimeError('exception-map symbols outside the histogram radius')
+                    exception_bits = numpy.array([int(lossless_compression.exception_map_nb_bits(row, self.map_size))
+                                                  for row in hist.astype(numpy.int64)], dtype=numpy.int64)
+                ticket._values = {'nb_bits': coder_bits + exception_bits, 'coder_bits': coder_bits,
+                                  'exception_bits': exception_bits, 'sse': sse.astype(numpy.int64).copy(),
+                                  'nb_deads': (flags == 0).sum(axis=1).astype(numpy.int64)}
+            except Exception as exc:      # surfaced by Ticket.result()
+                ticket._error = exc
+            finally:
+                slot_free.set()
+                ticket._done.set()
+
+
+class BatchCodec(object):
+    """Encode -> quantise -> entropy-code (with round trip) -> decode -> squared error for batches of a fixed shape."""
+
+    def __init__(self, variables, are_bin_widths_learned, bin_widths_test, map_mean, binary_probabilities, idx_map_exception,
+                 batch_size, h_in, w_in, device='cuda', nb_in_flight=2, keep_reconstruction=False, launch_hook=None,
+                 coder='device', host_coder_threads=0):
+        """coder: 'device' (the coder kernels on side streams), 'host' (ONE device -> host copy of the symbols per batch, then
+        the host C-ABI coder `eae_coder_compress_maps` on `host_coder_threads` threads: the shape BASELINE.json sketches) or
+        'none' (transforms only; the bit counts come back as zeros)."""
+        if coder not in ('device', 'host', 'none'):
+            raise ValueError('`coder` is neither "device" nor "host" nor "none".')
+        if h_in % csts.STRIDE_PROD != 0 or w_in % csts.STRIDE_PROD != 0:
+            raise ValueError('The image size is not divisible by the product of the three strides.')
+        self.device = torch.device(device)
+        self.learned = are_bin_widths_learned
+        self.encoder = pipeline.DeviceEncoder(variables, are_bin_widths_learned, self.device)
+        self.decoder = pipeline.DeviceDecoder(variables, are_bin_widths_learned, self.device)
+        self.batch_size = batch_size
+        (self.h_in, self.w_in) = (h_in, w_in)
+        self.nb_maps = csts.NB_MAPS_3
+        self.map_size = (h_in//csts.STRIDE_PROD)*(w_in//csts.STRIDE_PROD)
+        self.idx_map_exception = idx_map_exception if 0 <= idx_map_exception < self.nb_maps else -1
+        probabilities = numpy.ascontiguousarray(binary_probabilities, dtype=numpy.float64)
+        if probabilities.ndim != 2 or probabilities.shape[0] != self.nb_maps:
+            raise ValueError('`binary_probabilities` must have one row per map.')
+        self.truncated_unary_length = probabilities.shape[1]
+        if self.truncated_unary_length > 255:
+            raise OverflowError('value too large to convert to numpy.uint8_t')   # interface_cython.pyx:49
+        self.bin_widths = torch.from_numpy(numpy.ascontiguousarray(bin_widths_test, dtype=numpy.float32)).to(self.device)
+        self.map_mean = torch.from_numpy(numpy.ascontiguousarray(map_mean, dtype=numpy.float32)).to(self.device)
+        self.probabilities = torch.from_numpy(probabilities).to(self.device)
+        prob_row = torch.arange(self.nb_maps, dtype=torch.int32).repeat(batch_size)
+        if self.idx_map_exception >= 0:
+            prob_row[self.idx_map_exception::self.nb_maps] = -1        # costed from its histogram (compression.py:68-75)
+        self.prob_row = prob_row.to(self.device)
+        self.keep_reconstruction = keep_reconstruction
+        self.coder = coder
+        self.launch_hook = launch_hook if launch_hook is not None else (lambda name, fn: fn())
+        n_maps = batch_size*self.nb_maps
+        nb_hist = batch_size if self.idx_map_exception >= 0 else 0
+        self._n_maps = n_maps
+        # per-slot device block for the host: [coder results 4 x n_maps | exception histograms | overflow | flags | checks(4)]
+        # followed by the squared errors (int64 per image, published on their own once the synthesis transform is through)
+        self._layout = (4*n_maps, nb_hist*(2*_HIST_RADIUS + 1), nb_hist, n_maps, 4)
+        nb_words = sum(self._layout)
+        assert nb_words % 2 == 0
+        self.nb_slots = nb_in_flight + 2
+        self._streams = _side_streams(nb_in_flight)
+        self._slot_all = [torch.zeros(nb_words + 2*batch_size, dtype=torch.int32, device=self.device) for _ in range(self.nb_slots)]
+        self._slot_out = [t[:nb_words] for t in self._slot_all]
+        self._pinned_out = [torch.zeros(nb_words, dtype=torch.int32).pin_memory() for _ in range(self.nb_slots)]
+        self._slot_sse = [t[nb_words:].view(torch.int64) for t in self._slot_all]
+        self._pinned_sse = [torch.zeros(batch_size, dtype=torch.int64).pin_memory() for _ in range(self.nb_slots)]
+        self._symbols = [torch.empty((batch_size, self.nb_maps, self.map_size), dtype=torch.int16, device=self.device)
+                         for _ in range(self.nb_slots)]
+        self._coder_streams = [dev.CoderStreams(n_maps, self.map_size, self.truncated_unary_length, self.device,
+                                                results=self._views(self._slot_out[i])[0]) for i in range(self.nb_slots)]
+        self._workspaces = [dev.coder_workspace(n_maps, self.map_size, self.truncated_unary_length, self.device)
+                            for _ in range(self.nb_slots)]
+        self._slot_free = [threading.Event() for _ in range(self.nb_slots)]
+        for event in self._slot_free:
+            event.set()
+        self._pinned_symbols = [torch.empty((batch_size, self.nb_maps, self.map_size), dtype=torch.int16).pin_memory()
+                                if coder == 'host' else None for _ in range(self.nb_slots)]
+        self._worker = _Worker(self.map_size, self.nb_maps, probabilities if coder == 'host' else None, self.idx_map_exception,
+                               host_coder_threads)
+        self._worker.start()
+        self._index = 0
+
+    def _views(self, t):
+        out = []
+        pos = 0
+        for count in self._layout:
+            out.append(t[pos:pos + count])
+            pos += count
+        (results, hist, overflow, flags, checks) = out
+        nb_hist = overflow.numel()
+        return (results.view(4, self._n_maps), hist.view(nb_hist, 2*_HIST_RADIUS + 1) if nb_hist else hist, overflow,
+                flags.view(self.batch_size, self.nb_maps), checks)
+
+    def submit(self, luminances_uint8):
+        """uint8 device tensor (batch_size, h_in, w_in) -> Ticket. Everything is enqueued; nothing is waited for except a
+        free slot (at most nb_in_flight + 2 batches are pending)."""
+        if luminances_uint8.dtype != torch.uint8:
+            raise TypeError('`luminances_uint8.dtype` is not equal to `torch.uint8`.')
+        if tuple(luminances_uint8.shape) != (self.batch_size, self.h_in, self.w_in):
+            raise ValueError('`luminances_uint8.shape` is not (batch_size, h_in, w_in).')
+        hook = self.launch_hook
+        (enc, dec) = (self.encoder, self.decoder)
+        (v, d) = (enc.v, dec.v)
+        gdn_1 = dev.conv9x9s4_u8(luminances_uint8, enc.w1, v['encoder/biases_1'], enc.g[1], v['encoder/beta_1'])
+        gdn_2 = hook('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, enc.w2, v['encoder/biases_2'], dev.NORM_GDN, enc.g[2], v['encoder/beta_2']))
+        y_raw = hook('conv3', lambda: dev.conv5x5s2(gdn_2, enc.w3, v['encoder/biases_3'], dev.NORM_NONE))
+        slot = self._index % self.nb_slots
+        stream = self._streams[self._index % len(self._streams)]
+        self._index += 1
+        self._slot_free[slot].wait()
+        self._slot_free[slot].clear()
+        (results, hist, overflow, flags, checks) = self._views(self._slot_out[slot])
+        self._slot_all[slot][4*self._n_maps:].zero_()    # histograms, overflow, flags, checks, squared errors: accumulated into
+        # gdn_3 -> centre / quantise / symbols / dead-map flags -> de-centre -> inverse_gdn_4: one pass over the latents
+        q = dev.latent_stage(y_raw, self.bin_widths, self.map_mean,
+                             gdn_in=None if self.learned else (enc.g[3], v['encoder/beta_3']),
+                             igdn_out=None if self.learned else (dec.g[4], d['decoder/beta_4']),
+                             want_shifted=self.learned, want_symbols=True, want_flags=True, out_symbols=self._symbols[slot],
+                             out_flags=flags, out_checks=checks[:3])
+        symbols = self._symbols[slot].view(self._n_maps, self.map_size)
+        if self.idx_map_exception >= 0:
+            dev.symbol_histograms(symbols, _HIST_RADIUS, out=(hist, overflow), first_map=self.idx_map_exception,
+                                  map_step=self.nb_maps, zero=False)
+        quantized = torch.cuda.Event()
+        quantized.record()
+        with torch.cuda.stream(stream):
+            stream.wait_event(quantized)
+            if self.coder == 'device':
+                dev.coder_encode_batch(symbols, self.probabilities, self.prob_row, self.truncated_unary_length,
+                                       out=self._coder_streams[slot], workspace=self._workspaces[slot])
+                dev.coder_decode_batch(self._coder_streams[slot], self.probabilities, self.prob_row, expected=symbols,
+                                       workspace=self._workspaces[slot])
+            elif self.coder == 'host':
+                self._pinned_symbols[slot].copy_(self._symbols[slot], non_blocking=True)
+            else:
+                results.zero_()
+            dev.publish_to_host(self._slot_out[slot], self._pinned_out[slot])
+            coded = torch.cuda.Event()
+            coded.record()
+        t = q['shifted'] if self.learned else q['t']
+        t = hook('tconv1_igdn5', lambda: dev.tconv5x5s2(t, dec.w4, d['decoder/biases_4'], dev.NORM_IGDN, dec.g[5], d['decoder/beta_5']))
+        t = hook('tconv2_igdn6', lambda: dev.tconv5x5s2(t, dec.w5, d['decoder/biases_5'], dev.NORM_IGDN, dec.g[6], d['decoder/beta_6']))
+        (_, reconstruction, _) = dev.tconv9x9s4_luma(t, dec.w6, want_f32=False, want_u8=True, ref_u8=luminances_uint8,
+                                                     sse=self._slot_sse[slot])
+        dev.publish_to_host(self._slot_sse[slot], self._pinned_sse[slot])
+        decoded = torch.cuda.Event()
+        decoded.record()
+        ticket = Ticket(self.batch_size)
+        if self.keep_reconstruction:
+            ticket.reconstruction_uint8 = reconstruction
+        self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],),
+                               self._pinned_symbols[slot], self._slot_free[slot]))
+        return ticket
+
+    def drain(self):
+        """Waits until every submitted batch is through."""
+        torch.cuda.synchronize(self.device)
+        for event in self._slot_free:
+            event.wait()
+
+    def close(self):
+        self.drain()
+        self._worker.jobs.put(None)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- Mpixels/s of the compression inference path (encode -> quantise -> entropy-code -> decode) on MI355X.
 
-One STEP = one pass of the whole hot path over one batch of Kodak-sized (512x768) synthetic luminance images that
+One STEP = one `codec.BatchCodec.submit`: one pass of the whole hot path over one batch of Kodak-sized (512x768) synthetic luminance images that
 are already resident in HBM:
     conv1+GDN1 -> conv2+GDN2 -> conv3 -> [GDN3 -> centre/quantise/int16 symbols (+dead-map flags) -> IGDN4] (one kernel)
     -> exception-map histogram
@@ -17,9 +17,7 @@ import argparse
 import gc
 import json
 import os
-import queue
 import sys
-import threading
 import time
 
 import numpy
@@ -28,10 +26,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from autoencoder_based_image_compression_amd import codec                    # noqa: E402
 from autoencoder_based_image_compression_amd import device as dev            # noqa: E402
 from autoencoder_based_image_compression_amd import pipeline                 # noqa: E402
 from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var   # noqa: E402
-from autoencoder_based_image_compression_amd.kodak.lossless import compression as lossless_compression   # noqa: E402
 from autoencoder_based_image_compression_amd.kodak.lossless import stats as lossless_stats   # noqa: E402
 from autoencoder_based_image_compression_amd.kodak.tools import tools as tls   # noqa: E402
 
@@ -71,129 +69,26 @@ def synthetic_model(bin_width=1.):
     return v
 
 
-class RateWorker(threading.Thread):
-    """Host end of the rate measurement, off the launch thread: waits for a batch's (small) device -> host copy of the
-    coder's per-map results and of the exception-map histograms, checks every status, sums the bit counts and forms the
-    exception map's ceil(h*w*entropy) (compression.py:68-75) in numpy float64 like the reference."""
-
-    def __init__(self, map_size, host_probabilities=None, host_threads=0):
-        super(RateWorker, self).__init__(daemon=True)
-        self.map_size = map_size
-        self.host_probabilities = host_probabilities      # --coder host: the C-ABI host coder runs here
-        self.host_threads = host_threads
-        self.jobs = queue.Queue()
-        self.coder_bits = 0
-        self.exception_bits = 0
-        self.dead_maps = 0
-        self.error = None
-        self.busy_s = 0.
-
-    def run(self):
-        while True:
-            job = self.jobs.get()
-            if job is None:
-                return
-            (event, results_host, hist_host, overflow_host, flags_host, checks_host, symbols_host, slot_free) = job
-            try:
-                event.synchronize()
-                t0 = time.perf_counter()
-                results = results_host.numpy()
-                if symbols_host is not None:
-                    # the north star's shape: ONE device -> host copy of the symbols, then the host C-ABI coder (encode +
-                    # decode + compare per map like compress_lossless), threaded over maps
-                    (_, nb_bits) = lossless_compression.code_planar_symbols(symbols_host.numpy(), self.host_probabilities,
-                                                                           IDX_MAP_EXCEPTION, nb_threads=self.host_threads,
-                                                                           roundtrip=True, verify_only=True)
-                    results = numpy.zeros_like(results)
-                    results[0] = nb_bits.reshape(-1)
-                if results[2].any():
-                    bad = int(numpy.flatnonzero(results[2])[0])
-                    raise RuntimeError('device coder: map {0} failed with status {1} at stage {2}'.format(bad, results[2, bad], results[3, bad]))
-                if int(overflow_host.numpy().sum()) != 0:
-                    raise RuntimeError('exception-map symbols outside the histogram radius')
-                if os.environ.get('EAE_CODER_DEBUG_CLOCKS'):
-                    keep = results[1] > 0
-                    sys.stderr.write('CLOCKS shader-cycles mean {:.0f} max {} refclk-ticks mean {:.0f} -> MHz {:.0f}\n'.format(
-                        results[3][keep].mean(), results[3][keep].max(), results[1][keep].mean(),
-                        100.*results[3][keep].mean()/results[1][keep].mean()))
-                if int(checks_host[0]) != 0:
-                    raise AssertionError('The rounded array elements cannot be represented as 16-bit signed integers.')
-                self.dead_maps += int((flags_host.numpy() == 0).sum())        # tls.count_nb_deads (tools.py:294-320)
-                self.coder_bits += int(results[0].astype(numpy.int64).sum()) + int(results[1].astype(numpy.int64).sum())
-                self.exception_bits += sum(int(lossless_compression.exception_map_nb_bits(row, self.map_size))
-                                           for row in hist_host.numpy().astype(numpy.int64))
-                self.busy_s += time.perf_counter() - t0
-            except Exception as exc:   # surfaced by the main thread
-                self.error = exc
-            finally:
-                slot_free.set()
-
-
-_STREAM_POOL = []
-
-
 def run_pipeline(args, batch, steps, warmup, device, world, rank, cores, tracing, variables, coder_streams=None):
-    """Builds the resident state for `batch` images per step, runs `warmup` untimed and `steps` timed steps, and returns
-    what the report needs. Everything in here up to the first barrier is outside the timed region."""
+    """Builds the resident state for `batch` images per step (codec.BatchCodec: weights, tables, per-slot buffers), runs
+    `warmup` untimed and `steps` timed steps, and returns what the report needs. Everything in here up to the first barrier
+    is outside the timed region."""
     if world > 1:
         import torch.distributed as dist
-    # ---- model, inputs, coder tables (outside the timed region) ---------------------------------------------------
-    encoder = pipeline.DeviceEncoder(variables, False, device)
-    decoder = pipeline.DeviceDecoder(variables, False, device)
-    bin_widths = torch.from_numpy(variables[var.BIN_WIDTHS_NAME]).to(device)
     images = torch.from_numpy(synthetic_images(1000 + rank, batch, H_IN, W_IN)).to(device)
-    (h_map, w_map) = (H_IN//16, W_IN//16)
-    map_size = h_map*w_map
+    map_size = (H_IN//16)*(W_IN//16)
     # statistics that feed the coder, from this build's own a26/a27 path on the first batch (lossless/stats.py:306, :13-68)
+    encoder = pipeline.DeviceEncoder(variables, False, device)
     y0 = encoder(images)
     map_mean_host = dev.map_means(y0).cpu().numpy()
     probabilities = lossless_stats.compute_binary_probabilities(y0.cpu().numpy(), variables[var.BIN_WIDTHS_NAME], map_mean_host,
                                                                 TRUNCATED_UNARY_LENGTH)
-    map_mean = torch.from_numpy(map_mean_host).to(device)
-    del y0
-    probabilities_dev = torch.from_numpy(numpy.ascontiguousarray(probabilities, dtype=numpy.float64)).to(device)
-    # row of `probabilities` per map of the batch; -1 = the exception map, costed from its histogram (compression.py:68-75)
-    prob_row = torch.arange(128, dtype=torch.int32).repeat(batch)
-    prob_row[IDX_MAP_EXCEPTION::128] = -1
-    prob_row = prob_row.to(device)
-    n_maps = batch*128
-    nb_coder_streams = coder_streams or args.coder_streams
-    nb_slots = nb_coder_streams + 2
-    # everything the host needs from one batch, contiguous on the device:
-    # [coder results 4 x n_maps | exception-map histograms | their overflow counts | non-zero flags of every map | 3 checks]
-    nb_host_words = 4*n_maps + batch*511 + batch + n_maps + 3
-    slot_out = [torch.zeros(nb_host_words, dtype=torch.int32, device=device) for _ in range(nb_slots)]
-    pinned_out = [torch.zeros(nb_host_words, dtype=torch.int32).pin_memory() for _ in range(nb_slots)]
-
-    def views(t):
-        (a, b) = (4*n_maps, 4*n_maps + batch*511)
-        return (t[:a].view(4, n_maps), t[a:b].view(batch, 511), t[b:b + batch],
-                t[b + batch:b + batch + n_maps].view(batch, 128), t[b + batch + n_maps:])
-
-    streams = [dev.CoderStreams(n_maps, map_size, TRUNCATED_UNARY_LENGTH, device, results=views(slot_out[i])[0]) for i in range(nb_slots)]
-    slot_hist = [views(slot_out[i])[1:3] for i in range(nb_slots)]
-    slot_flags = [views(slot_out[i])[3:] for i in range(nb_slots)]
-    pinned_views = [views(pinned_out[i]) for i in range(nb_slots)]
-    slot_symbols = [torch.empty((batch, 128, map_size), dtype=torch.int16, device=device) for _ in range(nb_slots)]
-    workspaces = [dev.coder_workspace(n_maps, map_size, TRUNCATED_UNARY_LENGTH, device) for _ in range(nb_slots)]
-    slot_free = [threading.Event() for _ in range(nb_slots)]
-    for e in slot_free:
-        e.set()
-    host_coder = args.coder == 'host'
-    coder_threads = args.coder_threads if args.coder_threads > 0 else max(1, cores//max(world, 1) - 2)
-    worker = RateWorker(map_size, probabilities if host_coder else None, coder_threads)
-    pinned_symbols = [torch.empty((batch, 128, map_size), dtype=torch.int16).pin_memory() if host_coder else None for _ in range(nb_slots)]
-    worker.start()
-    # HIP multiplexes streams onto 4 hardware queues: streams are reused across runs of this function so that a coder
-    # stream never ends up sharing a queue with the transform stream
-    while len(_STREAM_POOL) < nb_coder_streams:
-        _STREAM_POOL.append(torch.cuda.Stream())
-    coder_streams = _STREAM_POOL[:nb_coder_streams]
-    sse_total = torch.zeros(batch, dtype=torch.int64, device=device)
+    del y0, encoder
     gemm_events = []            # (start, stop, launch name) around every conv_gemm launch of the timed region
+    recording = [False]
 
-    def timed_launch(name, fn, record):
-        if not record:
+    def timed_launch(name, fn):
+        if not recording[0]:
             return fn()
         (a, b) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         a.record()
@@ -202,109 +97,40 @@ def run_pipeline(args, batch, steps, warmup, device, world, rank, cores, tracing
         gemm_events.append((a, b, name))
         return out
 
-    host_marks = []
-
-    def mark(tag):
-        if tracing:
-            host_marks.append((tag, time.perf_counter()))
-
-    def step(index, record):
-        mark('begin')
-        v = encoder.v
-        gdn_1 = dev.conv9x9s4_u8(images, encoder.w1, v['encoder/biases_1'], encoder.g[1], v['encoder/beta_1'])
-        gdn_2 = timed_launch('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, encoder.w2, v['encoder/biases_2'], dev.NORM_GDN,
-                                                                 encoder.g[2], v['encoder/beta_2']), record)
-        y_raw = timed_launch('conv3', lambda: dev.conv5x5s2(gdn_2, encoder.w3, v['encoder/biases_3'], dev.NORM_NONE), record)
-        mark('encoder')
-        slot = index % nb_slots
-        slot_free[slot].wait()
-        slot_free[slot].clear()
-        mark('slot')
-        # buffers that cross to the coder streams are per-slot and preallocated (no caching-allocator traffic across streams)
-        slot_out[slot][4*n_maps:].zero_()            # histograms, overflow, flags, checks: the kernels below accumulate into them
-        # gdn_3 -> centre / quantise / symbols / dead-map flags -> de-centre -> inverse_gdn_4: one pass over the latents
-        d = decoder.v
-        q = dev.latent_stage(y_raw, bin_widths, map_mean, gdn_in=(encoder.g[3], v['encoder/beta_3']),
-                             igdn_out=(decoder.g[4], d['decoder/beta_4']), want_symbols=True, want_flags=True,
-                             out_symbols=slot_symbols[slot], out_flags=slot_flags[slot][0], out_checks=slot_flags[slot][1])
-        # exception map of every image: exact histogram on the device; its entropy is formed on the host by the rate worker
-        dev.symbol_histograms(q['symbols'].view(n_maps, map_size), 255, out=slot_hist[slot], first_map=IDX_MAP_EXCEPTION,
-                              map_step=128, zero=False)
-        quantized = torch.cuda.Event()
-        quantized.record()
-        # entropy coding off the transform stream, concurrent with the transforms of this and the next batches: every map
-        # is encoded (streams left in HBM), then decoded back and compared in a second launch (what compress_lossless +
-        # the assert of compression.py:146-153 do); then ONE small device -> host copy of the per-map bit counts /
-        # statuses. The coder is a few latency-bound waves: several batches are kept in flight on separate streams.
-        mark('quantize')
-        symbols = q['symbols'].view(n_maps, map_size)
-        coder_stream = coder_streams[index % len(coder_streams)]
-        with torch.cuda.stream(coder_stream):
-            coder_stream.wait_event(quantized)
-            if host_coder:
-                pinned_symbols[slot].copy_(q['symbols'], non_blocking=True)
-            elif not os.environ.get('EAE_BENCH_NO_CODER'):    # diagnostic only: transforms without the coder
-                if args.coder_lanes >= 0:                     # per-lane kernels (coder_device.hip), for comparison
-                    dev.coder_compress_maps(symbols, probabilities_dev, prob_row, TRUNCATED_UNARY_LENGTH,
-                                            mode=dev.CODER_ENCODE_ONLY, out=streams[slot], lanes_per_wave=args.coder_lanes)
-                    dev.coder_verify_maps(streams[slot], symbols, probabilities_dev, prob_row, args.coder_lanes)
-                else:                                         # 64 maps per wavefront in step (coder_simd.hip)
-                    dev.coder_encode_batch(symbols, probabilities_dev, prob_row, TRUNCATED_UNARY_LENGTH, out=streams[slot],
-                                           workspace=workspaces[slot])
-                    mark('c_encode')
-                    dev.coder_decode_batch(streams[slot], probabilities_dev, prob_row, expected=symbols, workspace=workspaces[slot])
-                    mark('c_decode')
-            dev.publish_to_host(slot_out[slot], pinned_out[slot])
-            mark('c_copies')
-            copied = torch.cuda.Event()
-            copied.record()
-        mark('coder')
-        worker.jobs.put((copied,) + pinned_views[slot] + (pinned_symbols[slot], slot_free[slot]))
-        t = timed_launch('tconv1_igdn5', lambda: dev.tconv5x5s2(q['t'], decoder.w4, d['decoder/biases_4'], dev.NORM_IGDN,
-                                                                decoder.g[5], d['decoder/beta_5']), record)
-        t = timed_launch('tconv2_igdn6', lambda: dev.tconv5x5s2(t, decoder.w5, d['decoder/biases_5'], dev.NORM_IGDN,
-                                                                decoder.g[6], d['decoder/beta_6']), record)
-        dev.tconv9x9s4_luma(t, decoder.w6, want_f32=False, want_u8=True, ref_u8=images, sse=sse_total)
-        mark('decoder')
-
-    def drain():
-        torch.cuda.synchronize()
-        for e in slot_free:
-            e.wait()
-        if worker.error is not None:
-            raise worker.error
+    coder_mode = 'none' if os.environ.get('EAE_BENCH_NO_CODER') else args.coder      # 'none': diagnostic only
+    coder_threads = args.coder_threads if args.coder_threads > 0 else max(1, cores//max(world, 1) - 2)
+    the_codec = codec.BatchCodec(variables, False, variables[var.BIN_WIDTHS_NAME], map_mean_host, probabilities, IDX_MAP_EXCEPTION,
+                                 batch, H_IN, W_IN, device=device, nb_in_flight=coder_streams or args.coder_streams,
+                                 launch_hook=timed_launch, coder=coder_mode, host_coder_threads=coder_threads)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(warmup):
-        step(i, False)
-    drain()
-    worker.coder_bits = 0
-    worker.exception_bits = 0
-    worker.dead_maps = 0
-    sse_total.zero_()
-    worker.busy_s = 0.
+    for _ in range(warmup):
+        the_codec.submit(images)
+    the_codec.drain()
 
     # the launch thread allocates only short-lived wrappers: keep the cyclic collector (a 30 ms pause every ~75 steps) out of it
     gc.collect()
     gc.disable()
+    recording[0] = True
     barrier()
     t0 = time.perf_counter()
     step_marks = []
-    for i in range(steps):
+    tickets = []
+    for _ in range(steps):
         if tracing:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             step_marks.append((time.perf_counter() - t0, ev))
-        step(i, True)
-    drain()
+        tickets.append(the_codec.submit(images))
+    the_codec.drain()
+    results = [t.result() for t in tickets]          # raises here if any map of any batch failed
     # the path's only exchange step: sum the rate / PSNR accumulators over ranks
-    coder_bits = float(worker.coder_bits) + float(worker.exception_bits)
-    stats = torch.tensor([coder_bits, float(sse_total.sum().item()), float(worker.dead_maps), float(steps*batch)],
-                         dtype=torch.float64, device=device)
+    stats = torch.tensor([float(sum(int(r['nb_bits'].sum()) for r in results)), float(sum(int(r['sse'].sum()) for r in results)),
+                          float(sum(int(r['nb_deads'].sum()) for r in results)), float(steps*batch)], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     barrier()
@@ -314,11 +140,10 @@ def run_pipeline(args, batch, steps, warmup, device, world, rank, cores, tracing
         te = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-
-    worker.jobs.put(None)
+    the_codec.close()
     return {'elapsed': elapsed, 'stats': stats, 'gemm_events': gemm_events, 'probabilities': probabilities,
-            'map_mean_host': map_mean_host, 'host_coder': host_coder, 'coder_threads': coder_threads,
-            'step_marks': step_marks, 'host_marks': host_marks}
+            'map_mean_host': map_mean_host, 'host_coder': coder_mode == 'host', 'coder_threads': coder_threads,
+            'step_marks': step_marks}
 
 
 def main():
@@ -335,11 +160,9 @@ def main():
     parser.add_argument('--coder-threads', type=int, default=0, help='host coder threads (0 = usable CPUs - 2)')
     parser.add_argument('--coder-streams', type=int, default=int(os.environ.get('EAE_CODER_STREAMS', '2')),
                         help='batches whose entropy coding may be in flight at once (each on its own HIP stream)')
-    parser.add_argument('--coder-lanes', type=int, default=int(os.environ.get('EAE_CODER_LANES', '-1')),
-                        help='-1: 64 maps per wavefront in step (default); >= 0: the per-lane kernels with that many maps per block')
     args = parser.parse_args()
 
-    # two Python threads share the GIL (kernel launches; rate bookkeeping): hand it over quickly
+    # two Python threads share the GIL (kernel launches; the codec's result worker): hand it over quickly
     sys.setswitchinterval(1e-4)
     tracing = bool(os.environ.get('EAE_BENCH_TRACE'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -360,7 +183,7 @@ def main():
     run = run_pipeline(args, args.batch, args.steps, args.warmup, device, world, rank, cores, tracing, variables)
     (elapsed, stats, gemm_events, probabilities, map_mean_host) = (run['elapsed'], run['stats'], run['gemm_events'],
                                                                     run['probabilities'], run['map_mean_host'])
-    (host_coder, coder_threads, step_marks, host_marks) = (run['host_coder'], run['coder_threads'], run['step_marks'], run['host_marks'])
+    (host_coder, coder_threads, step_marks) = (run['host_coder'], run['coder_threads'], run['step_marks'])
 
     # ---- derived figures (outside the timed region) ------------------------------------------------------------------
     pixels_per_step = args.batch*H_IN*W_IN
@@ -405,16 +228,6 @@ def main():
                      'algorithmic_flop_per_launch': {k: flops[k]*pixels_per_step for k in flops}},
     }
     if step_marks:
-        sections = {}
-        slow = []
-        for ((tag_a, t_a), (tag_b, t_b)) in zip(host_marks[:-1], host_marks[1:]):
-            if tag_b == 'begin':
-                continue
-            sections.setdefault(tag_b, []).append((t_b - t_a)*1e3)
-            if (t_b - t_a) > 4e-3:
-                slow.append((tag_b, len(sections[tag_b]) - 1, round((t_b - t_a)*1e3, 1)))
-        sys.stderr.write('TRACE host sections mean ms: {}\nTRACE host sections > 4 ms (section, step, ms): {}\n'.format(
-            {k: round(sum(v_)/len(v_), 3) for (k, v_) in sections.items()}, slow))
         host = [round(m[0]*1e3, 2) for m in step_marks]
         gpu = [round(step_marks[0][1].elapsed_time(m[1]), 2) for m in step_marks]
         sys.stderr.write('TRACE host enqueue deltas (ms): {}\nTRACE gpu step deltas (ms): {}\nTRACE total ms {}\n'.format(

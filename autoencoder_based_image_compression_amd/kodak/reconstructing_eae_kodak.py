@@ -89,6 +89,56 @@ def fix_gamma(reference_uint8, bin_width_init, multipliers, idx_training, gamma_
     return (rate, psnr)
 
 
+def fix_gamma_batched(reference_uint8, bin_width_init, multipliers, idx_training, gamma_scaling, batch_size,
+                      are_bin_widths_learned, root='.', return_nb_deads=False):
+    """`fix_gamma(..., is_lossless=True)` through `codec.BatchCodec`: same files, same returned arrays (equal element for
+    element, tests/test_gpu_surface.py), but every rate point is a handful of asynchronous launches per mini-batch instead
+    of one `sess.run` + numpy pass + 127 coder calls per image: the latents, symbols and streams never leave HBM."""
+    import torch
+
+    from .. import codec
+    from .eae.graph import variables as var
+    nb_points = multipliers.size
+    (nb_images, h_in, w_in) = reference_uint8.shape
+    if reference_uint8.dtype != numpy.uint8:
+        raise TypeError('`luminances_uint8.dtype` is not equal to `numpy.uint8`.')     # eae/batching.py:86-87
+    tls.subdivide_set(nb_images, batch_size)                                            # ValueError like encode_mini_batches
+    if are_bin_widths_learned:
+        suffix = 'learning_bw_{0}_{1}'.format(tls.float_to_str(bin_width_init), tls.float_to_str(gamma_scaling))
+    else:
+        suffix = '{0}_{1}'.format(tls.float_to_str(bin_width_init), tls.float_to_str(gamma_scaling))
+    path_to_restore = os.path.join(root, 'eae/results/{0}/model_{1}.npz'.format(suffix, idx_training))
+    if not os.path.isfile(path_to_restore):
+        raise IOError('The model "{}" does not exist.'.format(path_to_restore))
+    path_to_stats = os.path.join(root, 'lossless/results/{0}/training_index_{1}/'.format(suffix, idx_training))
+    variables = var.load_variables(path_to_restore)
+    bin_widths = variables[var.BIN_WIDTHS_NAME]
+    map_mean = numpy.load(os.path.join(path_to_stats, 'map_mean.npy'))
+    with open(os.path.join(path_to_stats, 'idx_map_exception.pkl'), 'rb') as file:
+        idx_map_exception = pickle.load(file)
+    rate = numpy.zeros((nb_points, nb_images))
+    psnr = numpy.zeros((nb_points, nb_images))
+    array_nb_deads = numpy.zeros((nb_points, nb_images), dtype=numpy.int32)
+    images = torch.from_numpy(numpy.ascontiguousarray(reference_uint8)).cuda()
+    for i in range(nb_points):
+        multiplier = multipliers[i].item()
+        binary_probabilities = compression.load_binary_probabilities(
+            os.path.join(path_to_stats, 'binary_probabilities_{}.npy'.format(tls.float_to_str(multiplier))))
+        batch_codec = codec.BatchCodec(variables, are_bin_widths_learned, multiplier*bin_widths, map_mean, binary_probabilities,
+                                       idx_map_exception, batch_size, h_in, w_in)
+        tickets = [batch_codec.submit(images[lo:lo + batch_size]) for lo in range(0, nb_images, batch_size)]
+        for (k, ticket) in enumerate(tickets):
+            values = ticket.result()
+            sl = slice(k*batch_size, (k + 1)*batch_size)
+            rate[i, sl] = values['nb_bits'].astype(numpy.float64)/(h_in*w_in)
+            psnr[i, sl] = [tls.psnr_from_sse(int(v), h_in*w_in) for v in values['sse']]
+            array_nb_deads[i, sl] = values['nb_deads']
+        batch_codec.close()
+    if return_nb_deads:
+        return (rate, psnr, array_nb_deads)
+    return (rate, psnr)
+
+
 def vary_gamma_fix_bin_widths(reference_uint8, bin_width_init, idxs_training, gammas_scaling, batch_size,
                               path_to_checking_r=None, list_rotation=None, positions_top_left=None, root='.'):
     """Rate and PSNR of several entropy autoencoders, each trained with a different scaling coefficient (:401-556)."""

@@ -148,6 +148,11 @@ def test_fix_gamma_harness_against_the_oracle(tmp_path, tls, cgold, learned):
     for is_lossless in (True, False):
         (rate, psnr, nb_deads) = rk.fix_gamma(x, 0.5 if learned else 1., multipliers, 10, 10000., 2, learned, is_lossless,
                                               root=str(tmp_path), return_nb_deads=True)
+        if is_lossless:
+            # the same harness through codec.BatchCodec (everything in HBM, asynchronous): identical arrays
+            fast = rk.fix_gamma_batched(x, 0.5 if learned else 1., multipliers, 10, 10000., 2, learned, root=str(tmp_path),
+                                        return_nb_deads=True)
+            assert numpy.array_equal(fast[0], rate) and numpy.array_equal(fast[1], psnr) and numpy.array_equal(fast[2], nb_deads)
         # ---- expectation ---------------------------------------------------------------------------------------
         y = T.encoder(x.astype(numpy.float32)[..., None], v, learned)
         centered = y - numpy.tile(map_mean, y.shape[:3] + (1,))

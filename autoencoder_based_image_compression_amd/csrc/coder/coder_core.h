@@ -41,6 +41,9 @@ EAE_HD uint32_t count_nb_bits(uint32_t x) {  // utils.cpp:13-28: floor(log2(x)) 
     return x ? (uint32_t)(32 - __builtin_clz(x)) : 1u;
 }
 EAE_HD uint32_t rev16(uint32_t v) {  // reverse the low 16 bits
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_bitreverse32(v << 16);   // v_bfrev_b32
+#endif
     v = ((v & 0x5555u) << 1) | ((v >> 1) & 0x5555u);
     v = ((v & 0x3333u) << 2) | ((v >> 2) & 0x3333u);
     v = ((v & 0x0F0Fu) << 4) | ((v >> 4) & 0x0F0Fu);

@@ -16,7 +16,7 @@
 //                one decision per lane and advances a three-register binarisation state (unary count, symbol index).
 //            (4) compare_kernel: decoded == encoded symbols (the assert of lossless/compression.py:146-153).
 //
-// Anything the fast kernels do not handle -- an error of any kind (their exact code and stage matter), more than 32
+// Anything the fast kernels do not handle -- an error of any kind (their exact code and stage matter), more than 47
 // pending E3 bits, a stream longer than its LDS window, L == 0 or L > 32 -- marks the map RETRY, and the general
 // per-lane kernel (the shared core of coder_core.h, statement for statement the reference) recodes that map from
 // scratch. Results are therefore identical to the host library's in every case; tests/test_coder_device.py compares
@@ -173,20 +173,29 @@ __global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
     bool live = in_range && row >= 0 && p.status[m] == 0;
     const uint32_t L = p.L;
     double* probs = lds_dyn;                            // [context][lane]
+    bool retry = false;
     if (live)
-        for (uint32_t k = 0; k < L; k++) probs[k * 64u + lane] = p.probs[(size_t)row * L + k];
-    const uint32_t nd = live ? p.ndec[m] : 0u;
+        for (uint32_t k = 0; k < L; k++) {
+            const double pk = p.probs[(size_t)row * L + k];
+            probs[k * 64u + lane] = pk;
+            // An invalid probability only matters if its context is coded (BinaryArithmeticCoder.cpp:146-153): the general
+            // kernel sorts that out; here the whole map is handed over so that the steps below need no check.
+            if (!(pk > 0. && pk < 1.)) retry = true;
+        }
+    const uint32_t nd = live && !retry ? p.ndec[m] : 0u;
     const uint32_t steps = wave_max(nd);
     Bac bac;
     bac.init();
     bac.bs.init_writer(p.streams + (uint64_t)(in_range ? m : 0u) * p.stride, required_bits(p.map_size, L));
     const uint8_t* dec = p.decisions + (size_t)blockIdx.x * 64u * p.dcap + (size_t)lane * 8u;
     uint32_t low = 0, high = kRangeMax, e3 = 0;
-    bool retry = false;
     uint2 ahead = steps ? *reinterpret_cast<const uint2*>(dec) : make_uint2(0, 0);
     for (uint32_t jb = 0; jb < steps; jb += 8) {
         const unsigned long long d8 = (unsigned long long)ahead.x | ((unsigned long long)ahead.y << 32);
         if (jb + 8 < steps) ahead = *reinterpret_cast<const uint2*>(dec + (size_t)((jb >> 3) + 1u) * 512u);
+        // eight steps emit at most 8 x (16 + 47) bits: near the end of the stream's capacity (Bitstream.cpp:32-35) the map
+        // goes to the general kernel, which reproduces the exact point of failure
+        if (bac.bs.write_index + 8u * 63u > bac.bs.size_bits) retry = true;
 #pragma unroll
         for (uint32_t q = 0; q < 8; q++) {
             const uint32_t j = jb + q;
@@ -198,34 +207,29 @@ __global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
                 const uint32_t mid = low + (uint32_t)(pk * (double)(high - low));
                 uint32_t nl = bit ? mid + 1u : low;
                 uint32_t nh = bit ? high : mid;
-                if (!(pk > 0. && pk < 1.) || nl > kRangeMax) retry = true;
+                if (nl > kRangeMax) retry = true;                    // precision_error (cannot happen with 0 < p < 1)
                 // E1/E2 in closed form (as Bac::encode): n leading equal bits leave, with the pending E3 bits behind the first
                 const uint32_t diff = (nl ^ nh) & 0xFFFFu;
                 const uint32_t n = diff ? (uint32_t)__builtin_clz(diff) - 16u : 16u;
+                if (e3 > 47u) retry = true;                          // the 64-bit put below holds 1 + 47 + 15 bits
                 if (n && !retry) {
-                    if (e3 > 32u) retry = true;
-                    else {
-                        const uint32_t out = rev16(nh);
-                        const unsigned long long first = out & 1u;
-                        const unsigned long long run = first ? 0ull : ((1ull << e3) - 1ull);
-                        const unsigned long long rest = (out >> 1) & ((1u << (n - 1u)) - 1u);
-                        const unsigned long long bits = first | (run << 1) | (rest << (1u + e3));
-                        const uint32_t cnt = n + e3;
-                        Bitstream& bs = bac.bs;
-                        if (bs.write_index + cnt > bs.size_bits) retry = true;
-                        else {
-                            const uint32_t sh = bs.write_index & 63u;
-                            bs.acc |= bits << sh;
-                            if (sh + cnt >= 64u) {
-                                store64(bs.data + ((bs.write_index >> 6) << 3), bs.acc);
-                                bs.acc = sh ? bits >> (64u - sh) : 0ull;
-                            }
-                            bs.write_index += cnt;
-                            e3 = 0;
-                            nl = (nl << n) & 0xFFFFu;
-                            nh = ((nh << n) & 0xFFFFu) | ((1u << n) - 1u);
-                        }
+                    const uint32_t out = rev16(nh);
+                    const unsigned long long first = out & 1u;
+                    const unsigned long long run = first ? 0ull : ((1ull << e3) - 1ull);
+                    const unsigned long long rest = (out >> 1) & ((1u << (n - 1u)) - 1u);
+                    const unsigned long long bits = first | (run << 1) | (rest << (1u + e3));
+                    const uint32_t cnt = n + e3;
+                    Bitstream& bs = bac.bs;
+                    const uint32_t sh = bs.write_index & 63u;
+                    bs.acc |= bits << sh;
+                    if (sh + cnt >= 64u) {
+                        store64(bs.data + ((bs.write_index >> 6) << 3), bs.acc);
+                        bs.acc = sh ? bits >> (64u - sh) : 0ull;
                     }
+                    bs.write_index += cnt;
+                    e3 = 0;
+                    nl = (nl << n) & 0xFFFFu;
+                    nh = ((nh << n) & 0xFFFFu) | ((1u << n) - 1u);
                 }
                 // E3 (BinaryArithmeticCoder.cpp:238-245)
                 while (!retry && nl > kRangeQuarter && nh <= kRangeThreeQuarters) {
@@ -272,7 +276,11 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
     bool retry = false;
     if (live && (nbac > WB * 32u || nbyp > WY * 32u)) retry = true;   // longer than the window: next pass
     if (live)
-        for (uint32_t k = 0; k < L; k++) probs[k * 64u + lane] = p.probs[(size_t)row * L + k];
+        for (uint32_t k = 0; k < L; k++) {
+            const double pk = p.probs[(size_t)row * L + k];
+            probs[k * 64u + lane] = pk;
+            if (!(pk > 0. && pk < 1.)) retry = true;     // only an error if that context is decoded: general kernel
+        }
     // stage the streams of the 64 maps: the wave copies one map per iteration, coalesced
     for (uint32_t l = 0; l < 64u; l++) {
         const uint32_t ml = blockIdx.x * 64u + l;
@@ -317,7 +325,6 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
         const double pk = probs[unary * 64u + lane];
         // Bac::decode (BinaryArithmeticCoder.cpp:124-134, 254-320) with the closed-form renormalisation of coder_core.h
         const uint32_t mid = low + (uint32_t)(pk * (double)(high - low));
-        if (!(pk > 0. && pk < 1.)) { retry = true; break; }
         const uint32_t bit = code > mid ? 1u : 0u;
         uint32_t nl = bit ? mid + 1u : low;
         uint32_t nh = bit ? high : mid;

@@ -170,11 +170,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the product path.')
+    if os.environ.get('EAE_BENCH_SHARE_GPU'):      # test hook: several ranks on one GPU (gloo instead of RCCL)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend='gloo' if os.environ.get('EAE_BENCH_SHARE_GPU') else 'nccl', rank=rank, world_size=world)
     device = torch.device('cuda', local_rank)
     cores = usable_cpus()
     os.environ.setdefault('OMP_NUM_THREADS', str(cores))      # the oracle's OpenMP transforms (cpu_baseline only)

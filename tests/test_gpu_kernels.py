@@ -220,3 +220,38 @@ def test_full_chain_bitwise(T, dev, orc, learned):
     (f32, u8, _) = pipeline.DeviceDecoder(v, learned)(q, want_float=True, want_uint8=True)
     assert numpy.array_equal(f32.cpu().numpy(), rec_ref)
     assert numpy.array_equal(u8.cpu().numpy(), numpy.round(rec_ref.clip(min=16., max=235.)).astype(numpy.uint8))
+
+
+@pytest.mark.parametrize('learned', [False, True])
+@pytest.mark.parametrize('size', ['64x96', '256x256'])
+def test_transforms_equal_the_committed_fixture(learned, size):
+    """tests/golden/transforms_golden.npz (written by the CPU restatement, oracle/gen_transforms_golden.py): the HIP path
+    reproduces the latents, the reconstruction and the per-layer checksums without running the oracle."""
+    import os
+    import zlib
+    import torch
+    from autoencoder_based_image_compression_amd import device as dev
+    from autoencoder_based_image_compression_amd import pipeline
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    v = var.random_variables(1., learned, seed=0, bias_std=0.01)
+    v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
+    tag = '{0}_{1}'.format('learned' if learned else 'fixed', size)
+    with numpy.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'transforms_golden.npz')) as g:
+        (x, y_ref, q_ref, rec_ref) = (g[tag + '_x'], g[tag + '_y'], g[tag + '_q'], g[tag + '_rec_u8'])
+        crc = {name: g[tag + '_sum_crc_' + name] for name in ('gdn_1', 'gdn_2', 'conv_3', 'igdn_3')}
+    enc = pipeline.DeviceEncoder(v, learned)
+    dec = pipeline.DeviceDecoder(v, learned)
+    xd = torch.from_numpy(x).cuda()
+    y = enc(xd)
+    assert numpy.array_equal(y.cpu().numpy(), y_ref)
+    (_, rec, _) = dec(torch.from_numpy(q_ref).cuda())
+    assert numpy.array_equal(rec.cpu().numpy(), rec_ref)
+    gdn_1 = dev.conv9x9s4_u8(xd, enc.w1, enc.v['encoder/biases_1'], enc.g[1], enc.v['encoder/beta_1'])
+    gdn_2 = dev.conv5x5s2(gdn_1, enc.w2, enc.v['encoder/biases_2'], dev.NORM_GDN, enc.g[2], enc.v['encoder/beta_2'])
+    conv_3 = dev.conv5x5s2(gdn_2, enc.w3, enc.v['encoder/biases_3'], dev.NORM_NONE)
+    for (name, a) in (('gdn_1', gdn_1), ('gdn_2', gdn_2), ('conv_3', conv_3)):
+        a = a.cpu().numpy()
+        # the float64 sum is blind to the one permitted difference, -0.0 against +0.0 (DESIGN.md section 3); the CRC is not
+        assert numpy.sum(a, dtype=numpy.float64) == crc[name][0], (tag, name)
+        if float(zlib.crc32(a.tobytes())) != crc[name][1]:
+            assert numpy.count_nonzero(a == 0.) > 0, (tag, name)

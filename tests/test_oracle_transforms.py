@@ -118,3 +118,25 @@ def test_oracle_order_is_one_fma_chain():
                     acc = numpy.float32(numpy.float64(x[0, r, c, ci])*numpy.float64(w[u, v, ci, co]) + numpy.float64(acc))
     assert got[0, i, j, co] == numpy.float32(acc + b[co])
     assert math.isfinite(float(acc))
+
+
+def test_oracle_reproduces_the_committed_transform_fixture():
+    """tests/golden/transforms_golden.npz (oracle/gen_transforms_golden.py) freezes the restatement:
+    same latents, quantised latents, reconstruction and per-layer checksums on this host as when it was generated."""
+    import os
+    import zlib
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    from oracle import transforms as T
+    with numpy.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'transforms_golden.npz')) as g:
+        for learned in (False, True):
+            v = var.random_variables(1., learned, seed=0, bias_std=0.01)
+            v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
+            tag = '{}_64x96'.format('learned' if learned else 'fixed')
+            x = g[tag + '_x']
+            (y, enc) = T.encoder(x.astype(numpy.float32)[..., None], v, learned, return_intermediates=True)
+            assert numpy.array_equal(y, g[tag + '_y'])
+            (rec, dec) = T.decoder(numpy.round(y), v, learned, return_intermediates=True)
+            assert numpy.array_equal(numpy.round(rec[..., 0].clip(min=16., max=235.)).astype(numpy.uint8), g[tag + '_rec_u8'])
+            for (name, a) in (('gdn_1', enc['gdn_1']), ('conv_3', enc['conv_3']), ('igdn_3', dec['igdn_3'])):
+                a = numpy.ascontiguousarray(a, dtype=numpy.float32)
+                assert float(zlib.crc32(a.tobytes())) == g[tag + '_sum_crc_' + name][1], (tag, name)

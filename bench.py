@@ -147,11 +147,14 @@ def run_pipeline(args, batch, steps, warmup, device, world, rank, cores, tracing
 
 
 def main():
+    global H_IN, W_IN
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
     parser.add_argument('--steps', type=int, default=100)
     parser.add_argument('--warmup', type=int, default=10)
-    parser.add_argument('--batch', type=int, default=24, help='Kodak-sized images per GPU per step')
+    parser.add_argument('--batch', type=int, default=24, help='images per GPU per step (default: the Kodak set)')
+    parser.add_argument('--height', type=int, default=H_IN, help='image height (default 512: Kodak)')
+    parser.add_argument('--width', type=int, default=W_IN, help='image width (default 768: Kodak); e.g. --height 256 --width 256 --batch 64 is one rank of BASELINE.json configs[3]')
     parser.add_argument('--no-cpu-baseline', action='store_true')
     parser.add_argument('--no-single-image', action='store_true', help='skip the one-image-per-step side measurement')
     parser.add_argument('--coder', choices=('device', 'host'), default='device',
@@ -161,6 +164,7 @@ def main():
     parser.add_argument('--coder-streams', type=int, default=int(os.environ.get('EAE_CODER_STREAMS', '2')),
                         help='batches whose entropy coding may be in flight at once (each on its own HIP stream)')
     args = parser.parse_args()
+    (H_IN, W_IN) = (args.height, args.width)
 
     # two Python threads share the GIL (kernel launches; the codec's result worker): hand it over quickly
     sys.setswitchinterval(1e-4)
@@ -213,7 +217,8 @@ def main():
         'value': round(value, 3), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed/args.steps*1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'kodak_512x768_luma_batch{}_per_gpu_bin_width_1.0_lossless_roundtrip'.format(args.batch),
+        'config': {'workload': '{0}_{1}x{2}_luma_batch{3}_per_gpu_bin_width_1.0_lossless_roundtrip'.format(
+                       'kodak' if (H_IN, W_IN) == (512, 768) else 'synthetic', H_IN, W_IN, args.batch),
                    'images_per_gpu_per_step': args.batch, 'height': H_IN, 'width': W_IN, 'bin_width_multiplier': 1.0,
                    'truncated_unary_length': TRUNCATED_UNARY_LENGTH, 'idx_map_exception': IDX_MAP_EXCEPTION,
                    'weights': 'random-init fixed-bin-width architecture (trained checkpoints absent from the reference)',
@@ -234,7 +239,7 @@ def main():
         gpu = [round(step_marks[0][1].elapsed_time(m[1]), 2) for m in step_marks]
         sys.stderr.write('TRACE host enqueue deltas (ms): {}\nTRACE gpu step deltas (ms): {}\nTRACE total ms {}\n'.format(
             [round(b - a, 1) for (a, b) in zip(host[:-1], host[1:])], [round(b - a, 1) for (a, b) in zip(gpu[:-1], gpu[1:])], round(elapsed*1e3, 2)))
-    if rank == 0 and world == 1 and args.batch != 1 and not args.no_single_image:
+    if rank == 0 and world == 1 and args.batch != 1 and not args.no_single_image and (H_IN, W_IN) == (512, 768):
         # BASELINE.json configs[1] is ONE Kodak image: the same path with one image per step (launch-bound, not the headline)
         del run, gemm_events
         one = run_pipeline(args, 1, 300, 30, device, world, rank, cores, False, variables, coder_streams=3)
@@ -298,7 +303,7 @@ def cpu_baseline(variables, probabilities, map_mean, cores):
     (t, bits, mse) = run(n_img)
     total = sum(t.values())
     return {'value': round(n_img*H_IN*W_IN/total/1e6, 4), 'unit': 'Mpixels/s', 'cores': cores, 'kind': 'port',
-            'sample': '{} synthetic 512x768 images, encode+quantise+code(enc+dec)+decode+PSNR, {:.1f} s of CPU work; transforms '
+            'sample': '{} synthetic ' + '{0}x{1}'.format(H_IN, W_IN) + ' images, encode+quantise+code(enc+dec)+decode+PSNR, {:.1f} s of CPU work; transforms '
                       'OpenMP on the {} usable CPUs, coder single-threaded like the reference'.format(n_img, total, cores),
             'seconds': {k: round(val, 3) for (k, val) in t.items()}, 'bits': int(bits), 'mse': round(mse, 4)}
 

@@ -260,6 +260,25 @@ __global__ __launch_bounds__(256) void floor_hist_kernel(const float* __restrict
     if (over) atomicAdd(&overflow[c], over);
 }
 
+// tls.rgb_to_ycbcr (tools.py:1019-1083): ITU-R BT.601 in float64, terms added left to right as numpy evaluates them, clip to
+// [0, 255], round half to even, uint8. The constants are the same IEEE doubles Python forms (65.481/255. etc.).
+__global__ void rgb_to_ycbcr_kernel(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ ycbcr, uint8_t* __restrict__ luma,
+                                    long count) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const double r = (double)rgb[3 * i], g = (double)rgb[3 * i + 1], b = (double)rgb[3 * i + 2];
+        const double y = 16. + (65.481 / 255.) * r + (128.553 / 255.) * g + (24.966 / 255.) * b;
+        const double cb = 128. - (37.797 / 255.) * r - (74.203 / 255.) * g + (112. / 255.) * b;
+        const double cr = 128. + (112. / 255.) * r - (93.786 / 255.) * g - (18.214 / 255.) * b;
+        const uint8_t y8 = (uint8_t)rint(fmin(fmax(y, 0.), 255.));
+        if (luma) luma[i] = y8;
+        if (ycbcr) {
+            ycbcr[3 * i] = y8;
+            ycbcr[3 * i + 1] = (uint8_t)rint(fmin(fmax(cb, 0.), 255.));
+            ycbcr[3 * i + 2] = (uint8_t)rint(fmin(fmax(cr, 0.), 255.));
+        }
+    }
+}
+
 extern "C" int eae_hip_map_sums(const float* y, double* sums, int64_t rows, int c, void* stream) {
     if (!y || !sums || rows <= 0 || c <= 0 || c > 256) return EAE_HIP_BAD_ARGUMENT;
     const long per_block = 256 / c;
@@ -341,6 +360,14 @@ extern "C" int eae_hip_floor_histograms(const float* y, uint32_t* hist, int radi
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(floor_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, hist, radius, overflow,
                        (long)rows, c);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}
+
+extern "C" int eae_hip_rgb_to_ycbcr(const uint8_t* rgb, uint8_t* ycbcr, uint8_t* luma, int64_t count, void* stream) {
+    if (!rgb || (!ycbcr && !luma) || count <= 0) return EAE_HIP_BAD_ARGUMENT;
+    hipLaunchKernelGGL(rgb_to_ycbcr_kernel, dim3(grid_for((long)count)), dim3(256), 0, (hipStream_t)stream, rgb, ycbcr, luma,
+                       (long)count);
     EAE_HIP_CHECK_LAUNCH();
     return EAE_HIP_OK;
 }

@@ -257,6 +257,15 @@ def cast_bt601(x):
     return out
 
 
+def rgb_to_ycbcr(rgb_uint8, want_ycbcr=True, want_luma=False):
+    """uint8 [..., 3] RGB -> (ycbcr uint8 [..., 3] or None, luma uint8 [...] or None), ITU-R BT.601 (tools.py:1019-1083)."""
+    count = rgb_uint8.numel()//3
+    ycbcr = torch.empty_like(rgb_uint8) if want_ycbcr else None
+    luma = torch.empty(rgb_uint8.shape[:-1], dtype=torch.uint8, device=rgb_uint8.device) if want_luma else None
+    _check(_native.hip().eae_hip_rgb_to_ycbcr(_p(rgb_uint8), _p(ycbcr), _p(luma), count, _stream()), 'eae_hip_rgb_to_ycbcr')
+    return ycbcr, luma
+
+
 def sse_u8(a, b):
     """Per-image sum of squared differences of two uint8 stacks [N, ...] -> int64 [N]."""
     n = a.shape[0]

@@ -257,6 +257,25 @@ def rate_from_entropies(entropies, height_map, width_map, h_in, w_in):
     return cumulated_rate/(h_in*w_in)
 
 
+def rgb_to_ycbcr(rgb_uint8):
+    """Converts the RGB image to YCbCr, ITU-R BT.601 like Matlab's `rgb2ycbcr` (tools.py:1019-1083), on the device.
+
+    Raises
+    ------
+    TypeError
+        If `rgb_uint8.dtype` is not equal to `numpy.uint8`.
+    ValueError
+        If `rgb_uint8.ndim` is not equal to 3 or `rgb_uint8.shape[2]` is not equal to 3.
+    """
+    if rgb_uint8.dtype != numpy.uint8:
+        raise TypeError('`rgb_uint8.dtype` is not equal to `numpy.uint8`.')
+    if rgb_uint8.ndim != 3:
+        raise ValueError('`rgb_uint8.ndim` is not equal to 3.')
+    if rgb_uint8.shape[2] != 3:
+        raise ValueError('`rgb_uint8.shape[2]` is not equal to 3.')
+    return bk.to_host(dev.rgb_to_ycbcr(bk.to_device(rgb_uint8))[0])
+
+
 def subdivide_set(nb_examples, batch_size):
     """Number of mini-batches in the set of examples (tools.py:1108-1132)."""
     if nb_examples % batch_size != 0:

@@ -248,6 +248,11 @@ int eae_hip_debug_set_stamp_buffer(uint64_t* device_buffer);
 /* tls.cast_bt601 (tools.py:61-93) on its own: u8 = uint8(round_half_even(clip(x, 16, 235))). */
 int eae_hip_cast_bt601(const float* x, uint8_t* out, int64_t count, void* stream);
 
+/* tls.rgb_to_ycbcr (tools.py:1019-1083; how the dataset builders turn RGB photographs into the luminance images of the
+ * path, datasets/kodak/kodak.py:70): rgb uint8 [count][3] -> ycbcr uint8 [count][3] and / or luma uint8 [count] (each
+ * nullable), ITU-R BT.601 in float64, round half to even. Exact for all 2^24 inputs (tests/test_gpu_kernels.py). */
+int eae_hip_rgb_to_ycbcr(const uint8_t* rgb, uint8_t* ycbcr, uint8_t* luma, int64_t count, void* stream);
+
 /* Squared error per image for tls.psnr_2d (tools.py:873-875): sse[i] += sum (a - b)^2 over pixels_per_image. */
 int eae_hip_sse_u8(const uint8_t* a, const uint8_t* b, uint64_t* sse, int n, int64_t pixels_per_image, void* stream);
 

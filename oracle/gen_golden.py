@@ -252,6 +252,10 @@ def tools_golden(tls, ref_compression, ref_stats, g_coder_dir):
     bd_r0 = numpy.array([0.12, 0.25, 0.48, 0.91, 1.43]); bd_p0 = numpy.array([27.1, 29.8, 32.6, 35.9, 38.2])
     bd_r1 = numpy.array([0.10, 0.22, 0.41, 0.80, 1.31, 1.9]); bd_p1 = numpy.array([27.4, 30.1, 32.7, 36.0, 38.6, 40.3])
     g.update(bd_r0=bd_r0, bd_p0=bd_p0, bd_r1=bd_r1, bd_p1=bd_p1, bd_out=numpy.float64(tls.compute_bjontegaard(bd_r0, bd_p0, bd_r1, bd_p1)))
+    # rgb_to_ycbcr (tools.py:1019-1083) on a random picture plus the corners of the RGB cube
+    rgb = numpy.random.RandomState(33).randint(0, 256, size=(24, 32, 3)).astype(numpy.uint8)
+    rgb[0, :8] = [[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [0, 255, 255], [255, 0, 255]]
+    g.update(rgb_in=rgb, rgb_out=tls.rgb_to_ycbcr(rgb))
     numpy.savez_compressed(os.path.join(OUT, 'tools_golden.npz'), **g)
     print('tools_golden.npz: rate', g['lat_rate'], 'bits', g['lossless_bits'], 'psnr', g['psnr_known'], 'idx exception', g['stats_idx'])
 

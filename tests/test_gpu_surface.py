@@ -286,3 +286,24 @@ def test_save_statistics_writes_the_three_kinds_of_files(tmp_path, capsys):
         ae.initialization(sess, '', seed=3)
         stats.save_statistics(x, sess, ae, 2, multipliers, 10, path_mean, path_idx, paths)
     assert 'already exist' in capsys.readouterr().out
+
+
+def test_rgb_to_ycbcr_all_colours(gold, tls):
+    """tools.py:1019-1083 on the device: equal to the reference's own function on the committed picture, and to its float64
+    expression for every one of the 2^24 RGB triples."""
+    assert numpy.array_equal(tls.rgb_to_ycbcr(gold['rgb_in']), gold['rgb_out'])
+    with pytest.raises(TypeError):
+        tls.rgb_to_ycbcr(gold['rgb_in'].astype(numpy.float32))
+    with pytest.raises(ValueError):
+        tls.rgb_to_ycbcr(gold['rgb_in'][:, :, :2])
+    with pytest.raises(ValueError):
+        tls.rgb_to_ycbcr(gold['rgb_in'][0])
+    levels = numpy.arange(256, dtype=numpy.uint8)
+    cube = numpy.stack(numpy.meshgrid(levels, levels, levels, indexing='ij'), axis=3).reshape(4096, 4096, 3)
+    got = tls.rgb_to_ycbcr(cube)
+    f = cube.astype(numpy.float64)
+    y = 16. + (65.481/255.)*f[:, :, 0] + (128.553/255.)*f[:, :, 1] + (24.966/255.)*f[:, :, 2]
+    cb = 128. - (37.797/255.)*f[:, :, 0] - (74.203/255.)*f[:, :, 1] + (112./255.)*f[:, :, 2]
+    cr = 128. + (112./255.)*f[:, :, 0] - (93.786/255.)*f[:, :, 1] - (18.214/255.)*f[:, :, 2]
+    expected = numpy.round(numpy.stack((y, cb, cr), axis=2).clip(min=0., max=255.)).astype(numpy.uint8)
+    assert numpy.array_equal(got, expected)

@@ -5,7 +5,7 @@ coder from oracle/_ref, numpy for the rest). Writes profiles/r01_rate_psnr_curve
 test script, not product code."""
 import json, os, sys, time
 import numpy, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # profiles/ -> repo root
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 from autoencoder_based_image_compression_amd import codec, device as dev, pipeline

@@ -27,7 +27,6 @@ import torch
 from . import device as dev
 from . import pipeline
 from .kodak.eae.graph import constants as csts
-from .kodak.eae.graph import variables as var
 from .kodak.lossless import compression as lossless_compression
 
 # HIP multiplexes streams onto 4 hardware queues: side streams are shared by every codec of the process so that a coder

@@ -3,8 +3,8 @@
 `fix_gamma` :31-243 and `vary_gamma_fix_bin_widths` :401-556 with the reference's arguments, written against exactly
 the calls the reference makes (`EntropyAutoencoder`, `IsolatedDecoder`, `tf.Session`, `eae.batching.*`, `tls.*`,
 `lossless.compression.rescale_compress_lossless_maps`), so it doubles as the proof that the reference's own script
-drops onto this package. Out of scope here: PNG dumps, plots, JPEG2000 / HEVC baselines and
-Bjontegaard metrics of the reference's `__main__` (SURVEY.md 8(f) "next").
+drops onto this package. With `path_to_checking_r` the reconstructions and their crops are written as PNG
+like the reference does (:227-232). Out of scope here: matplotlib plots, JPEG2000 / HEVC baselines of the reference's `__main__`.
 """
 import os
 import pickle
@@ -83,6 +83,15 @@ def fix_gamma(reference_uint8, bin_width_init, multipliers, idx_training, gamma_
                 else:
                     rate[i, j] = tls.rate_3d(centered_quantized_y_float32[j, :, :, :], bin_widths_test, h_in, w_in)
                 psnr[i, j] = tls.psnr_2d(reference_uint8[j, :, :], reconstruction_uint8[j, :, :])
+                if path_to_checking_r is not None:
+                    # the reference's PNG dumps (:227-232): the reconstruction, rotated for the portrait images, and its crops
+                    path_to_storage = os.path.join(path_to_checking_r, 'reconstruction_fix_gamma', suffix,
+                                                   'lossless' if is_lossless else 'approx', 'multiplier_{}'.format(str_multiplier))
+                    os.makedirs(path_to_storage, exist_ok=True)
+                    paths = [os.path.join(path_to_storage, 'reconstruction_{}.png'.format(j))]
+                    paths += [os.path.join(path_to_storage, 'reconstruction_{0}_crop_{1}.png'.format(j, index_crop))
+                              for index_crop in range(positions_top_left.shape[1])]
+                    tls.visualize_rotated_luminance(reconstruction_uint8[j, :, :], j in list_rotation, positions_top_left, paths)
     tf.reset_default_graph()
     if return_nb_deads:
         return (rate, psnr, array_nb_deads)

@@ -143,6 +143,27 @@ def _entropy_from_hist(hist):
     return disc_entropy
 
 
+def crop_repeat_2d(image_uint8, row_top_left, column_top_left):
+    """80x80 crop with every pixel repeated 2x2 -> uint8 160x160 (tools.py:434-484). Host-side harness helper.
+
+    Raises
+    ------
+    TypeError
+        If `image_uint8.dtype` is not equal to `numpy.uint8`.
+    ValueError
+        If the image is not strictly larger than the crop's bottom / right edge (or is not 2D).
+    """
+    if image_uint8.dtype != numpy.uint8:
+        raise TypeError('`image_uint8.dtype` is not equal to `numpy.uint8`.')
+    (height_image, width_image) = image_uint8.shape
+    for (start, extent, axis) in ((row_top_left, height_image, 0), (column_top_left, width_image, 1)):
+        if start + 80 >= extent:
+            raise ValueError('`image_uint8.shape[{0}]` is not strictly larger than `{1}_top_left + 80`.'.format(
+                axis, 'row' if axis == 0 else 'column'))
+    return numpy.kron(image_uint8[row_top_left:row_top_left + 80, column_top_left:column_top_left + 80],
+                      numpy.ones((2, 2), dtype=numpy.uint8))
+
+
 def discrete_entropy(quantized_samples, bin_width):
     """Entropy of the quantized samples (tools.py:486-537)."""
     return _entropy_from_hist(count_symbols(quantized_samples, bin_width))
@@ -276,8 +297,47 @@ def rgb_to_ycbcr(rgb_uint8):
     return bk.to_host(dev.rgb_to_ycbcr(bk.to_device(rgb_uint8))[0])
 
 
+def save_image(path, array_uint8):
+    """Saves the array as an image (tools.py:1082-1106).
+
+    Raises
+    ------
+    TypeError
+        If `array_uint8.dtype` is not equal to `numpy.uint8`.
+    """
+    if array_uint8.dtype != numpy.uint8:
+        raise TypeError('`array_uint8.dtype` is not equal to `numpy.uint8`.')
+    import PIL.Image
+    PIL.Image.fromarray(array_uint8).save(path)
+
+
 def subdivide_set(nb_examples, batch_size):
     """Number of mini-batches in the set of examples (tools.py:1108-1132)."""
     if nb_examples % batch_size != 0:
         raise ValueError('`nb_examples` is not divisible by `batch_size`.')
     return nb_examples//batch_size
+
+
+def visualize_crops(image_uint8, positions_top_left, paths):
+    """Saves one 160x160 `crop_repeat_2d` per column of `positions_top_left` (int32 (2, nb_crops)) (tools.py:1172-1218).
+
+    Raises
+    ------
+    ValueError
+        If `positions_top_left.shape[0]` is not equal to 2 or `len(paths)` is not the number of crops.
+    """
+    (nb_rows, nb_crops) = positions_top_left.shape
+    if nb_rows != 2:
+        raise ValueError('`positions_top_left.shape[0]` is not equal to 2.')
+    if len(paths) != nb_crops:
+        raise ValueError('`len(paths)` is not equal to `positions_top_left.shape[1]`.')
+    for (path, (row, column)) in zip(paths, positions_top_left.T.tolist()):
+        save_image(path, crop_repeat_2d(image_uint8, row, column))
+
+
+def visualize_rotated_luminance(luminance_before_rotation_uint8, is_rotated, positions_top_left, paths):
+    """Saves the luminance image, rotated by three quarter turns if required, to `paths[0]` and its crops to `paths[1:]`
+    (tools.py:1292-1330)."""
+    image_uint8 = numpy.rot90(luminance_before_rotation_uint8, k=3).copy() if is_rotated else luminance_before_rotation_uint8.copy()
+    visualize_crops(image_uint8, positions_top_left, paths[1:])
+    save_image(paths[0], image_uint8)

@@ -235,3 +235,32 @@ def test_compute_bjontegaard_against_the_reference():
         tls.compute_bjontegaard(r0, p0[:-1], r1, p1)
     with pytest.raises(AssertionError):
         tls.compute_bjontegaard(-r0, p0, r1, p1)
+
+
+def test_png_dump_helpers(tmp_path):
+    """crop_repeat_2d / visualize_crops / visualize_rotated_luminance / save_image (tools.py:434-484, 1172-1218, 1292-1330,
+    1082-1106): host-side harness helpers, same outputs and exceptions."""
+    import PIL.Image
+    from autoencoder_based_image_compression_amd.kodak.tools import tools as tls
+    image = numpy.random.RandomState(0).randint(0, 256, size=(100, 130)).astype(numpy.uint8)
+    crop = tls.crop_repeat_2d(image, 3, 7)
+    assert crop.shape == (160, 160) and crop.dtype == numpy.uint8
+    assert numpy.array_equal(crop, numpy.repeat(numpy.repeat(image[3:83, 7:87], 2, axis=0), 2, axis=1))
+    with pytest.raises(TypeError):
+        tls.crop_repeat_2d(image.astype(numpy.float32), 0, 0)
+    with pytest.raises(ValueError):
+        tls.crop_repeat_2d(image, 20, 0)          # 20 + 80 >= 100
+    with pytest.raises(ValueError):
+        tls.crop_repeat_2d(image, 0, 50)          # 50 + 80 >= 130
+    positions = numpy.array([[0, 10], [5, 15]], dtype=numpy.int32)
+    paths = [str(tmp_path/name) for name in ('full.png', 'crop_0.png', 'crop_1.png')]
+    tls.visualize_rotated_luminance(image, True, positions, paths)
+    rotated = numpy.rot90(image, k=3)
+    assert numpy.array_equal(numpy.asarray(PIL.Image.open(paths[0])), rotated)
+    assert numpy.array_equal(numpy.asarray(PIL.Image.open(paths[2])), tls.crop_repeat_2d(rotated.copy(), 10, 15))
+    with pytest.raises(ValueError):
+        tls.visualize_crops(image, positions[:1], paths[1:])
+    with pytest.raises(ValueError):
+        tls.visualize_crops(image, positions, paths[:1])
+    with pytest.raises(TypeError):
+        tls.save_image(paths[0], image.astype(numpy.int32))

@@ -307,3 +307,26 @@ def test_rgb_to_ycbcr_all_colours(gold, tls):
     cr = 128. + (112./255.)*f[:, :, 0] - (93.786/255.)*f[:, :, 1] - (18.214/255.)*f[:, :, 2]
     expected = numpy.round(numpy.stack((y, cb, cr), axis=2).clip(min=0., max=255.)).astype(numpy.uint8)
     assert numpy.array_equal(got, expected)
+
+
+def test_fix_gamma_writes_the_png_dumps(tmp_path, tls, cgold):
+    """reconstructing_eae_kodak.py:204-232: with `path_to_checking_r` the reconstruction of every image (rotated for the
+    indices in `list_rotation`) and its crops are saved under reconstruction_fix_gamma/<suffix>/<approx|lossless>/multiplier_<m>/."""
+    import PIL.Image
+    from autoencoder_based_image_compression_amd.kodak import reconstructing_eae_kodak as rk
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    v = var.random_variables(1., False, seed=3, bias_std=0.01)
+    v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
+    x = numpy.random.RandomState(2).randint(16, 236, size=(2, 96, 112)).astype(numpy.uint8)
+    multipliers = numpy.array([1.], dtype=numpy.float32)
+    _write_model(str(tmp_path), '1_10000', 10, v, numpy.zeros(128, dtype=numpy.float32), 67, cgold['real_probabilities_1'], multipliers, tls)
+    positions = numpy.array([[2], [9]], dtype=numpy.int32)
+    out = str(tmp_path/'checking')
+    rk.fix_gamma(x, 1., multipliers, 10, 10000., 2, False, False, path_to_checking_r=out, list_rotation=[1],
+                 positions_top_left=positions, root=str(tmp_path))
+    folder = os.path.join(out, 'reconstruction_fix_gamma', '1_10000', 'approx', 'multiplier_1')
+    assert sorted(os.listdir(folder)) == ['reconstruction_0.png', 'reconstruction_0_crop_0.png', 'reconstruction_1.png',
+                                          'reconstruction_1_crop_0.png']
+    assert numpy.asarray(PIL.Image.open(os.path.join(folder, 'reconstruction_0.png'))).shape == (96, 112)
+    assert numpy.asarray(PIL.Image.open(os.path.join(folder, 'reconstruction_1.png'))).shape == (112, 96)      # rotated
+    assert numpy.asarray(PIL.Image.open(os.path.join(folder, 'reconstruction_1_crop_0.png'))).shape == (160, 160)

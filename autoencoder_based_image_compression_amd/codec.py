@@ -32,7 +32,6 @@ from .kodak.lossless import compression as lossless_compression
 # HIP multiplexes streams onto 4 hardware queues: side streams are shared by every codec of the process so that a coder
 # stream never ends up on the hardware queue of the stream the transforms run on.
 _SIDE_STREAMS = []
-_HIST_RADIUS = 255
 
 
 def _side_streams(count):
@@ -119,10 +118,13 @@ class BatchCodec(object):
 
     def __init__(self, variables, are_bin_widths_learned, bin_widths_test, map_mean, binary_probabilities, idx_map_exception,
                  batch_size, h_in, w_in, device='cuda', nb_in_flight=2, keep_reconstruction=False, launch_hook=None,
-                 coder='device', host_coder_threads=0):
+                 coder='device', host_coder_threads=0, hist_radius=2047):
         """coder: 'device' (the coder kernels on side streams), 'host' (ONE device -> host copy of the symbols per batch, then
         the host C-ABI coder `eae_coder_compress_maps` on `host_coder_threads` threads: the shape BASELINE.json sketches) or
-        'none' (transforms only; the bit counts come back as zeros)."""
+        'none' (transforms only; the bit counts come back as zeros).
+        hist_radius: the exception map's entropy is formed from an exact histogram of its symbols over [-hist_radius,
+        hist_radius]; a symbol outside it makes `Ticket.result()` raise (the image-by-image functions of `kodak/` widen the
+        histogram instead)."""
         if coder not in ('device', 'host', 'none'):
             raise ValueError('`coder` is neither "device" nor "host" nor "none".')
         if h_in % csts.STRIDE_PROD != 0 or w_in % csts.STRIDE_PROD != 0:
@@ -150,6 +152,7 @@ class BatchCodec(object):
             prob_row[self.idx_map_exception::self.nb_maps] = -1        # costed from its histogram (compression.py:68-75)
         self.prob_row = prob_row.to(self.device)
         self.keep_reconstruction = keep_reconstruction
+        self.hist_radius = int(hist_radius)
         self.coder = coder
         self.launch_hook = launch_hook if launch_hook is not None else (lambda name, fn: fn())
         n_maps = batch_size*self.nb_maps
@@ -157,7 +160,7 @@ class BatchCodec(object):
         self._n_maps = n_maps
         # per-slot device block for the host: [coder results 4 x n_maps | exception histograms | overflow | flags | checks(4)]
         # followed by the squared errors (int64 per image, published on their own once the synthesis transform is through)
-        self._layout = (4*n_maps, nb_hist*(2*_HIST_RADIUS + 1), nb_hist, n_maps, 4)
+        self._layout = (4*n_maps, nb_hist*(2*self.hist_radius + 1), nb_hist, n_maps, 4)
         nb_words = sum(self._layout)
         assert nb_words % 2 == 0
         self.nb_slots = nb_in_flight + 2
@@ -191,7 +194,7 @@ class BatchCodec(object):
             pos += count
         (results, hist, overflow, flags, checks) = out
         nb_hist = overflow.numel()
-        return (results.view(4, self._n_maps), hist.view(nb_hist, 2*_HIST_RADIUS + 1) if nb_hist else hist, overflow,
+        return (results.view(4, self._n_maps), hist.view(nb_hist, 2*self.hist_radius + 1) if nb_hist else hist, overflow,
                 flags.view(self.batch_size, self.nb_maps), checks)
 
     def submit(self, luminances_uint8):
@@ -222,7 +225,7 @@ class BatchCodec(object):
                              out_flags=flags, out_checks=checks[:3])
         symbols = self._symbols[slot].view(self._n_maps, self.map_size)
         if self.idx_map_exception >= 0:
-            dev.symbol_histograms(symbols, _HIST_RADIUS, out=(hist, overflow), first_map=self.idx_map_exception,
+            dev.symbol_histograms(symbols, self.hist_radius, out=(hist, overflow), first_map=self.idx_map_exception,
                                   map_step=self.nb_maps, zero=False)
         quantized = torch.cuda.Event()
         quantized.record()

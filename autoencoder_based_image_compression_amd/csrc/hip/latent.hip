@@ -9,10 +9,14 @@
 // Arithmetic, operation by operation, is that of gdn.hip and quantize.hip (same helpers), so the results are the same bits.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
-// 64 positions per block (2 waves x 32 positions x 128 channels): 50 KB of LDS, three blocks per CU. Measured at Kodak batch
-// 24 (36,864 positions): 131 us, against 188 us for 128-position blocks and 162 us for 32 positions with one channel tile
-// per wave; the three separate kernels take 25 + 75 + 45 us plus two launch gaps.
+// Block-cooperative form (EAE_HIP_LATENT_LDS=1, kept for comparison): 64 positions per block (2 waves x 32 positions x 128
+// channels) in 50 KB of LDS. Measured at Kodak batch 24 (36,864 positions): 127-131 us in the bench, against 188 us for
+// 128-position blocks and 162 us for 32 positions with one channel tile per wave; the register-resident wave form below
+// (the default) takes 121 us; the three separate kernels 25 + 75 + 45 us plus two launch gaps. With about one wave per SIMD
+// every form is bound by exposed latencies (the gamma rows come from L2 behind an 8-deep ring), not by MFMA or HBM rates.
 constexpr int WAVES = 2;
 constexpr int TM = WAVES * 32;
 constexpr int SYM_STRIDE = TM + 2;
@@ -38,6 +42,11 @@ __global__ __launch_bounds__(WAVES * 64) void latent_kernel(const float* __restr
     }
     __syncthreads();
     const int col0 = lane & 31;
+    // image and pixel of a row of this tile without a division per element: one division per block when the tile spans at
+    // most two images (hw >= TM), the general formula otherwise
+    const long img0 = row0 / hw;
+    const int pix0 = (int)(row0 - img0 * hw);
+    const bool simple = hw >= TM;
     f32x16 d[4];
     if (GDN_IN) {
         gdn_denominator<4>(Xs, wm, lane, gamma_in, 0, d);
@@ -68,7 +77,10 @@ __global__ __launch_bounds__(WAVES * 64) void latent_kernel(const float* __restr
                 if (!((float)(int16_t)(int)rs * bw == centered)) altered++;
                 if (y_out) y_out[(size_t)row * EAE_C + c] = yv;
                 if (shifted_out) shifted_out[(size_t)row * EAE_C + c] = shifted;
-                if (cq != 0.f && nonzero) nonzero[(row / hw) * EAE_C + c] = 1u;     // benign race: every writer stores 1
+                if (cq != 0.f && nonzero) {
+                    const long img = simple ? img0 + (pix0 + mrow >= hw ? 1 : 0) : row / hw;
+                    nonzero[img * EAE_C + c] = 1u;                               // benign race: every writer stores 1
+                }
             }
             Xs[mrow * EAE_XS_STRIDE + c] = shifted;
             Sy[c * SYM_STRIDE + mrow] = (int16_t)(int)rs;
@@ -85,7 +97,12 @@ __global__ __launch_bounds__(WAVES * 64) void latent_kernel(const float* __restr
         for (int i = tid; i < EAE_C * TM; i += WAVES * 64) {
             const int ch = i / TM, px = i % TM;
             const long row = row0 + px;
-            if (row < rows) symbols[((size_t)(row / hw) * EAE_C + ch) * hw + (row % hw)] = Sy[ch * SYM_STRIDE + px];
+            if (row < rows) {
+                const bool next = pix0 + px >= hw;
+                const long img = simple ? img0 + (next ? 1 : 0) : row / hw;
+                const int pix = simple ? pix0 + px - (next ? hw : 0) : (int)(row % hw);
+                symbols[((size_t)img * EAE_C + ch) * hw + pix] = Sy[ch * SYM_STRIDE + px];
+            }
         }
     }
     if (IGDN_OUT) {
@@ -103,6 +120,151 @@ __global__ __launch_bounds__(WAVES * 64) void latent_kernel(const float* __restr
         }
     }
 }
+
+// ---- one wavefront per 32 positions, everything in registers ---------------------------------------------------------------
+// The layout is the one the conv GEMM epilogue uses (common.h wave_epilogue): lane (hi = lane >> 5, lj = lane & 31) holds, for
+// position lj, the 64 channels 32 t + 8 g + 4 hi + q in x[t][4 g + q]. x^2 goes from those registers straight into the MFMA
+// (B operand) through one v_permlane32_swap per register pair, gamma rows (packed channel order) stream through a register
+// ring as the A operand: no LDS tile, no barrier, and the same k-ascending FMA chain per element as gdn_denominator.
+template <bool INVERSE>
+__device__ __forceinline__ void wave_gdn_inplace(f32x16 (&x)[4], const float* beta_lds, const float* __restrict__ gamma_packed,
+                                                 int lane) {
+    constexpr int RING = 8;
+    const int hi = lane >> 5, lj = lane & 31;
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(gamma_packed), 0, (int)(EAE_C * EAE_C * sizeof(float)), 0x00020000);
+    const int g_lane = (hi * EAE_C + lj * 4) * 4;
+    f32x16 d[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[t][r] = 0.f;
+    float4 ring[RING];
+#define EAE_L_LOAD(dst_, kk_)                                                                                            \
+    {                                                                                                                    \
+        const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_lane + (kk_) * 2 * EAE_C * 4, 0, 0);            \
+        dst_ = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w));  \
+    }
+#pragma unroll
+    for (int i = 0; i < RING; ++i) EAE_L_LOAD(ring[i], i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float s0 = x[t][4 * g + 0], s1 = x[t][4 * g + 1], s2 = x[t][4 * g + 2], s3 = x[t][4 * g + 3];
+            swap_halves(s0, s1);     // s0 = channels (8g+0 | 8g+1), s1 = (8g+4 | 8g+5) in the (low | high) half-waves
+            swap_halves(s2, s3);     // s2 = (8g+2 | 8g+3), s3 = (8g+6 | 8g+7)
+            const float xs[4] = {s0, s2, s1, s3};            // k pairs in ascending order
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = 16 * t + 4 * g + e;            // k = 2 kk + hi
+                const float x2 = xs[e] * xs[e];
+                const float4 gq = ring[kk % RING];
+                d[0] = mfma32(gq.x, x2, d[0]);
+                d[1] = mfma32(gq.y, x2, d[1]);
+                d[2] = mfma32(gq.z, x2, d[2]);
+                d[3] = mfma32(gq.w, x2, d[3]);
+                if (kk + RING < EAE_C / 2) { EAE_L_LOAD(ring[kk % RING], kk + RING) }
+            }
+        }
+    }
+#undef EAE_L_LOAD
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bt = *reinterpret_cast<const float4*>(beta_lds + 32 * t + 8 * g + 4 * hi);
+            x[t][4 * g + 0] = gdn_apply(x[t][4 * g + 0], d[t][4 * g + 0], bt.x, INVERSE);
+            x[t][4 * g + 1] = gdn_apply(x[t][4 * g + 1], d[t][4 * g + 1], bt.y, INVERSE);
+            x[t][4 * g + 2] = gdn_apply(x[t][4 * g + 2], d[t][4 * g + 2], bt.z, INVERSE);
+            x[t][4 * g + 3] = gdn_apply(x[t][4 * g + 3], d[t][4 * g + 3], bt.w, INVERSE);
+        }
+}
+
+template <bool GDN_IN, bool IGDN_OUT>
+__global__ __launch_bounds__(64) void latent_wave_kernel(const float* __restrict__ x, const float* __restrict__ gamma_in,
+                                                         const float* __restrict__ beta_in, const float* __restrict__ map_mean,
+                                                         const float* __restrict__ bin_widths, const float* __restrict__ gamma_out,
+                                                         const float* __restrict__ beta_out, float* __restrict__ y_out,
+                                                         float* __restrict__ shifted_out, float* __restrict__ t_out,
+                                                         int16_t* __restrict__ symbols, unsigned int* __restrict__ nonzero,
+                                                         unsigned int* __restrict__ checks, long rows, int hw) {
+    __shared__ __attribute__((aligned(16))) float vec[4 * EAE_C];      // beta_in | beta_out | map_mean | bin_widths
+    const int lane = threadIdx.x, hi = lane >> 5, lj = lane & 31;
+    {
+        const float2 z = make_float2(0.f, 0.f);
+        *reinterpret_cast<float2*>(vec + 2 * lane) = GDN_IN ? *reinterpret_cast<const float2*>(beta_in + 2 * lane) : z;
+        *reinterpret_cast<float2*>(vec + EAE_C + 2 * lane) = IGDN_OUT ? *reinterpret_cast<const float2*>(beta_out + 2 * lane) : z;
+        *reinterpret_cast<float2*>(vec + 2 * EAE_C + 2 * lane) = map_mean ? *reinterpret_cast<const float2*>(map_mean + 2 * lane) : z;
+        *reinterpret_cast<float2*>(vec + 3 * EAE_C + 2 * lane) = *reinterpret_cast<const float2*>(bin_widths + 2 * lane);
+    }
+    const long row = (long)blockIdx.x * 32 + lj;
+    const bool valid = row < rows;
+    const long img = row / hw;
+    const int pix = (int)(row - img * hw);
+    const float* xrow = x + (size_t)(valid ? row : 0) * EAE_C + 4 * hi;
+    f32x16 v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 q = valid ? *reinterpret_cast<const float4*>(xrow + 32 * t + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[t][4 * g + 0] = q.x; v[t][4 * g + 1] = q.y; v[t][4 * g + 2] = q.z; v[t][4 * g + 3] = q.w;
+        }
+    __syncthreads();
+    if (GDN_IN) wave_gdn_inplace<false>(v, vec, gamma_in, lane);
+    unsigned int bad = 0, not_quantized = 0, altered = 0;
+    const size_t obase = (size_t)(valid ? row : 0) * EAE_C + 4 * hi;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 32 * t + 8 * g + 4 * hi;
+            const float4 m4 = *reinterpret_cast<const float4*>(vec + 2 * EAE_C + c0);
+            const float4 b4 = *reinterpret_cast<const float4*>(vec + 3 * EAE_C + c0);
+            const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, bw[4] = {b4.x, b4.y, b4.z, b4.w};
+            float sh[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float yv = v[t][4 * g + q];
+                // quantize.hip, statement for statement
+                const float centered = yv - mm[q];
+                const float rr = round_half_even(centered / bw[q]);
+                const float cq = bw[q] * rr;
+                const float rs = round_half_even(cq / bw[q]);
+                sh[q] = cq + mm[q];
+                if (valid) {
+                    if (!(fabsf(rs) < 32768.f)) bad++;
+                    if (!(fabs((double)cq - (double)centered) < 1.5e-10)) not_quantized++;
+                    if (!((float)(int16_t)(int)rs * bw[q] == centered)) altered++;
+                    if (cq != 0.f && nonzero) nonzero[img * EAE_C + c0 + q] = 1u;      // benign race: every writer stores 1
+                    // planar symbols: the 32 lanes of a half-wave write 32 consecutive pixels of one map
+                    if (symbols) symbols[((size_t)img * EAE_C + c0 + q) * hw + pix] = (int16_t)(int)rs;
+                }
+            }
+            if (valid && y_out)
+                *reinterpret_cast<float4*>(y_out + obase + 32 * t + 8 * g) =
+                    make_float4(v[t][4 * g], v[t][4 * g + 1], v[t][4 * g + 2], v[t][4 * g + 3]);
+            if (valid && shifted_out) *reinterpret_cast<float4*>(shifted_out + obase + 32 * t + 8 * g) = make_float4(sh[0], sh[1], sh[2], sh[3]);
+            v[t][4 * g + 0] = sh[0]; v[t][4 * g + 1] = sh[1]; v[t][4 * g + 2] = sh[2]; v[t][4 * g + 3] = sh[3];
+        }
+    if (checks) {
+        if (bad) atomicAdd(&checks[0], bad);
+        if (not_quantized) atomicAdd(&checks[1], not_quantized);
+        if (altered) atomicAdd(&checks[2], altered);
+    }
+    if (IGDN_OUT) {
+        wave_gdn_inplace<true>(v, vec + EAE_C, gamma_out, lane);
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(t_out + obase + 32 * t + 8 * g) =
+                        make_float4(v[t][4 * g], v[t][4 * g + 1], v[t][4 * g + 2], v[t][4 * g + 3]);
+        }
+    }
+}
 }  // namespace
 
 extern "C" int eae_hip_latent_stage(const float* x, const float* gamma_in_packed, const float* beta_in, const float* map_mean,
@@ -113,8 +275,22 @@ extern "C" int eae_hip_latent_stage(const float* x, const float* gamma_in_packed
     if ((gamma_in_packed == nullptr) != (beta_in == nullptr)) return EAE_HIP_BAD_ARGUMENT;
     if ((gamma_out_packed == nullptr) != (beta_out == nullptr) || (gamma_out_packed && !t_out)) return EAE_HIP_BAD_ARGUMENT;
     const long rows = (long)n * hw;
-    const unsigned grid = (unsigned)((rows + TM - 1) / TM);
     hipStream_t s = (hipStream_t)stream;
+    static const bool lds_form = std::getenv("EAE_HIP_LATENT_LDS") != nullptr;      // the block-cooperative form, for comparison
+    if (!lds_form) {
+        const unsigned wgrid = (unsigned)((rows + 31) / 32);
+#define EAE_LATENT_W(A_, B_)                                                                                              \
+        hipLaunchKernelGGL((latent_wave_kernel<A_, B_>), dim3(wgrid), dim3(64), 0, s, x, gamma_in_packed, beta_in, map_mean,  \
+                           bin_widths, gamma_out_packed, beta_out, y_out, shifted_out, t_out, symbols_planar, nonzero_flags, checks, rows, hw)
+        if (gamma_in_packed && gamma_out_packed) EAE_LATENT_W(true, true);
+        else if (gamma_in_packed) EAE_LATENT_W(true, false);
+        else if (gamma_out_packed) EAE_LATENT_W(false, true);
+        else EAE_LATENT_W(false, false);
+#undef EAE_LATENT_W
+        EAE_HIP_CHECK_LAUNCH();
+        return EAE_HIP_OK;
+    }
+    const unsigned grid = (unsigned)((rows + TM - 1) / TM);
 #define EAE_LATENT(A_, B_)                                                                                               \
     hipLaunchKernelGGL((latent_kernel<A_, B_>), dim3(grid), dim3(WAVES * 64), 0, s, x, gamma_in_packed, beta_in, map_mean, bin_widths, \
                        gamma_out_packed, beta_out, y_out, shifted_out, t_out, symbols_planar, nonzero_flags, checks, rows, hw)

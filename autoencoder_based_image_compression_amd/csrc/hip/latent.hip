@@ -11,6 +11,10 @@
 
 #include <cstdlib>
 
+#ifndef EAE_LATENT_RING
+#define EAE_LATENT_RING 8
+#endif
+
 namespace {
 // Block-cooperative form (EAE_HIP_LATENT_LDS=1, kept for comparison): 64 positions per block (2 waves x 32 positions x 128
 // channels) in 50 KB of LDS. Measured at Kodak batch 24 (36,864 positions): 127-131 us in the bench, against 188 us for
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(WAVES * 64) void latent_kernel(const float* __restr
 template <bool INVERSE>
 __device__ __forceinline__ void wave_gdn_inplace(f32x16 (&x)[4], const float* beta_lds, const float* __restrict__ gamma_packed,
                                                  int lane) {
-    constexpr int RING = 8;
+    constexpr int RING = EAE_LATENT_RING;
     const int hi = lane >> 5, lj = lane & 31;
     const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(gamma_packed), 0, (int)(EAE_C * EAE_C * sizeof(float)), 0x00020000);

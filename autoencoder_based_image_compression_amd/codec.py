@@ -118,10 +118,12 @@ class BatchCodec(object):
 
     def __init__(self, variables, are_bin_widths_learned, bin_widths_test, map_mean, binary_probabilities, idx_map_exception,
                  batch_size, h_in, w_in, device='cuda', nb_in_flight=2, keep_reconstruction=False, launch_hook=None,
-                 coder='device', host_coder_threads=0, hist_radius=2047):
+                 coder='device', host_coder_threads=0, hist_radius=2047, nb_transform_streams=1):
         """coder: 'device' (the coder kernels on side streams), 'host' (ONE device -> host copy of the symbols per batch, then
         the host C-ABI coder `eae_coder_compress_maps` on `host_coder_threads` threads: the shape BASELINE.json sketches) or
         'none' (transforms only; the bit counts come back as zeros).
+        nb_transform_streams: 1 = the transforms run on the caller's current stream; more = consecutive batches alternate
+        between that many private streams (worth it only for small batches, whose kernels leave most of the GPU idle).
         hist_radius: the exception map's entropy is formed from an exact histogram of its symbols over [-hist_radius,
         hist_radius]; a symbol outside it makes `Ticket.result()` raise (the image-by-image functions of `kodak/` widen the
         histogram instead)."""
@@ -165,6 +167,7 @@ class BatchCodec(object):
         assert nb_words % 2 == 0
         self.nb_slots = nb_in_flight + 2
         self._streams = _side_streams(nb_in_flight)
+        self._transform_streams = _side_streams(nb_in_flight + nb_transform_streams)[nb_in_flight:] if nb_transform_streams > 1 else []
         self._slot_all = [torch.zeros(nb_words + 2*batch_size, dtype=torch.int32, device=self.device) for _ in range(self.nb_slots)]
         self._slot_out = [t[:nb_words] for t in self._slot_all]
         self._pinned_out = [torch.zeros(nb_words, dtype=torch.int32).pin_memory() for _ in range(self.nb_slots)]
@@ -204,6 +207,18 @@ class BatchCodec(object):
             raise TypeError('`luminances_uint8.dtype` is not equal to `torch.uint8`.')
         if tuple(luminances_uint8.shape) != (self.batch_size, self.h_in, self.w_in):
             raise ValueError('`luminances_uint8.shape` is not (batch_size, h_in, w_in).')
+        if not self._transform_streams:
+            return self._submit(luminances_uint8)
+        # small batches leave most of the GPU idle and a step is a chain of short dependent kernels: consecutive batches go
+        # to different streams so that their chains overlap
+        stream = self._transform_streams[self._index % len(self._transform_streams)]
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            ticket = self._submit(luminances_uint8)
+        luminances_uint8.record_stream(stream)
+        return ticket
+
+    def _submit(self, luminances_uint8):
         hook = self.launch_hook
         (enc, dec) = (self.encoder, self.decoder)
         (v, d) = (enc.v, dec.v)

@@ -20,7 +20,13 @@ def _check(status, what):
         raise HipError('{0} failed with status {1}'.format(what, status))
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (every launch of this module goes there)."""
+    if _raw_stream is not None:                      # one C call instead of building a torch.cuda.Stream object per launch
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -69,7 +69,8 @@ def synthetic_model(bin_width=1.):
     return v
 
 
-def run_pipeline(args, batch, steps, warmup, device, world, rank, cores, tracing, variables, coder_streams=None):
+def run_pipeline(args, batch, steps, warmup, device, world, rank, cores, tracing, variables, coder_streams=None,
+                 transform_streams=1):
     """Builds the resident state for `batch` images per step (codec.BatchCodec: weights, tables, per-slot buffers), runs
     `warmup` untimed and `steps` timed steps, and returns what the report needs. Everything in here up to the first barrier
     is outside the timed region."""
@@ -101,7 +102,8 @@ def run_pipeline(args, batch, steps, warmup, device, world, rank, cores, tracing
     coder_threads = args.coder_threads if args.coder_threads > 0 else max(1, cores//max(world, 1) - 2)
     the_codec = codec.BatchCodec(variables, False, variables[var.BIN_WIDTHS_NAME], map_mean_host, probabilities, IDX_MAP_EXCEPTION,
                                  batch, H_IN, W_IN, device=device, nb_in_flight=coder_streams or args.coder_streams,
-                                 launch_hook=timed_launch, coder=coder_mode, host_coder_threads=coder_threads)
+                                 launch_hook=timed_launch, coder=coder_mode, host_coder_threads=coder_threads,
+                                 nb_transform_streams=transform_streams)
 
     def barrier():
         if world > 1:

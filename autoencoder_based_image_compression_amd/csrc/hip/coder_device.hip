@@ -125,9 +125,6 @@ template <int MODE, bool UNIFORM>
 __global__ __launch_bounds__(64) void coder_maps_kernel(const CoderParams p) {
     // a handful of latency-bound waves next to the transforms' MFMA waves: let them issue whenever they are ready
     __builtin_amdgcn_s_setprio(EAE_CODER_PRIO);
-#ifdef EAE_CODER_DEBUG_CLOCKS
-    const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     uint32_t m;
     if (!map_of_thread<UNIFORM>(p, m)) return;
     if (p.only_status && p.status[m] != p.only_status) return;
@@ -189,10 +186,6 @@ __global__ __launch_bounds__(64) void coder_maps_kernel(const CoderParams p) {
     p.bypass_bits[m] = nbyp;
     p.status[m] = s;
     if (p.stage) p.stage[m] = st;
-#ifdef EAE_CODER_DEBUG_CLOCKS
-    p.stage[m] = (int)(__builtin_amdgcn_s_memtime() - dbg_t0);
-    p.bypass_bits[m] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - dbg_r0);
-#endif
 }
 
 // The decoder side on its own: streams + bit lengths -> symbols (COMPARE = false), or -> a comparison with the symbols

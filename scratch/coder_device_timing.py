@@ -65,6 +65,25 @@ print('all-zero symbols: encode', timeit(zeros, 1), 'verify', timeit(zeros, 3))
 print('all-one symbols: encode', timeit(ones, 1), 'verify', timeit(ones, 3))
 rows = rows[:64].contiguous()
 print('64 maps only: encode', timeit(few, 1), 'verify', timeit(few, 3))
+def timeit(symbols, mode, lanes=1):
+    (s2, _) = dev.coder_compress_maps(symbols, p, rows, 10, mode=min(mode, 2), lanes_per_wave=lanes)
+    torch.cuda.synchronize()
+    a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a_.record()
+    for _ in range(5):
+        if mode == 3:
+            dev.coder_verify_maps(s2, symbols, p, rows, lanes)
+        else:
+            dev.coder_compress_maps(symbols, p, rows, 10, mode=mode, out=s2, lanes_per_wave=lanes)
+    b_.record(); torch.cuda.synchronize()
+    return round(a_.elapsed_time(b_)/5, 3)
+zeros = torch.zeros_like(sym)
+ones = torch.ones_like(sym)
+few = sym[:64].contiguous()
+print('all-zero symbols: encode', timeit(zeros, 1), 'verify', timeit(zeros, 3))
+print('all-one symbols: encode', timeit(ones, 1), 'verify', timeit(ones, 3))
+rows = rows[:64].contiguous()
+print('64 maps only: encode', timeit(few, 1), 'verify', timeit(few, 3))
 if os.environ.get('EAE_CODER_DEBUG_CLOCKS'):
     rows = torch.arange(128, dtype=torch.int32).repeat(24).cuda()
     for lanes in ((0, 1, 8) if mode < 4 else (64,)):

@@ -305,8 +305,9 @@ def cpu_baseline(variables, probabilities, map_mean, cores):
     (t, bits, mse) = run(n_img)
     total = sum(t.values())
     return {'value': round(n_img*H_IN*W_IN/total/1e6, 4), 'unit': 'Mpixels/s', 'cores': cores, 'kind': 'port',
-            'sample': '{} synthetic ' + '{0}x{1}'.format(H_IN, W_IN) + ' images, encode+quantise+code(enc+dec)+decode+PSNR, {:.1f} s of CPU work; transforms '
-                      'OpenMP on the {} usable CPUs, coder single-threaded like the reference'.format(n_img, total, cores),
+            'sample': ('{0} synthetic {1}x{2} images, encode+quantise+code(enc+dec)+decode+PSNR, {3:.1f} s of CPU work; '
+                       'transforms OpenMP on the {4} usable CPUs, coder single-threaded like the reference'
+                       ).format(n_img, H_IN, W_IN, total, cores),
             'seconds': {k: round(val, 3) for (k, val) in t.items()}, 'bits': int(bits), 'mse': round(mse, 4)}
 
 

@@ -6,6 +6,8 @@
 // pool over independent maps (the reference is single-threaded) and the extern "C" surface.
 #include "eae_coder.h"
 
+#include <nmmintrin.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -399,6 +401,20 @@ int eae_coder_count_binary_decisions(uint32_t n_maps, uint32_t map_size, const i
     };
     Pool::instance().parallel_for(n_maps, n_threads, body);
     return EAE_SUCCESS;
+}
+
+// ---- CRC-32C for checkpoint ingestion (the SSE4.2 crc32 instruction implements exactly this polynomial) ---------------
+uint32_t eae_crc32c(const void* data, size_t size, uint32_t crc) {
+    const uint8_t* p = static_cast<const uint8_t*>(data);
+    uint64_t state = (uint32_t)~crc;
+    while (size && ((uintptr_t)p & 7)) { state = _mm_crc32_u8((uint32_t)state, *p++); --size; }
+    for (; size >= 8; size -= 8, p += 8) {
+        uint64_t word;
+        std::memcpy(&word, p, 8);
+        state = _mm_crc32_u64(state, word);
+    }
+    while (size--) state = _mm_crc32_u8((uint32_t)state, *p++);
+    return ~(uint32_t)state;
 }
 
 }  // extern "C"

@@ -4,7 +4,6 @@ Kept: the constructor signature and its shape checks (:36-80), `node_visible_uni
 `initialization` (:440-463), `get_bin_widths` (:398-409), `save` (:465-482, to `.npz`). The training graph
 (:252-396, :411-438) -- noise, piecewise-linear density, optimisers, expansion -- is out of scope.
 """
-import os
 import pickle
 
 import numpy
@@ -72,14 +71,12 @@ class EntropyAutoencoder(object):
     def initialization(self, sess, path_to_restore, seed=None):
         """Either initializes all variables or restores a previous model (:440-463).
 
-        `path_to_restore`: '' -> random initialisation like the reference's; otherwise a `.npz` keyed by the TF
-        variable names (a path ending in ".ckpt" is mapped to the sibling ".npz").
+        `path_to_restore`: '' -> random initialisation like the reference's; otherwise the ".ckpt" prefix of a
+        TensorFlow checkpoint (V1 or V2, read without TensorFlow) or of a sibling `.npz` keyed by the TF variable
+        names (`variables.restore_variables`).
         """
         if path_to_restore:
-            path = path_to_restore[:-5] + '.npz' if path_to_restore.endswith('.ckpt') else path_to_restore
-            if not os.path.isfile(path):
-                raise IOError('The model "{}" does not exist.'.format(path))
-            self._variables = var.load_variables(path)
+            self._variables = var.restore_variables(path_to_restore, self.are_bin_widths_learned, 'encoder')
         else:
             self._variables = var.random_variables(self.bin_width_init, self.are_bin_widths_learned, seed=seed)
         self._encoder = pipeline.DeviceEncoder(self._variables, self.are_bin_widths_learned, bk.device())

@@ -1,6 +1,5 @@
 """The reference's `IsolatedDecoder` (kodak_tensorflow/eae/graph/IsolatedDecoder.py:21-129): decoder-only model fed
 with quantized latent variables, on the MI355X."""
-import os
 
 from . import constants as csts
 from . import variables as var
@@ -40,10 +39,7 @@ class IsolatedDecoder(object):
     def initialization(self, sess, path_to_restore, seed=None):
         """Either initializes all variables or restores a previous model (:109-129)."""
         if path_to_restore:
-            path = path_to_restore[:-5] + '.npz' if path_to_restore.endswith('.ckpt') else path_to_restore
-            if not os.path.isfile(path):
-                raise IOError('The model "{}" does not exist.'.format(path))
-            self._variables = var.load_variables(path)
+            self._variables = var.restore_variables(path_to_restore, self.are_bin_widths_learned, 'decoder')
         else:
             self._variables = var.random_variables(1., self.are_bin_widths_learned, seed=seed)
         self._decoder = pipeline.DeviceDecoder(self._variables, self.are_bin_widths_learned, bk.device())

@@ -1,10 +1,13 @@
 """Variables of the entropy autoencoder under their TensorFlow names, as numpy arrays in the TF layouts.
 
 Reference: kodak_tensorflow/eae/graph/EntropyAutoencoder.py:108-224 (encoder/decoder/bin-width variables and their
-initialisers) and kodak_tensorflow/eae/graph/IsolatedDecoder.py:54-97. The container format of this build is a
-``.npz`` keyed by those names (the trained ``model_*.ckpt`` files are absent from the reference mount,
+initialisers) and kodak_tensorflow/eae/graph/IsolatedDecoder.py:54-97. Models are restored from the reference's own
+TensorFlow checkpoints (`model_<i>.ckpt`, V1 or V2, read by `tf_checkpoint` without TensorFlow) or from a ``.npz``
+keyed by the same names (the trained ``model_*.ckpt`` files are absent from the reference mount,
 .MISSING_LARGE_BLOBS:1-9).
 """
+import os
+
 import numpy
 
 from . import constants as csts
@@ -97,3 +100,42 @@ def save_variables(path, variables):
 def load_variables(path):
     with numpy.load(path) as data:
         return {name: numpy.ascontiguousarray(data[name]) for name in data.files}
+
+
+def model_names(are_bin_widths_learned, side='both'):
+    """TF names of the variables the inference path reads: `side` = 'encoder', 'decoder' or 'both'."""
+    names = []
+    if side in ('encoder', 'both'):
+        names += list(ENCODER_NAMES) + ([] if are_bin_widths_learned else list(ENCODER_NAMES_FIXED_BW))
+    if side in ('decoder', 'both'):
+        names += list(DECODER_NAMES) + ([] if are_bin_widths_learned else list(DECODER_NAMES_FIXED_BW))
+    return names + [BIN_WIDTHS_NAME]
+
+
+def restore_variables(path_to_restore, are_bin_widths_learned, side='both'):
+    """What `tf.train.Saver().restore(sess, path_to_restore)` gives the inference path (EntropyAutoencoder.py:454-458,
+    IsolatedDecoder.py:123-124): the variables of `side`, float32, in the TF layouts.
+
+    `path_to_restore` ends with ".ckpt" like the reference's. Looked up in this order: a TensorFlow checkpoint at that
+    prefix (V2 `.index` + `.data-*`, then V1 single file), then the sibling `.npz`; a path that does not end with
+    ".ckpt" is an `.npz` file.
+
+    Raises
+    ------
+    IOError
+        If no model is found at `path_to_restore`.
+    KeyError, ValueError
+        If a variable is missing (e.g. a fixed-bin-width graph restored from a learned-bin-width model), or has the
+        wrong dtype or shape.
+    """
+    from . import tf_checkpoint
+    names = model_names(are_bin_widths_learned, side)
+    if tf_checkpoint.exists(path_to_restore):
+        variables = tf_checkpoint.load_checkpoint(path_to_restore, names=names)
+    else:
+        path = path_to_restore[:-5] + '.npz' if path_to_restore.endswith('.ckpt') else path_to_restore
+        if not os.path.isfile(path):
+            raise IOError('The model "{}" does not exist.'.format(path_to_restore))
+        variables = load_variables(path)
+    check_variables(variables, names)
+    return {name: numpy.ascontiguousarray(variables[name]) for name in names}

@@ -26,7 +26,7 @@ def fix_gamma(reference_uint8, bin_width_init, multipliers, idx_training, gamma_
 
     reference_uint8 : uint8 (nb_images, h_in, w_in). multipliers : float32 (nb_points,).
     Files are looked up like the reference does, relative to `root`:
-      eae/results/<suffix>/nb_itvs_per_side_<idx>.pkl, eae/results/<suffix>/model_<idx>.ckpt (here: .npz),
+      eae/results/<suffix>/nb_itvs_per_side_<idx>.pkl, eae/results/<suffix>/model_<idx>.ckpt (a TF checkpoint, or a sibling .npz),
       lossless/results/<suffix>/training_index_<idx>/{map_mean.npy, idx_map_exception.pkl, binary_probabilities_<m>.npy}.
     Returns (rate, psnr) float64 (nb_points, nb_images) [+ array_nb_deads int32 when `return_nb_deads`].
     """
@@ -116,11 +116,9 @@ def fix_gamma_batched(reference_uint8, bin_width_init, multipliers, idx_training
         suffix = 'learning_bw_{0}_{1}'.format(tls.float_to_str(bin_width_init), tls.float_to_str(gamma_scaling))
     else:
         suffix = '{0}_{1}'.format(tls.float_to_str(bin_width_init), tls.float_to_str(gamma_scaling))
-    path_to_restore = os.path.join(root, 'eae/results/{0}/model_{1}.npz'.format(suffix, idx_training))
-    if not os.path.isfile(path_to_restore):
-        raise IOError('The model "{}" does not exist.'.format(path_to_restore))
+    path_to_restore = os.path.join(root, 'eae/results/{0}/model_{1}.ckpt'.format(suffix, idx_training))
     path_to_stats = os.path.join(root, 'lossless/results/{0}/training_index_{1}/'.format(suffix, idx_training))
-    variables = var.load_variables(path_to_restore)
+    variables = var.restore_variables(path_to_restore, are_bin_widths_learned)       # IOError if absent
     bin_widths = variables[var.BIN_WIDTHS_NAME]
     map_mean = numpy.load(os.path.join(path_to_stats, 'map_mean.npy'))
     with open(os.path.join(path_to_stats, 'idx_map_exception.pkl'), 'rb') as file:

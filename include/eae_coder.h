@@ -21,6 +21,7 @@
 #ifndef EAE_CODER_H
 #define EAE_CODER_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -142,6 +143,12 @@ uint8_t eae_coder_count_nb_bits(uint32_t input);
  * zeros/ones: [n_maps][L] int64, ACCUMULATED into (caller zeroes). */
 int eae_coder_count_binary_decisions(uint32_t n_maps, uint32_t map_size, const int16_t* symbols,
                                      uint8_t truncated_unary_length, int64_t* zeros, int64_t* ones, int n_threads);
+
+/* ---- checkpoint ingestion helper ------------------------------------------------------------------------------------
+ * CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of `size` bytes, continuing from `crc` (0 to start). The
+ * reference restores its models with tf.train.Saver (eae/graph/EntropyAutoencoder.py:454-458); TensorFlow's bundle
+ * and table formats checksum every block and tensor with this CRC (kodak/eae/graph/tf_checkpoint.py is the caller). */
+uint32_t eae_crc32c(const void* data, size_t size, uint32_t crc);
 
 #ifdef __cplusplus
 }

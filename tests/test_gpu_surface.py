@@ -112,12 +112,21 @@ def test_lossless_compression(gold, cgold, tmp_path):
         compression.compress_lossless_maps(gold['lossless_symbols'], bad)
 
 
-def _write_model(root, suffix, idx, variables, map_mean, idx_exc, probabilities, multipliers, tls):
+def _write_model(root, suffix, idx, variables, map_mean, idx_exc, probabilities, multipliers, tls, layout='npz'):
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import tf_checkpoint
     from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
     os.makedirs(os.path.join(root, 'eae/results', suffix))
     stats_dir = os.path.join(root, 'lossless/results', suffix, 'training_index_{}'.format(idx))
     os.makedirs(stats_dir)
-    var.save_variables(os.path.join(root, 'eae/results', suffix, 'model_{}.npz'.format(idx)), variables)
+    if layout == 'npz':
+        var.save_variables(os.path.join(root, 'eae/results', suffix, 'model_{}.npz'.format(idx)), variables)
+    else:
+        # a TensorFlow checkpoint like the authors' (`Saver.save`, EntropyAutoencoder.py:465-482): model + other tensors
+        stored = dict(variables)
+        stored['encoder/weights_1/Adam'] = numpy.ones((9, 9, 1, 128), dtype=numpy.float32)
+        stored['decaying_lr/global_step'] = numpy.array(7, dtype=numpy.int32)
+        prefix = os.path.join(root, 'eae/results', suffix, 'model_{}.ckpt'.format(idx))
+        (tf_checkpoint.save_checkpoint_v1 if layout == 'v1' else tf_checkpoint.save_checkpoint)(prefix, stored)
     with open(os.path.join(root, 'eae/results', suffix, 'nb_itvs_per_side_{}.pkl'.format(idx)), 'wb') as f:
         pickle.dump(91, f, protocol=2)
     numpy.save(os.path.join(stats_dir, 'map_mean.npy'), map_mean)
@@ -144,7 +153,8 @@ def test_fix_gamma_harness_against_the_oracle(tmp_path, tls, cgold, learned):
     map_mean = cgold['real_map_mean'].astype(numpy.float32)*numpy.float32(0.1)
     probabilities = cgold['real_probabilities_2']
     suffix = ('learning_bw_0dot5_10000' if learned else '1_10000')
-    _write_model(str(tmp_path), suffix, 10, v, map_mean, 67, probabilities, multipliers, tls)
+    _write_model(str(tmp_path), suffix, 10, v, map_mean, 67, probabilities, multipliers, tls,
+                 layout='v1' if learned else 'npz')
     for is_lossless in (True, False):
         (rate, psnr, nb_deads) = rk.fix_gamma(x, 0.5 if learned else 1., multipliers, 10, 10000., 2, learned, is_lossless,
                                               root=str(tmp_path), return_nb_deads=True)
@@ -203,7 +213,7 @@ def test_vary_gamma_and_batching_errors(tmp_path, tls, cgold):
         v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
         vs.append(v)
         _write_model(str(tmp_path), '1_{}'.format(int(g)), 10, v, numpy.zeros(128, dtype=numpy.float32), 67,
-                     cgold['real_probabilities_1'], [1.], tls)
+                     cgold['real_probabilities_1'], [1.], tls, layout='v2' if seed == 42 else 'npz')
     x = numpy.random.RandomState(43).randint(16, 236, size=(2, 16, 32)).astype(numpy.uint8)
     (rate, psnr) = rk.vary_gamma_fix_bin_widths(x, 1., idxs, gammas, 2, root=str(tmp_path))
     for (i, v) in enumerate(vs):

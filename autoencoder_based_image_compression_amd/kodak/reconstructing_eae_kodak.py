@@ -4,7 +4,9 @@
 the calls the reference makes (`EntropyAutoencoder`, `IsolatedDecoder`, `tf.Session`, `eae.batching.*`, `tls.*`,
 `lossless.compression.rescale_compress_lossless_maps`), so it doubles as the proof that the reference's own script
 drops onto this package. With `path_to_checking_r` the reconstructions and their crops are written as PNG
-like the reference does (:227-232). Out of scope here: matplotlib plots, JPEG2000 / HEVC baselines of the reference's `__main__`.
+like the reference does (:227-232, :550-555). `write_reference` :558-591 and `evaluate_cached` (the `.npy` result cache and
+the Bjontegaard dictionary of the reference's `__main__`, :593-760, :809-860) complete the entropy-autoencoder side.
+Out of scope here: matplotlib plots and running the JPEG2000 / HEVC baselines (external codecs).
 """
 import os
 import pickle
@@ -177,4 +179,117 @@ def vary_gamma_fix_bin_widths(reference_uint8, bin_width_init, idxs_training, ga
         for j in range(nb_images):
             rate[i, j] = tls.rate_3d(quantized_y_float32[j, :, :, :], bin_widths, h_in, w_in)
             psnr[i, j] = tls.psnr_2d(reference_uint8[j, :, :], reconstruction_uint8[j, :, :])
+            if path_to_checking_r is not None:                                           # the PNG dumps of :491-495, :550-555
+                path_to_storage = os.path.join(path_to_checking_r, 'reconstruction_vary_gamma_fix_bin_widths', suffix)
+                os.makedirs(path_to_storage, exist_ok=True)
+                paths = [os.path.join(path_to_storage, 'reconstruction_{}.png'.format(j))]
+                paths += [os.path.join(path_to_storage, 'reconstruction_{0}_crop_{1}.png'.format(j, index_crop))
+                          for index_crop in range(positions_top_left.shape[1])]
+                tls.visualize_rotated_luminance(reconstruction_uint8[j, :, :], j in list_rotation, positions_top_left, paths)
     return (rate, psnr)
+
+
+def write_reference(reference_uint8, path_to_checking_r, list_rotation, positions_top_left):
+    """Writes the luminance images and their crops under `<path_to_checking_r>/reference/` (:558-591)."""
+    os.makedirs(os.path.join(path_to_checking_r, 'reference'), exist_ok=True)
+    for i in range(reference_uint8.shape[0]):
+        paths = [os.path.join(path_to_checking_r, 'reference/reference_{}.png'.format(i))]
+        paths += [os.path.join(path_to_checking_r, 'reference/reference_{0}_crop_{1}.png'.format(i, index_crop))
+                  for index_crop in range(positions_top_left.shape[1])]
+        tls.visualize_rotated_luminance(reference_uint8[i, :, :], i in list_rotation, positions_top_left, paths)
+
+
+# The three entropy-autoencoder experiments of the reference's `__main__` (:609-626).
+DICT_VARY_GAMMA_FIX_BIN_WIDTHS = {
+    'bin_width_init': 1.,
+    'idxs_training': numpy.array([10, 10, 10, 10, 10, 7, 6], dtype=numpy.int32),
+    'gammas_scaling': numpy.array([10000., 12000., 16000., 24000., 40000., 72000., 96000.])
+}
+DICT_FIX_GAMMA_LEARN_BIN_WIDTHS = {
+    'bin_width_init': 0.5,
+    'multipliers': numpy.array([1., 1.25, 1.5, 2., 3., 4., 6., 8., 10.], dtype=numpy.float32),
+    'idx_training': 10,
+    'gamma_scaling': 10000.
+}
+DICT_FIX_GAMMA_FIX_BIN_WIDTHS = {
+    'bin_width_init': 1.,
+    'multipliers': numpy.array([1., 1.25, 1.5, 2., 3., 4., 6., 8., 10.], dtype=numpy.float32),
+    'idx_training': 10,
+    'gamma_scaling': 10000.
+}
+
+
+def _cached(path_to_rate, path_to_psnr, label, compute, verbose):
+    """The reference's result cache (:674-760): two `.npy` files per curve; present -> loaded, absent -> computed and saved."""
+    if os.path.isfile(path_to_rate) and os.path.isfile(path_to_psnr):
+        if verbose:
+            print('For {0}, the rates at "{1}" and the PSNRs at "{2}" are loaded.'.format(label, path_to_rate, path_to_psnr))
+            print('Delete them manually to re-compute them.')
+        return (numpy.load(path_to_rate), numpy.load(path_to_psnr))
+    if verbose:
+        print('For {}, the rates and the PSNRs are computed.'.format(label))
+    (rate, psnr) = compute()
+    numpy.save(path_to_rate, rate)
+    numpy.save(path_to_psnr, psnr)
+    return (rate, psnr)
+
+
+def evaluate_cached(reference_uint8, path_to_checking_r, list_rotation, positions_top_left, code_lossless, batch_size=4,
+                    root='.', write_ref=False, dump_images=True, batched=False, verbose=True,
+                    dict_vary_gamma_fix_bin_widths=None, dict_fix_gamma_learn_bin_widths=None,
+                    dict_fix_gamma_fix_bin_widths=None):
+    """The entropy-autoencoder part of the reference's `__main__` (:593-760, :809-860) with its on-disk result layout.
+
+    Under `path_to_checking_r` (the reference uses 'eae/visualization/test/checking_reconstructing/<kodak|bsds>'):
+      rate_vary_gamma_fix_bin_widths.npy, psnr_vary_gamma_fix_bin_widths.npy               (orange curve)
+      rate_fix_gamma_learn_bin_widths_<code>.npy, psnr_fix_gamma_learn_bin_widths_<code>.npy (green curve)
+      rate_fix_gamma_fix_bin_widths_<code>.npy, psnr_fix_gamma_fix_bin_widths_<code>.npy     (red curve)
+    with <code> = 'lossless' if `code_lossless` else 'approx'. A curve whose two files exist is loaded, not recomputed.
+    When `rate_jpeg2000.npy` / `psnr_jpeg2000.npy` and `rate_hevc.npy` / `psnr_hevc.npy` are there too (the reference
+    makes them with external codecs, out of scope here), `dictionary_bjontegaard_<code>.pkl` is written like :839-860.
+    `batched` routes the lossless `fix_gamma` curves through `fix_gamma_batched` (same arrays, everything in HBM; no PNG
+    dumps). Returns a dict with the six arrays, the mean curves and the Bjontegaard dictionary (or None).
+    """
+    vary = dict_vary_gamma_fix_bin_widths or DICT_VARY_GAMMA_FIX_BIN_WIDTHS
+    learn = dict_fix_gamma_learn_bin_widths or DICT_FIX_GAMMA_LEARN_BIN_WIDTHS
+    fix = dict_fix_gamma_fix_bin_widths or DICT_FIX_GAMMA_FIX_BIN_WIDTHS
+    os.makedirs(path_to_checking_r, exist_ok=True)
+    if write_ref:
+        write_reference(reference_uint8, path_to_checking_r, list_rotation, positions_top_left)
+    dumps = (path_to_checking_r, list_rotation, positions_top_left) if dump_images else (None, None, None)
+    str_code = 'lossless' if code_lossless else 'approx'
+
+    def path(name):
+        return os.path.join(path_to_checking_r, name)
+
+    def run_fix_gamma(config, are_bin_widths_learned):
+        if batched and code_lossless:
+            return fix_gamma_batched(reference_uint8, config['bin_width_init'], config['multipliers'], config['idx_training'],
+                                     config['gamma_scaling'], batch_size, are_bin_widths_learned, root=root)
+        return fix_gamma(reference_uint8, config['bin_width_init'], config['multipliers'], config['idx_training'],
+                         config['gamma_scaling'], batch_size, are_bin_widths_learned, code_lossless, *dumps, root=root)
+    out = {}
+    (out['rate_vary_gamma_fix_bin_widths'], out['psnr_vary_gamma_fix_bin_widths']) = _cached(
+        path('rate_vary_gamma_fix_bin_widths.npy'), path('psnr_vary_gamma_fix_bin_widths.npy'), 'the orange curve',
+        lambda: vary_gamma_fix_bin_widths(reference_uint8, vary['bin_width_init'], vary['idxs_training'], vary['gammas_scaling'],
+                                          batch_size, *dumps, root=root), verbose)
+    (out['rate_fix_gamma_learn_bin_widths'], out['psnr_fix_gamma_learn_bin_widths']) = _cached(
+        path('rate_fix_gamma_learn_bin_widths_{}.npy'.format(str_code)), path('psnr_fix_gamma_learn_bin_widths_{}.npy'.format(str_code)),
+        'the green curve', lambda: run_fix_gamma(learn, True), verbose)
+    (out['rate_fix_gamma_fix_bin_widths'], out['psnr_fix_gamma_fix_bin_widths']) = _cached(
+        path('rate_fix_gamma_fix_bin_widths_{}.npy'.format(str_code)), path('psnr_fix_gamma_fix_bin_widths_{}.npy'.format(str_code)),
+        'the red curve', lambda: run_fix_gamma(fix, False), verbose)
+    for key in list(out):
+        out['mean_' + key] = numpy.mean(out[key], axis=1)                                                       # :809-815
+    out['dict_bjontegaard'] = None
+    external = [path('{0}_{1}.npy'.format(kind, codec_name)) for codec_name in ('jpeg2000', 'hevc') for kind in ('rate', 'psnr')]
+    if all(os.path.isfile(p) for p in external):
+        means = {name: numpy.mean(numpy.load(path('{}.npy'.format(name))), axis=1)
+                 for name in ('rate_jpeg2000', 'psnr_jpeg2000', 'rate_hevc', 'psnr_hevc')}
+        out['dict_bjontegaard'] = {
+            '{0}_{1}'.format(curve, codec_name): tls.compute_bjontegaard(out['mean_rate_' + curve], out['mean_psnr_' + curve],
+                                                                         means['rate_' + codec_name], means['psnr_' + codec_name])
+            for curve in ('fix_gamma_learn_bin_widths', 'fix_gamma_fix_bin_widths') for codec_name in ('jpeg2000', 'hevc')}
+        with open(path('dictionary_bjontegaard_{}.pkl'.format(str_code)), 'wb') as file:
+            pickle.dump(out['dict_bjontegaard'], file, protocol=2)
+    return out

@@ -340,3 +340,73 @@ def test_fix_gamma_writes_the_png_dumps(tmp_path, tls, cgold):
     assert numpy.asarray(PIL.Image.open(os.path.join(folder, 'reconstruction_0.png'))).shape == (96, 112)
     assert numpy.asarray(PIL.Image.open(os.path.join(folder, 'reconstruction_1.png'))).shape == (112, 96)      # rotated
     assert numpy.asarray(PIL.Image.open(os.path.join(folder, 'reconstruction_1_crop_0.png'))).shape == (160, 160)
+
+
+@pytest.mark.filterwarnings('ignore:overflow encountered')
+def test_evaluate_cached_reproduces_the_reference_result_layout(tmp_path, tls, cgold):
+    """The reference's `__main__` (reconstructing_eae_kodak.py:593-760, :809-860): per-curve `.npy` caches under
+    `path_to_checking_r`, reuse of existing caches, reference PNGs with `write_ref`, and the Bjontegaard dictionary when
+    the JPEG2000 / HEVC arrays are present."""
+    from autoencoder_based_image_compression_amd.kodak import reconstructing_eae_kodak as rk
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    root = str(tmp_path)
+    multipliers = numpy.array([1., 1.5, 2., 3.], dtype=numpy.float32)
+    models = {}
+    for (suffix, learned, seed, layout) in (('1_10000', False, 5, 'v1'), ('1_12000', False, 6, 'npz'),
+                                            ('learning_bw_0dot5_10000', True, 7, 'v2')):
+        v = var.random_variables(0.5 if learned else 1., learned, seed=seed, bias_std=0.01)
+        v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
+        models[suffix] = v
+        _write_model(root, suffix, 10, v, cgold['real_map_mean'].astype(numpy.float32)*numpy.float32(0.1), 67,
+                     cgold['real_probabilities_2'], multipliers, tls, layout=layout)
+    x = numpy.random.RandomState(8).randint(16, 236, size=(4, 96, 112)).astype(numpy.float64)
+    x = numpy.round((x + numpy.roll(x, 1, 1) + numpy.roll(x, 1, 2))/3.).astype(numpy.uint8)
+    positions = numpy.array([[2, 3], [9, 1]], dtype=numpy.int32)
+    configs = {
+        'dict_vary_gamma_fix_bin_widths': {'bin_width_init': 1., 'idxs_training': numpy.array([10, 10], dtype=numpy.int32),
+                                           'gammas_scaling': numpy.array([10000., 12000.])},
+        'dict_fix_gamma_learn_bin_widths': {'bin_width_init': 0.5, 'multipliers': multipliers, 'idx_training': 10, 'gamma_scaling': 10000.},
+        'dict_fix_gamma_fix_bin_widths': {'bin_width_init': 1., 'multipliers': multipliers, 'idx_training': 10, 'gamma_scaling': 10000.},
+    }
+    checking = os.path.join(root, 'eae/visualization/test/checking_reconstructing/kodak')
+    out = rk.evaluate_cached(x, checking, [2], positions, True, batch_size=2, root=root, write_ref=True, verbose=False, **configs)
+    assert sorted(name for name in os.listdir(checking) if name.endswith('.npy')) == [
+        'psnr_fix_gamma_fix_bin_widths_lossless.npy', 'psnr_fix_gamma_learn_bin_widths_lossless.npy', 'psnr_vary_gamma_fix_bin_widths.npy',
+        'rate_fix_gamma_fix_bin_widths_lossless.npy', 'rate_fix_gamma_learn_bin_widths_lossless.npy', 'rate_vary_gamma_fix_bin_widths.npy']
+    assert out['rate_vary_gamma_fix_bin_widths'].shape == (2, 4) and out['rate_fix_gamma_learn_bin_widths'].shape == (4, 4)
+    assert out['dict_bjontegaard'] is None and not os.path.isfile(os.path.join(checking, 'dictionary_bjontegaard_lossless.pkl'))
+    assert sorted(os.listdir(os.path.join(checking, 'reference')))[:4] == ['reference_0.png', 'reference_0_crop_0.png',
+                                                                          'reference_0_crop_1.png', 'reference_1.png']
+    assert len(os.listdir(os.path.join(checking, 'reconstruction_vary_gamma_fix_bin_widths', '1_12000'))) == 4*3
+    assert len(os.listdir(os.path.join(checking, 'reconstruction_fix_gamma', 'learning_bw_0dot5_10000', 'lossless', 'multiplier_1dot5'))) == 4*3
+    # the arrays are the harness functions' own results
+    direct = rk.fix_gamma(x, 1., multipliers, 10, 10000., 2, False, True, root=root)
+    assert numpy.array_equal(direct[0], out['rate_fix_gamma_fix_bin_widths']) and numpy.array_equal(direct[1], out['psnr_fix_gamma_fix_bin_widths'])
+    assert numpy.array_equal(numpy.load(os.path.join(checking, 'rate_fix_gamma_fix_bin_widths_lossless.npy')), direct[0])
+    # the fused route fills the same cache with the same numbers
+    fused = rk.evaluate_cached(x, os.path.join(root, 'fused'), [2], positions, True, batch_size=2, root=root, batched=True,
+                               dump_images=False, verbose=False, **configs)
+    for key in ('rate_fix_gamma_learn_bin_widths', 'psnr_fix_gamma_learn_bin_widths', 'rate_fix_gamma_fix_bin_widths',
+                'psnr_fix_gamma_fix_bin_widths', 'rate_vary_gamma_fix_bin_widths', 'psnr_vary_gamma_fix_bin_widths'):
+        assert numpy.array_equal(fused[key], out[key]), key
+    assert not os.path.isdir(os.path.join(root, 'fused', 'reconstruction_fix_gamma'))
+    # caches win over recomputation; 'approx' results live in their own files
+    marked = out['rate_fix_gamma_fix_bin_widths'] + 1.
+    numpy.save(os.path.join(checking, 'rate_fix_gamma_fix_bin_widths_lossless.npy'), marked)
+    for codec_name in ('jpeg2000', 'hevc'):      # the external baselines' arrays (9 points in the reference; any count works)
+        numpy.save(os.path.join(checking, 'rate_{}.npy'.format(codec_name)), numpy.tile(numpy.linspace(0.2, 2.5, 6)[:, None], (1, 4)))
+        numpy.save(os.path.join(checking, 'psnr_{}.npy'.format(codec_name)), numpy.tile(numpy.linspace(27., 40., 6)[:, None], (1, 4)))
+    again = rk.evaluate_cached(x, checking, [2], positions, True, batch_size=2, root=root, verbose=False, **configs)
+    assert numpy.array_equal(again['rate_fix_gamma_fix_bin_widths'], marked)
+    assert numpy.array_equal(again['rate_fix_gamma_learn_bin_widths'], out['rate_fix_gamma_learn_bin_widths'])
+    with open(os.path.join(checking, 'dictionary_bjontegaard_lossless.pkl'), 'rb') as file:
+        stored = pickle.load(file)
+    assert sorted(stored) == ['fix_gamma_fix_bin_widths_hevc', 'fix_gamma_fix_bin_widths_jpeg2000',
+                              'fix_gamma_learn_bin_widths_hevc', 'fix_gamma_learn_bin_widths_jpeg2000']
+    expected = tls.compute_bjontegaard(numpy.mean(out['rate_fix_gamma_learn_bin_widths'], axis=1), numpy.mean(out['psnr_fix_gamma_learn_bin_widths'], axis=1),
+                                       numpy.linspace(0.2, 2.5, 6), numpy.linspace(27., 40., 6))
+    assert stored['fix_gamma_learn_bin_widths_hevc'] == expected == again['dict_bjontegaard']['fix_gamma_learn_bin_widths_jpeg2000']
+    approx = rk.evaluate_cached(x, checking, [2], positions, False, batch_size=2, root=root, dump_images=False, verbose=False, **configs)
+    assert os.path.isfile(os.path.join(checking, 'rate_fix_gamma_fix_bin_widths_approx.npy'))
+    assert not numpy.array_equal(approx['rate_fix_gamma_fix_bin_widths'], out['rate_fix_gamma_fix_bin_widths'])
+    assert numpy.array_equal(approx['psnr_fix_gamma_fix_bin_widths'], out['psnr_fix_gamma_fix_bin_widths'])

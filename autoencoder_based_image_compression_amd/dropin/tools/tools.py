@@ -1,9 +1,9 @@
 from autoencoder_based_image_compression_amd.kodak.tools.tools import (  # noqa: F401
     average_entropies, cast_bt601, cast_float_to_int16, compute_bjontegaard, count_nb_deads, count_symbols, crop_repeat_2d,
-    discrete_entropy, float_to_str, jensen_shannon_divergence, psnr_2d, quantize_per_map, rate_3d, rgb_to_ycbcr, save_image,
+    discrete_entropy, float_to_str, jensen_shannon_divergence, psnr_2d, quantize_per_map, rate_3d, read_image_mode, rgb_to_ycbcr, save_image,
     subdivide_set, visualize_crops, visualize_rotated_luminance)
 
-_OUT_OF_SCOPE = ('plot_graphs', 'histogram', 'read_image_mode', 'crop_option_2d', 'untar_archive', 'tile_cauchy',
+_OUT_OF_SCOPE = ('plot_graphs', 'histogram', 'crop_option_2d', 'untar_archive', 'tile_cauchy',
                  'kl_divergence', 'normed_histogram',
                  'visualize_luminances', 'visualize_representation', 'visualize_weights', 'clean_sort_list_strings',
                  'convert_approx_entropy', 'expand_all', 'expand_parameters', 'gradient_density_approximation',

@@ -16,6 +16,8 @@ def device():
 
 def to_device(array, dtype=None):
     a = numpy.ascontiguousarray(array, dtype=dtype)
+    if not a.flags.writeable:          # e.g. numpy.asarray(PIL image): torch refuses to alias read-only memory silently
+        a = a.copy()
     return torch.from_numpy(a).to(device(), non_blocking=False)
 
 

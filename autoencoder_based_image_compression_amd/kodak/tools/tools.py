@@ -278,6 +278,21 @@ def rate_from_entropies(entropies, height_map, width_map, h_in, w_in):
     return cumulated_rate/(h_in*w_in)
 
 
+def read_image_mode(path, mode):
+    """Reads the image if its mode matches the given mode, e.g. 'RGB' or 'L' (tools.py:991-1017).
+
+    Raises
+    ------
+    ValueError
+        If the image mode is not equal to `mode`.
+    """
+    import PIL.Image
+    image = PIL.Image.open(path)
+    if image.mode != mode:
+        raise ValueError('The image mode is {0} whereas the given mode is {1}.'.format(image.mode, mode))
+    return numpy.asarray(image)
+
+
 def rgb_to_ycbcr(rgb_uint8):
     """Converts the RGB image to YCbCr, ITU-R BT.601 like Matlab's `rgb2ycbcr` (tools.py:1019-1083), on the device.
 

@@ -410,3 +410,52 @@ def test_evaluate_cached_reproduces_the_reference_result_layout(tmp_path, tls, c
     assert os.path.isfile(os.path.join(checking, 'rate_fix_gamma_fix_bin_widths_approx.npy'))
     assert not numpy.array_equal(approx['rate_fix_gamma_fix_bin_widths'], out['rate_fix_gamma_fix_bin_widths'])
     assert numpy.array_equal(approx['psnr_fix_gamma_fix_bin_widths'], out['psnr_fix_gamma_fix_bin_widths'])
+
+
+def test_create_kodak_ingests_the_png_files(tmp_path, tls, capsys):
+    """datasets/kodak/kodak.py:11-106: 24 RGB pictures -> uint8 luminances (24, 512, 768), portrait ones rotated and listed;
+    an existing result is kept; a picture of another size is refused; absent pictures go through `urlretrieve`."""
+    import PIL.Image
+    from autoencoder_based_image_compression_amd.kodak.datasets.kodak import kodak
+    rng = numpy.random.RandomState(12)
+    folder = str(tmp_path/'data')
+    os.makedirs(folder)
+    portrait = (3, 8, 16)
+    pictures = []
+    for i in range(24):
+        shape = (768, 512, 3) if i in portrait else (512, 768, 3)
+        coarse = rng.randint(0, 256, size=(shape[0]//16, shape[1]//16, 3)).astype(numpy.uint8)
+        rgb = numpy.kron(coarse, numpy.ones((16, 16, 1), dtype=numpy.uint8)) ^ rng.randint(0, 4, size=shape).astype(numpy.uint8)
+        pictures.append(rgb)
+        PIL.Image.fromarray(rgb).save(os.path.join(folder, 'kodim{:02d}.png'.format(i + 1)))
+    (path_to_kodak, path_to_list_rotation) = (str(tmp_path/'kodak.npy'), str(tmp_path/'list_rotation.pkl'))
+    kodak.create_kodak('http://127.0.0.1:9/nowhere/', folder, path_to_kodak, path_to_list_rotation)
+    assert capsys.readouterr().out.count('already exists. The image is not downloaded.') == 24
+    reference_uint8 = numpy.load(path_to_kodak)
+    with open(path_to_list_rotation, 'rb') as file:
+        assert pickle.load(file) == list(portrait)
+    assert reference_uint8.dtype == numpy.uint8 and reference_uint8.shape == (24, 512, 768)
+    for (i, rgb) in enumerate(pictures):
+        f = rgb.astype(numpy.float64)
+        y = 16. + (65.481/255.)*f[:, :, 0] + (128.553/255.)*f[:, :, 1] + (24.966/255.)*f[:, :, 2]      # tools.py:1067-1071
+        expected = numpy.round(y.clip(min=0., max=255.)).astype(numpy.uint8)
+        assert numpy.array_equal(reference_uint8[i], numpy.rot90(expected) if i in portrait else expected), i
+    assert reference_uint8.min() >= 16 and reference_uint8.max() <= 235
+    # an existing test set is not rebuilt
+    numpy.save(path_to_kodak, reference_uint8[:1])
+    kodak.create_kodak('http://127.0.0.1:9/nowhere/', folder, path_to_kodak, path_to_list_rotation)
+    assert 'Delete them manually to recreate the Kodak test set.' in capsys.readouterr().out
+    assert numpy.load(path_to_kodak).shape == (1, 512, 768)
+    os.remove(path_to_kodak)
+    # wrong size; wrong mode; missing picture -> the download is attempted, like the reference
+    PIL.Image.fromarray(pictures[0][:100]).save(os.path.join(folder, 'kodim05.png'))
+    with pytest.raises(ValueError):
+        kodak.create_kodak('http://127.0.0.1:9/nowhere/', folder, path_to_kodak, path_to_list_rotation)
+    PIL.Image.fromarray(pictures[0][:, :, 0]).save(os.path.join(folder, 'kodim05.png'))
+    with pytest.raises(ValueError):
+        tls.read_image_mode(os.path.join(folder, 'kodim05.png'), 'RGB')
+    assert tls.read_image_mode(os.path.join(folder, 'kodim05.png'), 'L').shape == (512, 768)
+    os.remove(os.path.join(folder, 'kodim24.png'))
+    with pytest.raises(IOError):
+        kodak.create_kodak('http://127.0.0.1:9/nowhere/', folder, path_to_kodak, path_to_list_rotation)
+    assert not os.path.isfile(path_to_kodak)

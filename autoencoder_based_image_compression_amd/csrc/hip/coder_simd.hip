@@ -16,8 +16,9 @@
 //                one decision per lane and advances a three-register binarisation state (unary count, symbol index).
 //            (4) compare_kernel: decoded == encoded symbols (the assert of lossless/compression.py:146-153).
 //
-// Anything the fast kernels do not handle -- an error of any kind (their exact code and stage matter), more than 47
-// pending E3 bits, a stream longer than its LDS window, L == 0 or L > 32 -- marks the map RETRY, and the general
+// Anything the fast kernels do not handle -- an error of any kind (their exact code and stage matter), a stream longer
+// than the LDS windows (64 / 16 words, 192 / 48 for maps of more than 4096 symbols, then 448 / 96 in a second pass),
+// L == 0 or L > 32 -- marks the map RETRY, and the general
 // per-lane kernel (the shared core of coder_core.h, statement for statement the reference) recodes that map from
 // scratch. Results are therefore identical to the host library's in every case; tests/test_coder_device.py compares
 // bytes, bit counts, symbols, statuses and stages.
@@ -49,6 +50,9 @@ constexpr uint32_t kMaxFastL = 32;        // contexts staged in LDS: 32 x 64 lan
 // 20 KB per block, small enough to sit next to the transform kernels' blocks. Second pass, only for the maps the first
 // one found too long: 14336 + 3072 bits, 136 KB per block (one block per CU).
 constexpr uint32_t kBacWindowWords = 64, kBypassWindowWords = 16;
+// maps of more than kMediumMapSize symbols (latents of images beyond about 1 Mpixel) start with wider windows: their streams
+// would mostly overflow the small ones and the second pass costs a full serial decode of its own
+constexpr uint32_t kBacWindowWordsMedium = 192, kBypassWindowWordsMedium = 48, kMediumMapSize = 4096;
 constexpr uint32_t kBacWindowWordsBig = 448, kBypassWindowWordsBig = 96;
 
 struct SimdParams {
@@ -193,9 +197,9 @@ __global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
     for (uint32_t jb = 0; jb < steps; jb += 8) {
         const unsigned long long d8 = (unsigned long long)ahead.x | ((unsigned long long)ahead.y << 32);
         if (jb + 8 < steps) ahead = *reinterpret_cast<const uint2*>(dec + (size_t)((jb >> 3) + 1u) * 512u);
-        // eight steps emit at most 8 x (16 + 47) bits: near the end of the stream's capacity (Bitstream.cpp:32-35) the map
-        // goes to the general kernel, which reproduces the exact point of failure
-        if (bac.bs.write_index + 8u * 63u > bac.bs.size_bits) retry = true;
+        // eight steps emit at most the pending E3 bits + 8 x (16 leaving bits + 15 new E3 bits): near the end of the stream's
+        // capacity (Bitstream.cpp:32-35) the map goes to the general kernel, which reproduces the exact point of failure
+        if (bac.bs.write_index + e3 + 8u * 31u > bac.bs.size_bits) retry = true;
 #pragma unroll
         for (uint32_t q = 0; q < 8; q++) {
             const uint32_t j = jb + q;
@@ -211,22 +215,32 @@ __global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
                 // E1/E2 in closed form (as Bac::encode): n leading equal bits leave, with the pending E3 bits behind the first
                 const uint32_t diff = (nl ^ nh) & 0xFFFFu;
                 const uint32_t n = diff ? (uint32_t)__builtin_clz(diff) - 16u : 16u;
-                if (e3 > 47u) retry = true;                          // the 64-bit put below holds 1 + 47 + 15 bits
                 if (n && !retry) {
                     const uint32_t out = rev16(nh);
                     const unsigned long long first = out & 1u;
-                    const unsigned long long run = first ? 0ull : ((1ull << e3) - 1ull);
-                    const unsigned long long rest = (out >> 1) & ((1u << (n - 1u)) - 1u);
-                    const unsigned long long bits = first | (run << 1) | (rest << (1u + e3));
-                    const uint32_t cnt = n + e3;
                     Bitstream& bs = bac.bs;
-                    const uint32_t sh = bs.write_index & 63u;
-                    bs.acc |= bits << sh;
-                    if (sh + cnt >= 64u) {
-                        store64(bs.data + ((bs.write_index >> 6) << 3), bs.acc);
-                        bs.acc = sh ? bits >> (64u - sh) : 0ull;
+                    auto put = [&](unsigned long long bits, uint32_t cnt) {     // cnt <= 63 bits, first in time at bit 0
+                        const uint32_t sh = bs.write_index & 63u;
+                        bs.acc |= bits << sh;
+                        if (sh + cnt >= 64u) {
+                            store64(bs.data + ((bs.write_index >> 6) << 3), bs.acc);
+                            bs.acc = sh ? bits >> (64u - sh) : 0ull;
+                        }
+                        bs.write_index += cnt;
+                    };
+                    if (e3 > 47u) {
+                        // a long run of pending E3 bits (maps that are almost all zeros): the leaving bit, then the run in
+                        // pieces, so that the single put below again holds at most 1 + 47 + 15 bits
+                        put(first, 1u);
+                        while (e3 > 32u) { put(first ? 0ull : 0xFFFFFFFFull, 32u); e3 -= 32u; }
+                        const unsigned long long run = first ? 0ull : ((1ull << e3) - 1ull);
+                        const unsigned long long rest = (out >> 1) & ((1u << (n - 1u)) - 1u);
+                        put(run | (rest << e3), n - 1u + e3);
+                    } else {
+                        const unsigned long long run = first ? 0ull : ((1ull << e3) - 1ull);
+                        const unsigned long long rest = (out >> 1) & ((1u << (n - 1u)) - 1u);
+                        put(first | (run << 1) | (rest << (1u + e3)), n + e3);
                     }
-                    bs.write_index += cnt;
                     e3 = 0;
                     nl = (nl << n) & 0xFFFFu;
                     nh = ((nh << n) & 0xFFFFu) | ((1u << n) - 1u);
@@ -502,8 +516,19 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
     if (symbols_out) p.decoded = symbols_out;
     if (!expected) (void)hipMemsetAsync(status, 0, (size_t)n_maps * sizeof(int32_t), s);   // a pure decode starts from a clean slate
     if (fast_applies(L) && map_size) {
-        const size_t lds = (size_t)L * 64u * sizeof(double) + (size_t)(kBacWindowWords + kBypassWindowWords) * 64u * sizeof(uint32_t);
-        hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, false>), dim3((n_maps + 63u) / 64u), dim3(64), lds, s, p);
+        if (map_size > kMediumMapSize) {
+            const size_t lds = (size_t)L * 64u * sizeof(double) +
+                               (size_t)(kBacWindowWordsMedium + kBypassWindowWordsMedium) * 64u * sizeof(uint32_t);
+            static const hipError_t medium_ok = hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, false>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (medium_ok != hipSuccess) return (int)medium_ok;
+            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, false>), dim3((n_maps + 63u) / 64u),
+                               dim3(64), lds, s, p);
+        } else {
+            const size_t lds = (size_t)L * 64u * sizeof(double) + (size_t)(kBacWindowWords + kBypassWindowWords) * 64u * sizeof(uint32_t);
+            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, false>), dim3((n_maps + 63u) / 64u), dim3(64), lds, s, p);
+        }
         // maps whose streams did not fit the small windows: same kernel, big windows (waves with no such map exit at once)
         const size_t lds_big = (size_t)L * 64u * sizeof(double) + (size_t)(kBacWindowWordsBig + kBypassWindowWordsBig) * 64u * sizeof(uint32_t);
         static const hipError_t big_ok = hipFuncSetAttribute(

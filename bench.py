@@ -188,7 +188,8 @@ def main():
     os.environ.setdefault('OMP_NUM_THREADS', str(cores))      # the oracle's OpenMP transforms (cpu_baseline only)
 
     variables = synthetic_model(1.)
-    run = run_pipeline(args, args.batch, args.steps, args.warmup, device, world, rank, cores, tracing, variables)
+    run = run_pipeline(args, args.batch, args.steps, args.warmup, device, world, rank, cores, tracing, variables,
+                       transform_streams=int(os.environ.get('EAE_TRANSFORM_STREAMS', '1')))
     (elapsed, stats, gemm_events, probabilities, map_mean_host) = (run['elapsed'], run['stats'], run['gemm_events'],
                                                                     run['probabilities'], run['map_mean_host'])
     (host_coder, coder_threads, step_marks) = (run['host_coder'], run['coder_threads'], run['step_marks'])

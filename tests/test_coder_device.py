@@ -251,6 +251,48 @@ def test_batch_encoder_and_decoder_equal_the_host_coder(gold, dev, scale):
     assert status[5] != 0 and not numpy.delete(status, 5).any()
 
 
+def test_batch_large_maps_long_pending_runs_and_every_window_tier(gold, dev):
+    """Maps of 128 x 128 latents (a 2048 x 2048 image): near-dead maps under a very skewed p0 build runs of pending E3 bits far
+    beyond 47, and the stream lengths cover the decoder's window tiers (192 / 48 words first for maps this large, 448 / 96
+    in the second pass, the general kernel beyond). Bytes, bit counts and decoded symbols equal the host coder's."""
+    rng = numpy.random.RandomState(77)
+    size = 128*128
+    L = 10
+    n = 70
+    planar = numpy.zeros((n, size), dtype=numpy.int16)
+    probs = numpy.tile(gold['real_probabilities_1'][0], (n, 1))
+    # 0-19: (almost) dead maps, p0 from 0.9 to 0.99999: long runs of identical decisions
+    for m in range(20):
+        probs[m, 0] = 1. - 10.**(-1. - 0.2*m)
+        if m % 2:
+            planar[m, rng.randint(0, size, size=m)] = rng.choice([-2, -1, 1, 3], size=m)
+    # 20-69: densities from a few hundred bits to several times the largest window
+    for m in range(20, n):
+        density = 0.0005*1.25**(m - 20)
+        hits = rng.rand(size) < min(density, 0.9)
+        planar[m, hits] = numpy.clip(numpy.round(rng.laplace(size=int(hits.sum()))*3.), -300, 300).astype(numpy.int16)
+    rows = numpy.arange(n, dtype=numpy.int32)
+    (streams, sym, p, r) = batch_code(dev, planar, probs, rows)
+    ok = assert_equals_host(streams, planar, probs, rows, 'large')
+    assert ok.all()
+    bits = streams.bac_bits.cpu().numpy()
+    assert (bits < 64*32).any() and ((bits > 64*32) & (bits <= 192*32)).any() and ((bits > 192*32) & (bits <= 448*32)).any() \
+        and (bits > 448*32).any(), bits
+    out = dev.coder_decode_batch(streams, p, r).cpu().numpy()
+    assert not streams.status.cpu().numpy().any()
+    assert numpy.array_equal(out, planar)
+    dev.coder_decode_batch(streams, p, r, expected=sym)
+    assert not streams.status.cpu().numpy().any()
+    # one corrupted stream per window tier is found, and only those
+    order = [int(m) for m in numpy.argsort(bits) if bits[m] >= 64]      # the flipped bit must be a coded one
+    victims = [order[0], order[len(order)//2], order[-1]]
+    for m in victims:
+        streams.streams[m, 0] ^= 0x20
+    dev.coder_decode_batch(streams, p, r, expected=sym)
+    status = streams.status.cpu().numpy()
+    assert all(status[m] != 0 for m in victims) and not numpy.delete(status, victims).any()
+
+
 def test_batch_golden_streams_of_the_reference_build(gold, dev):
     for i in range(int(gold['nb_cases'])):
         x = numpy.ascontiguousarray(gold['case{}_in'.format(i)]).reshape(1, -1)

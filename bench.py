@@ -20,8 +20,13 @@ import os
 import sys
 import time
 
-import numpy
-import torch
+# The HIP runtime multiplexes streams onto 4 hardware queues by default; streams that land on the same queue serialise.
+# With a transform stream, 2-3 coder streams and optional extra transform streams that aliasing was measured to cost up to
+# 30 %. Must be set before the runtime initialises; an explicit setting of the caller wins.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+import numpy          # noqa: E402
+import torch          # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -165,6 +170,11 @@ def main():
     parser.add_argument('--coder-threads', type=int, default=0, help='host coder threads (0 = usable CPUs - 2)')
     parser.add_argument('--coder-streams', type=int, default=int(os.environ.get('EAE_CODER_STREAMS', '2')),
                         help='batches whose entropy coding may be in flight at once (each on its own HIP stream)')
+    parser.add_argument('--transform-streams', type=int, default=int(os.environ.get('EAE_TRANSFORM_STREAMS', '1')),
+                        help='1 (default): the transforms of consecutive batches run back to back on one stream, so that the HIP '
+                             'events around a launch time that kernel alone (the roofline figures). 2-3: consecutive batches '
+                             'alternate between private streams and their kernels overlap (fills the tails: +6-8 %% whole-job '
+                             'throughput with --coder-streams 3), but a launch then shares the GPU and its duration says little')
     args = parser.parse_args()
     (H_IN, W_IN) = (args.height, args.width)
 
@@ -189,7 +199,7 @@ def main():
 
     variables = synthetic_model(1.)
     run = run_pipeline(args, args.batch, args.steps, args.warmup, device, world, rank, cores, tracing, variables,
-                       transform_streams=int(os.environ.get('EAE_TRANSFORM_STREAMS', '1')))
+                       transform_streams=args.transform_streams)
     (elapsed, stats, gemm_events, probabilities, map_mean_host) = (run['elapsed'], run['stats'], run['gemm_events'],
                                                                     run['probabilities'], run['map_mean_host'])
     (host_coder, coder_threads, step_marks) = (run['host_coder'], run['coder_threads'], run['step_marks'])

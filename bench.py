@@ -112,7 +112,10 @@ def run_pipeline(args, batch, steps, warmup, device, world, rank, cores, tracing
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if dist.get_backend() == 'nccl':
+                dist.barrier(device_ids=[device.index])      # RCCL: name the device, no guess from the rank
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(warmup):

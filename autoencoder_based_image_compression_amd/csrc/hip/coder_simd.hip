@@ -54,6 +54,10 @@ constexpr uint32_t kBacWindowWords = 64, kBypassWindowWords = 16;
 // would mostly overflow the small ones and the second pass costs a full serial decode of its own
 constexpr uint32_t kBacWindowWordsMedium = 192, kBypassWindowWordsMedium = 48, kMediumMapSize = 4096;
 constexpr uint32_t kBacWindowWordsBig = 448, kBypassWindowWordsBig = 96;
+// dynamic LDS of bac_decode_kernel<WB, WY>: probabilities [L + 1][64] doubles, windows [WB + 3][64] and [WY + 1][64] words
+constexpr size_t decode_lds_bytes(uint32_t L, uint32_t wb, uint32_t wy) {
+    return ((size_t)L + 1u) * 64u * sizeof(double) + ((size_t)wb + 3u + wy + 1u) * 64u * sizeof(uint32_t);
+}
 
 struct SimdParams {
     uint32_t n_maps, map_size, L, dcap;   // dcap: bytes of decision storage per map (multiple of 8)
@@ -280,21 +284,26 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
     const bool in_range = m < p.n_maps;
     const int32_t row = in_range ? (p.prob_row ? p.prob_row[m] : (int32_t)m) : -1;
     const uint32_t L = p.L;
-    double* probs = lds_dyn;                                                        // [context][lane]
-    uint32_t* wbac = reinterpret_cast<uint32_t*>(lds_dyn + (size_t)L * 64u);        // [word][lane]
-    uint32_t* wbyp = wbac + WB * 64u;                                               // [word][lane]
+    // LDS: probabilities [L + 1][lane], arithmetic-coded window [WB + 3][lane], bypass window [WY + 1][lane]. The extra rows
+    // let the step below read one context / up to three words / one word beyond the valid ones without a guard (see
+    // decode_lds_bytes): a zeroed word is what the reference reads beyond the end of a stream anyway.
+    double* probs = lds_dyn;
+    uint32_t* wbac = reinterpret_cast<uint32_t*>(lds_dyn + ((size_t)L + 1u) * 64u);
+    uint32_t* wbyp = wbac + (WB + 3u) * 64u;
     bool live = in_range && row >= 0 && p.status[m] == (SECOND ? RETRY : 0);
     if (SECOND && !__any(live)) return;                  // nothing was handed on to this pass in this group of 64 maps
     const uint32_t nbac = live ? p.bac_bits[m] : 0u;
     const uint32_t nbyp = live ? p.bypass_bits[m] : 0u;
     bool retry = false;
     if (live && (nbac > WB * 32u || nbyp > WY * 32u)) retry = true;   // longer than the window: next pass
-    if (live)
+    if (live) {
         for (uint32_t k = 0; k < L; k++) {
             const double pk = p.probs[(size_t)row * L + k];
             probs[k * 64u + lane] = pk;
             if (!(pk > 0. && pk < 1.)) retry = true;     // only an error if that context is decoded: general kernel
         }
+        probs[L * 64u + lane] = 0.5;                     // read ahead of an escape, never used
+    }
     // stage the streams of the 64 maps: the wave copies one map per iteration, coalesced
     for (uint32_t l = 0; l < 64u; l++) {
         const uint32_t ml = blockIdx.x * 64u + l;
@@ -305,38 +314,67 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
         const uint32_t* srcy = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)ml * p.stride + p.stride / 2);
         for (uint32_t w = lane; w < WY && w * 32u < bits_y; w += 64u) wbyp[w * 64u + l] = srcy[w];
     }
+    {   // zeros behind the last word of this lane's stream: at most three window words are loaded beyond it (a refill happens
+        // at 32 buffered bits or fewer and only stream bits are ever consumed: refills <= bits / 32 + 2)
+        const uint32_t nwords = retry ? 0u : (nbac + 31u) >> 5;
+        for (uint32_t t = 0; t < 3u; t++) wbac[(nwords + t) * 64u + lane] = 0u;
+    }
     __syncthreads();
     int16_t* out = p.decoded + (size_t)(in_range ? m : 0u) * p.map_size;
-    // Bac::start_decoding (BinaryArithmeticCoder.cpp:104-122): 16 bits, the last one repeated once the stream is exhausted
     uint32_t low = 0, high = kRangeMax, code = 0, ridx = 0, yidx = 0;
-    unsigned long long rwin = 0;          // bits [ridx, ridx + rcount) of the arithmetic-coded stream, bit 0 first
+    // rwin: the next rcount bits of the arithmetic-coded stream, LEFT-aligned with the next bit in time at bit 63, so that
+    // "the next k bits, first in time most significant" (what the 16-bit code register wants) is one shift, not a bit reversal
+    unsigned long long rwin = 0;
     uint32_t rcount = 0, rword = 0;       // rword: next dword of the window to load
-    auto refill = [&]() {
-        if (rcount <= 32u) {
-            const uint32_t w = rword < WB && rword * 32u < nbac ? wbac[rword * 64u + lane] : 0u;
-            rwin |= (unsigned long long)w << rcount;
-            rcount += 32u;
-            rword++;
-        }
+    auto refill = [&]() {                 // 32 more bits once at most 32 are left, zeros beyond the stream
+        const bool need = rcount <= 32u;
+        const bool have = rword < WB && rword * 32u < nbac;
+        const uint32_t w = wbac[(have ? rword : 0u) * 64u + lane];
+        rwin |= (unsigned long long)(need && have ? __builtin_bitreverse32(w) : 0u) << (need ? 32u - rcount : 0u);
+        rcount += need ? 32u : 0u;
+        rword += need ? 1u : 0u;
+    };
+    auto take = [&](uint32_t k) {         // k <= 16 bits off the window (k == 0: nothing, returns 0)
+        const uint32_t bits = (uint32_t)((rwin >> 1) >> (63u - k));
+        rwin <<= k;
+        rcount -= k;
+        return bits;
     };
     bool active = live && !retry;
     if (active) {
+        // Bac::start_decoding (BinaryArithmeticCoder.cpp:104-122): 16 bits, the last one repeated once the stream is exhausted
         refill();
         const uint32_t k = nbac < 16u ? nbac : 16u;
-        uint32_t bits = k ? rev16((uint32_t)rwin & ((1u << k) - 1u)) >> (16u - k) : 0u;
-        const uint32_t sticky = k ? (bits & 1u) : 0u;
-        if (k < 16u) bits = (bits << (16u - k)) | (sticky ? ((1u << (16u - k)) - 1u) : 0u);
+        uint32_t bits = take(k);
+        const uint32_t sticky = bits & 1u;
+        bits = (bits << (16u - k)) | (sticky ? ((1u << (16u - k)) - 1u) : 0u);
         code = bits;
-        rwin >>= k;
-        rcount -= k;
         ridx = k;
     }
     uint32_t unary = 0, i = 0;
     const uint32_t size = p.map_size;
     if (size == 0) active = false;
+    // One decision per lane per iteration. The body is written without lane-divergent branches except for the rare events
+    // (E3 scalings, Exp-Golomb escapes): a lone wavefront issues an instruction every 6-7 cycles, so the length of this loop
+    // IS the decoder's speed, and every divergent `if` costs a handful of scalar mask instructions on top of its body.
+    // The three LDS reads of a step are issued one step ahead of their use (the window word of the next refill, the
+    // probability of the context the next decision will be in if this one is a one, the bypass word holding the next sign
+    // bit): none of their latencies sits in the decision -> decision dependency chain.
+    const double p0 = active ? probs[lane] : 0.5;
+    double pk = p0;
+    uint32_t wnext = active ? wbac[rword * 64u + lane] : 0u;
+    uint32_t err = 0;
     while (active) {
-        refill();
-        const double pk = probs[unary * 64u + lane];
+        {   // refill: 32 more bits once at most 32 are left, zeros beyond the stream
+            const bool need = rcount <= 32u;
+            rwin |= (unsigned long long)(need ? __builtin_bitreverse32(wnext) : 0u) << (need ? 32u - rcount : 0u);
+            rcount += need ? 32u : 0u;
+            rword += need ? 1u : 0u;
+        }
+        const uint32_t wload = wbac[rword * 64u + lane];
+        const double pspec = probs[(unary + 1u) * 64u + lane];
+        const uint32_t yrow = yidx >> 5;
+        uint32_t yword = wbyp[(yrow < WY ? yrow : WY) * 64u + lane];
         // Bac::decode (BinaryArithmeticCoder.cpp:124-134, 254-320) with the closed-form renormalisation of coder_core.h
         const uint32_t mid = low + (uint32_t)(pk * (double)(high - low));
         const uint32_t bit = code > mid ? 1u : 0u;
@@ -344,29 +382,28 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
         uint32_t nh = bit ? high : mid;
         const uint32_t diff = (nl ^ nh) & 0xFFFFu;
         const uint32_t n = diff ? (uint32_t)__builtin_clz(diff) - 16u : 16u;
-        uint32_t sticky = 0;
+        uint32_t sticky;
         {
             const uint32_t avail = nbac - ridx;
             const uint32_t k = n < avail ? n : avail;
-            uint32_t bits = k ? rev16((uint32_t)rwin & ((1u << k) - 1u)) >> (16u - k) : 0u;
-            if (k) sticky = bits & 1u;
-            if (k < n) bits = (bits << (n - k)) | (sticky ? ((1u << (n - k)) - 1u) : 0u);
-            rwin >>= k;
-            rcount -= k;
+            uint32_t bits = take(k);                                       // first in time most significant
+            sticky = bits & 1u;
+            const uint32_t ext = n - k;                                    // bits wanted beyond the end: the last one repeats
+            bits = (bits << ext) | (sticky ? ((1u << ext) - 1u) : 0u);
             ridx += k;
             nl = (nl << n) & kRangeMax;
             nh = ((nh << n) & kRangeMax) | ((1u << n) - 1u);
             code = ((code << n) & kRangeMax) | bits;
         }
+        // E3: at most 15 scalings follow a decision and at least 17 bits are buffered here (33 after the refill, 16 leave
+        // above), so the window never runs dry inside this loop
         while (nh <= kRangeThreeQuarters && nl > kRangeQuarter && nh > kRangeHalf && nl <= kRangeHalf) {
             nh -= kRangeQuarter + 1u; nl -= kRangeQuarter + 1u; code -= kRangeQuarter + 1u;
-            if (ridx < nbac) {
-                if (rcount == 0) refill();
-                sticky = (uint32_t)rwin & 1u;
-                rwin >>= 1;
-                rcount--;
-                ridx++;
-            }
+            const uint32_t more = ridx < nbac ? 1u : 0u;
+            sticky = more ? (uint32_t)(rwin >> 63) : sticky;
+            rwin <<= more;
+            rcount -= more;
+            ridx += more;
             nh = ((nh << 1) & kRangeMax) | 1u;
             nl = (nl << 1) & kRangeMax;
             code = ((code << 1) & kRangeMax) | sticky;
@@ -374,50 +411,46 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
         low = nl;
         high = nh;
         // binarisation state (LosslessCoder.cpp:193-230, 254-276): a one advances the unary count up to L, a zero ends it
-        bool symbol_done = false;
-        uint32_t a = 0;
-        if (bit) {
-            unary++;
-            if (unary == L) { symbol_done = true; a = L; }
-        } else {
-            symbol_done = true;
-            a = unary;
-        }
-        if (symbol_done) {
-            if (a == L) {
-                // Exp-Golomb suffix from the bypass stream (LosslessCoder.cpp:113-165)
-                uint32_t nn = 0;
-                bool bad = false;
-                for (;;) {
-                    if (yidx >= nbyp) { bad = true; break; }
-                    const uint32_t b = (wbyp[(yidx >> 5) * 64u + lane] >> (yidx & 31u)) & 1u;
-                    yidx++;
-                    if (!b) break;
-                    nn++;
-                    if (nn > 16u) { bad = true; break; }
-                }
-                uint32_t suffix = 0;
-                for (uint32_t q = 0; q < nn && !bad; q++) {
-                    if (yidx >= nbyp) { bad = true; break; }
-                    suffix = (suffix << 1) | ((wbyp[(yidx >> 5) * 64u + lane] >> (yidx & 31u)) & 1u);
-                    yidx++;
-                }
-                if (bad) { retry = true; break; }
-                a = (L + ((suffix + (1u << nn) - 1u) & 0xFFFFu)) & 0xFFFFu;    // uint16 arithmetic of the reference
-            }
-            int v = (int)(int16_t)a;
-            if (v != 0) {
-                if (yidx >= nbyp) { retry = true; break; }       // resource_error -> general kernel for the exact status
+        const bool escape = bit && unary + 1u == L;
+        const bool done = !bit || escape;
+        uint32_t a = bit ? L : unary;
+        bool bad = false;
+        if (escape) {
+            // Exp-Golomb suffix from the bypass stream (LosslessCoder.cpp:113-165)
+            uint32_t nn = 0;
+            for (;;) {
+                if (yidx >= nbyp) { bad = true; break; }
                 const uint32_t b = (wbyp[(yidx >> 5) * 64u + lane] >> (yidx & 31u)) & 1u;
                 yidx++;
-                if (!b) v = -v;
+                if (!b) break;
+                nn++;
+                if (nn > 16u) { bad = true; break; }
             }
-            out[i] = (int16_t)v;
-            i++;
-            unary = 0;
-            if (i == size) active = false;
+            uint32_t suffix = 0;
+            for (uint32_t q = 0; q < nn && !bad; q++) {
+                if (yidx >= nbyp) { bad = true; break; }
+                suffix = (suffix << 1) | ((wbyp[(yidx >> 5) * 64u + lane] >> (yidx & 31u)) & 1u);
+                yidx++;
+            }
+            a = (L + ((suffix + (1u << nn) - 1u) & 0xFFFFu)) & 0xFFFFu;    // uint16 arithmetic of the reference
+            yword = wbyp[((yidx >> 5) < WY ? (yidx >> 5) : WY) * 64u + lane];   // the sign now sits further on
+            if (bad) err = 1u;
         }
+        int v = (int)(int16_t)a;
+        // sign bit of a non-zero symbol (LosslessCoder.cpp:39-56). A sign missing from the bypass stream (resource_error) is
+        // noticed after the loop (yidx > nbyp): the lane runs on over zero bits and the general kernel reports the exact status
+        const bool nonzero = done && v != 0;
+        const uint32_t sign = (yword >> (yidx & 31u)) & 1u;
+        v = nonzero && !sign ? -v : v;
+        yidx += nonzero ? 1u : 0u;
+        if (done) out[i] = (int16_t)v;
+        i += done ? 1u : 0u;
+        unary = done ? 0u : unary + 1u;
+        pk = done ? p0 : pspec;
+        wnext = wload;
+        active = i < size && err == 0u;
     }
+    if (live && !retry && (err != 0u || yidx > nbyp || i < size)) retry = true;   // something only the general kernel reports
     if (live) p.status[m] = retry ? RETRY : 0;
 }
 
@@ -517,8 +550,7 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
     if (!expected) (void)hipMemsetAsync(status, 0, (size_t)n_maps * sizeof(int32_t), s);   // a pure decode starts from a clean slate
     if (fast_applies(L) && map_size) {
         if (map_size > kMediumMapSize) {
-            const size_t lds = (size_t)L * 64u * sizeof(double) +
-                               (size_t)(kBacWindowWordsMedium + kBypassWindowWordsMedium) * 64u * sizeof(uint32_t);
+            const size_t lds = decode_lds_bytes(L, kBacWindowWordsMedium, kBypassWindowWordsMedium);
             static const hipError_t medium_ok = hipFuncSetAttribute(
                 reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, false>),
                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -526,11 +558,11 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
             hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, false>), dim3((n_maps + 63u) / 64u),
                                dim3(64), lds, s, p);
         } else {
-            const size_t lds = (size_t)L * 64u * sizeof(double) + (size_t)(kBacWindowWords + kBypassWindowWords) * 64u * sizeof(uint32_t);
+            const size_t lds = decode_lds_bytes(L, kBacWindowWords, kBypassWindowWords);
             hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, false>), dim3((n_maps + 63u) / 64u), dim3(64), lds, s, p);
         }
         // maps whose streams did not fit the small windows: same kernel, big windows (waves with no such map exit at once)
-        const size_t lds_big = (size_t)L * 64u * sizeof(double) + (size_t)(kBacWindowWordsBig + kBypassWindowWordsBig) * 64u * sizeof(uint32_t);
+        const size_t lds_big = decode_lds_bytes(L, kBacWindowWordsBig, kBypassWindowWordsBig);
         static const hipError_t big_ok = hipFuncSetAttribute(
             reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsBig, kBypassWindowWordsBig, true>),
             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);

@@ -16,7 +16,8 @@ inputs (tests/test_gpu_codec.py); `bench.py` times exactly this class.
 Concurrency: the coder is a few latency-bound wavefronts, so its launches go to side streams and overlap the synthesis
 transforms of the same batch and the analysis transforms of the next ones; `nb_in_flight` batches of coder work may be
 pending. Buffers that cross streams are preallocated per slot; results reach the host through a kernel that writes pinned
-memory (no hipMemcpyAsync on the launch thread) and a worker thread turns them into per-image numbers.
+memory (no hipMemcpyAsync on the launch thread) and a worker thread turns them into per-image numbers. For small batches the
+step can be replayed as three hipGraphs per slot (`use_graphs`) over several transform streams (`nb_transform_streams`).
 """
 import queue
 import threading
@@ -118,17 +119,22 @@ class BatchCodec(object):
 
     def __init__(self, variables, are_bin_widths_learned, bin_widths_test, map_mean, binary_probabilities, idx_map_exception,
                  batch_size, h_in, w_in, device='cuda', nb_in_flight=2, keep_reconstruction=False, launch_hook=None,
-                 coder='device', host_coder_threads=0, hist_radius=2047, nb_transform_streams=1):
+                 coder='device', host_coder_threads=0, hist_radius=2047, nb_transform_streams=1, use_graphs=False):
         """coder: 'device' (the coder kernels on side streams), 'host' (ONE device -> host copy of the symbols per batch, then
         the host C-ABI coder `eae_coder_compress_maps` on `host_coder_threads` threads: the shape BASELINE.json sketches) or
         'none' (transforms only; the bit counts come back as zeros).
         nb_transform_streams: 1 = the transforms run on the caller's current stream; more = consecutive batches alternate
         between that many private streams (worth it only for small batches, whose kernels leave most of the GPU idle).
+        use_graphs: capture the launches of one step into three hipGraphs per slot on first use (analysis side, coder,
+        synthesis side) and replay them afterwards: three host launches per step instead of about twenty. For small batches, where the launch thread is the
+        bottleneck (one Kodak image per step); `launch_hook` is not called for replayed steps. Not for coder='host'.
         hist_radius: the exception map's entropy is formed from an exact histogram of its symbols over [-hist_radius,
         hist_radius]; a symbol outside it makes `Ticket.result()` raise (the image-by-image functions of `kodak/` widen the
         histogram instead)."""
         if coder not in ('device', 'host', 'none'):
             raise ValueError('`coder` is neither "device" nor "host" nor "none".')
+        if use_graphs and coder == 'host':
+            raise ValueError('`use_graphs` needs the coder on the device (or none).')
         if h_in % csts.STRIDE_PROD != 0 or w_in % csts.STRIDE_PROD != 0:
             raise ValueError('The image size is not divisible by the product of the three strides.')
         self.device = torch.device(device)
@@ -188,6 +194,11 @@ class BatchCodec(object):
                                host_coder_threads)
         self._worker.start()
         self._index = 0
+        self.use_graphs = bool(use_graphs)
+        self._graphs = [None]*self.nb_slots          # per slot: (three graphs, static input, latents, reconstruction)
+        self._warm = False
+        if self.use_graphs and not self._transform_streams:
+            self._transform_streams = _side_streams(nb_in_flight + 1)[nb_in_flight:]     # replays never go to the caller's stream
 
     def _views(self, t):
         out = []
@@ -207,6 +218,8 @@ class BatchCodec(object):
             raise TypeError('`luminances_uint8.dtype` is not equal to `torch.uint8`.')
         if tuple(luminances_uint8.shape) != (self.batch_size, self.h_in, self.w_in):
             raise ValueError('`luminances_uint8.shape` is not (batch_size, h_in, w_in).')
+        if self.use_graphs:
+            return self._submit_graph(luminances_uint8)
         if not self._transform_streams:
             return self._submit(luminances_uint8)
         # small batches leave most of the GPU idle and a step is a chain of short dependent kernels: consecutive batches go
@@ -218,52 +231,72 @@ class BatchCodec(object):
         luminances_uint8.record_stream(stream)
         return ticket
 
+    def _submit_graph(self, luminances_uint8):
+        """One step = three hipGraph launches: the analysis side (conv1 .. symbols) and the synthesis side on a transform
+        stream, the coder on a coder stream between two events, exactly the stream structure of the launch-by-launch path.
+        Slot s owns its buffers (symbols, streams, result blocks), so it owns its three graphs too: captured the first time the
+        slot comes up (after one ordinary step that gets every lazy initialisation out of the way), replayed afterwards."""
+        if not self._warm:
+            self._warm = True
+            self._submit(luminances_uint8).result()          # first launches: function attributes, lazy module loads
+        slot = self._index % self.nb_slots
+        stream = self._transform_streams[self._index % len(self._transform_streams)]
+        coder_stream = self._streams[self._index % len(self._streams)]
+        self._index += 1
+        self._slot_free[slot].wait()
+        self._slot_free[slot].clear()
+        caller = torch.cuda.current_stream()
+        if self._graphs[slot] is None:
+            static_input = torch.empty_like(luminances_uint8)
+            caller.synchronize()
+            graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
+            with torch.cuda.graph(graphs[0], stream=stream):
+                latents = self._launch_analysis(static_input, slot, None)
+            with torch.cuda.graph(graphs[1], stream=coder_stream):
+                self._launch_coder(slot)
+            with torch.cuda.graph(graphs[2], stream=stream):
+                reconstruction = self._launch_synthesis(latents, static_input, slot, None)
+            self._graphs[slot] = (graphs, static_input, latents, reconstruction)
+        (graphs, static_input, _, reconstruction) = self._graphs[slot]
+        stream.wait_stream(caller)
+        with torch.cuda.stream(stream):
+            static_input.copy_(luminances_uint8, non_blocking=True)
+            graphs[0].replay()
+            quantized = torch.cuda.Event()
+            quantized.record()
+        with torch.cuda.stream(coder_stream):
+            coder_stream.wait_event(quantized)
+            graphs[1].replay()
+            coded = torch.cuda.Event()
+            coded.record()
+        with torch.cuda.stream(stream):
+            graphs[2].replay()
+            decoded = torch.cuda.Event()
+            decoded.record()
+        luminances_uint8.record_stream(stream)
+        ticket = Ticket(self.batch_size)
+        if self.keep_reconstruction:
+            ticket.reconstruction_uint8 = reconstruction       # valid until this slot is replayed again
+        self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],), None,
+                               self._slot_free[slot]))
+        return ticket
+
     def _submit(self, luminances_uint8):
-        hook = self.launch_hook
-        (enc, dec) = (self.encoder, self.decoder)
-        (v, d) = (enc.v, dec.v)
-        gdn_1 = dev.conv9x9s4_u8(luminances_uint8, enc.w1, v['encoder/biases_1'], enc.g[1], v['encoder/beta_1'])
-        gdn_2 = hook('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, enc.w2, v['encoder/biases_2'], dev.NORM_GDN, enc.g[2], v['encoder/beta_2']))
-        y_raw = hook('conv3', lambda: dev.conv5x5s2(gdn_2, enc.w3, v['encoder/biases_3'], dev.NORM_NONE))
         slot = self._index % self.nb_slots
         stream = self._streams[self._index % len(self._streams)]
         self._index += 1
         self._slot_free[slot].wait()
         self._slot_free[slot].clear()
-        (results, hist, overflow, flags, checks) = self._views(self._slot_out[slot])
-        self._slot_all[slot][4*self._n_maps:].zero_()    # histograms, overflow, flags, checks, squared errors: accumulated into
-        # gdn_3 -> centre / quantise / symbols / dead-map flags -> de-centre -> inverse_gdn_4: one pass over the latents
-        q = dev.latent_stage(y_raw, self.bin_widths, self.map_mean,
-                             gdn_in=None if self.learned else (enc.g[3], v['encoder/beta_3']),
-                             igdn_out=None if self.learned else (dec.g[4], d['decoder/beta_4']),
-                             want_shifted=self.learned, want_symbols=True, want_flags=True, out_symbols=self._symbols[slot],
-                             out_flags=flags, out_checks=checks[:3])
-        symbols = self._symbols[slot].view(self._n_maps, self.map_size)
-        if self.idx_map_exception >= 0:
-            dev.symbol_histograms(symbols, self.hist_radius, out=(hist, overflow), first_map=self.idx_map_exception,
-                                  map_step=self.nb_maps, zero=False)
+        hook = self.launch_hook
+        latents = self._launch_analysis(luminances_uint8, slot, hook)
         quantized = torch.cuda.Event()
         quantized.record()
         with torch.cuda.stream(stream):
             stream.wait_event(quantized)
-            if self.coder == 'device':
-                dev.coder_encode_batch(symbols, self.probabilities, self.prob_row, self.truncated_unary_length,
-                                       out=self._coder_streams[slot], workspace=self._workspaces[slot])
-                dev.coder_decode_batch(self._coder_streams[slot], self.probabilities, self.prob_row, expected=symbols,
-                                       workspace=self._workspaces[slot])
-            elif self.coder == 'host':
-                self._pinned_symbols[slot].copy_(self._symbols[slot], non_blocking=True)
-            else:
-                results.zero_()
-            dev.publish_to_host(self._slot_out[slot], self._pinned_out[slot])
+            self._launch_coder(slot)
             coded = torch.cuda.Event()
             coded.record()
-        t = q['shifted'] if self.learned else q['t']
-        t = hook('tconv1_igdn5', lambda: dev.tconv5x5s2(t, dec.w4, d['decoder/biases_4'], dev.NORM_IGDN, dec.g[5], d['decoder/beta_5']))
-        t = hook('tconv2_igdn6', lambda: dev.tconv5x5s2(t, dec.w5, d['decoder/biases_5'], dev.NORM_IGDN, dec.g[6], d['decoder/beta_6']))
-        (_, reconstruction, _) = dev.tconv9x9s4_luma(t, dec.w6, want_f32=False, want_u8=True, ref_u8=luminances_uint8,
-                                                     sse=self._slot_sse[slot])
-        dev.publish_to_host(self._slot_sse[slot], self._pinned_sse[slot])
+        reconstruction = self._launch_synthesis(latents, luminances_uint8, slot, hook)
         decoded = torch.cuda.Event()
         decoded.record()
         ticket = Ticket(self.batch_size)
@@ -272,6 +305,61 @@ class BatchCodec(object):
         self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],),
                                self._pinned_symbols[slot], self._slot_free[slot]))
         return ticket
+
+    @staticmethod
+    def _no_hook(name, fn):
+        return fn()
+
+    def _launch_analysis(self, luminances_uint8, slot, hook):
+        """conv1+GDN1 -> conv2+GDN2 -> conv3 -> latent stage (symbols, dead-map flags, decoder input) -> exception-map
+        histograms, on the current stream. Returns the synthesis transform's input."""
+        hook = hook or self._no_hook
+        enc = self.encoder
+        v = enc.v
+        d = self.decoder.v
+        gdn_1 = dev.conv9x9s4_u8(luminances_uint8, enc.w1, v['encoder/biases_1'], enc.g[1], v['encoder/beta_1'])
+        gdn_2 = hook('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, enc.w2, v['encoder/biases_2'], dev.NORM_GDN, enc.g[2], v['encoder/beta_2']))
+        y_raw = hook('conv3', lambda: dev.conv5x5s2(gdn_2, enc.w3, v['encoder/biases_3'], dev.NORM_NONE))
+        (_, hist, overflow, flags, checks) = self._views(self._slot_out[slot])
+        self._slot_all[slot][4*self._n_maps:].zero_()    # histograms, overflow, flags, checks, squared errors: accumulated into
+        # gdn_3 -> centre / quantise / symbols / dead-map flags -> de-centre -> inverse_gdn_4: one pass over the latents
+        q = dev.latent_stage(y_raw, self.bin_widths, self.map_mean,
+                             gdn_in=None if self.learned else (enc.g[3], v['encoder/beta_3']),
+                             igdn_out=None if self.learned else (self.decoder.g[4], d['decoder/beta_4']),
+                             want_shifted=self.learned, want_symbols=True, want_flags=True, out_symbols=self._symbols[slot],
+                             out_flags=flags, out_checks=checks[:3])
+        if self.idx_map_exception >= 0:
+            dev.symbol_histograms(self._symbols[slot].view(self._n_maps, self.map_size), self.hist_radius, out=(hist, overflow),
+                                  first_map=self.idx_map_exception, map_step=self.nb_maps, zero=False)
+        return q['shifted'] if self.learned else q['t']
+
+    def _launch_coder(self, slot):
+        """The lossless coder over the slot's symbols (encode every map, decode it back, compare) and the publication of the
+        slot's result block, on the current stream."""
+        symbols = self._symbols[slot].view(self._n_maps, self.map_size)
+        if self.coder == 'device':
+            dev.coder_encode_batch(symbols, self.probabilities, self.prob_row, self.truncated_unary_length,
+                                   out=self._coder_streams[slot], workspace=self._workspaces[slot])
+            dev.coder_decode_batch(self._coder_streams[slot], self.probabilities, self.prob_row, expected=symbols,
+                                   workspace=self._workspaces[slot])
+        elif self.coder == 'host':
+            self._pinned_symbols[slot].copy_(self._symbols[slot], non_blocking=True)
+        else:
+            self._views(self._slot_out[slot])[0].zero_()
+        dev.publish_to_host(self._slot_out[slot], self._pinned_out[slot])
+
+    def _launch_synthesis(self, latents, luminances_uint8, slot, hook):
+        """tconv1+IGDN5 -> tconv2+IGDN6 -> tconv3 + BT.601 cast + squared error against the input, and the publication of the
+        squared errors, on the current stream. Returns the uint8 reconstruction."""
+        hook = hook or self._no_hook
+        dec = self.decoder
+        d = dec.v
+        t = hook('tconv1_igdn5', lambda: dev.tconv5x5s2(latents, dec.w4, d['decoder/biases_4'], dev.NORM_IGDN, dec.g[5], d['decoder/beta_5']))
+        t = hook('tconv2_igdn6', lambda: dev.tconv5x5s2(t, dec.w5, d['decoder/biases_5'], dev.NORM_IGDN, dec.g[6], d['decoder/beta_6']))
+        (_, reconstruction, _) = dev.tconv9x9s4_luma(t, dec.w6, want_f32=False, want_u8=True, ref_u8=luminances_uint8,
+                                                     sse=self._slot_sse[slot])
+        dev.publish_to_host(self._slot_sse[slot], self._pinned_sse[slot])
+        return reconstruction
 
     def drain(self):
         """Waits until every submitted batch is through."""

@@ -22,8 +22,9 @@ import time
 
 # The HIP runtime multiplexes streams onto 4 hardware queues by default; streams that land on the same queue serialise.
 # With a transform stream, 2-3 coder streams and optional extra transform streams that aliasing was measured to cost up to
-# 30 %. Must be set before the runtime initialises; an explicit setting of the caller wins.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# 30 % (and the one-image-per-step leg keeps 14 streams busy). Must be set before the runtime initialises; an explicit
+# setting of the caller wins.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 
 import numpy          # noqa: E402
 import torch          # noqa: E402
@@ -75,7 +76,7 @@ def synthetic_model(bin_width=1.):
 
 
 def run_pipeline(args, batch, steps, warmup, device, world, rank, cores, tracing, variables, coder_streams=None,
-                 transform_streams=1):
+                 transform_streams=1, use_graphs=False):
     """Builds the resident state for `batch` images per step (codec.BatchCodec: weights, tables, per-slot buffers), runs
     `warmup` untimed and `steps` timed steps, and returns what the report needs. Everything in here up to the first barrier
     is outside the timed region."""
@@ -108,7 +109,7 @@ def run_pipeline(args, batch, steps, warmup, device, world, rank, cores, tracing
     the_codec = codec.BatchCodec(variables, False, variables[var.BIN_WIDTHS_NAME], map_mean_host, probabilities, IDX_MAP_EXCEPTION,
                                  batch, H_IN, W_IN, device=device, nb_in_flight=coder_streams or args.coder_streams,
                                  launch_hook=timed_launch, coder=coder_mode, host_coder_threads=coder_threads,
-                                 nb_transform_streams=transform_streams)
+                                 nb_transform_streams=transform_streams, use_graphs=use_graphs)
 
     def barrier():
         if world > 1:
@@ -178,6 +179,9 @@ def main():
                              'events around a launch time that kernel alone (the roofline figures). 2-3: consecutive batches '
                              'alternate between private streams and their kernels overlap (fills the tails: +6-8 %% whole-job '
                              'throughput with --coder-streams 3), but a launch then shares the GPU and its duration says little')
+    parser.add_argument('--graphs', action='store_true',
+                        help='replay one captured hipGraph per step instead of launching kernel by kernel (small batches: the '
+                             'launch thread is the bottleneck there). No per-launch events, so no roofline figures')
     args = parser.parse_args()
     (H_IN, W_IN) = (args.height, args.width)
 
@@ -202,7 +206,7 @@ def main():
 
     variables = synthetic_model(1.)
     run = run_pipeline(args, args.batch, args.steps, args.warmup, device, world, rank, cores, tracing, variables,
-                       transform_streams=args.transform_streams)
+                       transform_streams=args.transform_streams, use_graphs=args.graphs)
     (elapsed, stats, gemm_events, probabilities, map_mean_host) = (run['elapsed'], run['stats'], run['gemm_events'],
                                                                     run['probabilities'], run['map_mean_host'])
     (host_coder, coder_threads, step_marks) = (run['host_coder'], run['coder_threads'], run['step_marks'])
@@ -258,10 +262,12 @@ def main():
     if rank == 0 and world == 1 and args.batch != 1 and not args.no_single_image and (H_IN, W_IN) == (512, 768):
         # BASELINE.json configs[1] is ONE Kodak image: the same path with one image per step (launch-bound, not the headline)
         del run, gemm_events
-        one = run_pipeline(args, 1, 300, 30, device, world, rank, cores, False, variables, coder_streams=3)
+        one = run_pipeline(args, 1, 300, 30, device, world, rank, cores, False, variables, coder_streams=8, transform_streams=6,
+                           use_graphs=True)
         line['single_image'] = {'ms_per_image': round(one['elapsed']/300*1e3, 4),
                                 'mpixels_per_s': round(300*H_IN*W_IN/one['elapsed']/1e6, 2), 'steps': 300, 'warmup': 30,
-                                'note': 'one 512x768 image per step, steps pipelined back to back; host launch overhead dominates'}
+                                'note': 'one 512x768 image per step; a step is a chain of short latency-bound kernels, so steps '
+                                        'are pipelined: 6 transform streams, 8 coder streams, three hipGraph launches per step'}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(variables, probabilities, map_mean_host, cores)

@@ -113,3 +113,44 @@ def test_batch_codec_on_tiny_images(tmp_path, shape):
     assert numpy.array_equal(r['nb_bits'], nb_bits) and numpy.array_equal(r['nb_deads'], nb_deads)
     assert numpy.array_equal(ticket.reconstruction_uint8.cpu().numpy(), rec)
     c.close()
+
+
+@pytest.mark.parametrize('learned', [False, True])
+def test_batch_codec_graph_replay_equals_the_launch_by_launch_path(learned):
+    """use_graphs: a step captured into one hipGraph per slot and replayed (with the coder as a forked branch) gives the same
+    bits, squared errors, dead maps and reconstructions as the same codec launching kernel by kernel; replays of a slot with
+    different images do not leak into each other."""
+    from autoencoder_based_image_compression_amd import codec
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    with numpy.load(GOLD) as g:
+        probabilities = g['real_probabilities_1']
+    rng = numpy.random.RandomState(23)
+    v = var.random_variables(1., learned, seed=6, bias_std=0.01)
+    v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
+    images = torch.from_numpy(rng.randint(16, 236, size=(20, 64, 96)).astype(numpy.uint8)).cuda()
+    bin_widths = rng.uniform(0.6, 1.4, size=128).astype(numpy.float32)
+    map_mean = rng.normal(scale=0.05, size=128).astype(numpy.float32)
+    plain = codec.BatchCodec(v, learned, bin_widths, map_mean, probabilities, 67, 2, 64, 96, keep_reconstruction=True)
+    expected = []
+    for k in range(10):
+        t = plain.submit(images[2*k:2*k + 2])
+        expected.append((t.result(), t.reconstruction_uint8.cpu().numpy()))
+    plain.close()
+    graphed = codec.BatchCodec(v, learned, bin_widths, map_mean, probabilities, 67, 2, 64, 96, keep_reconstruction=True,
+                               use_graphs=True, nb_transform_streams=2)
+    order = list(range(10)) + [3, 9, 0, 5, 5, 1]                  # 16 steps over 4 slots: every graph is replayed several times
+    for start in range(0, len(order), 3):
+        chunk = order[start:start + 3]
+        tickets = [graphed.submit(images[2*k:2*k + 2]) for k in chunk]           # up to three steps in flight
+        for (k, t) in zip(chunk, tickets):
+            r = t.result()
+            for key in ('nb_bits', 'coder_bits', 'exception_bits', 'sse', 'nb_deads'):
+                assert numpy.array_equal(r[key], expected[k][0][key]), (k, key)
+    # the reconstruction of a replayed slot is that step's until the slot comes up again
+    t = graphed.submit(images[8:10])
+    t.result()
+    assert numpy.array_equal(t.reconstruction_uint8.cpu().numpy(), expected[4][1])
+    assert all(g is not None for g in graphed._graphs)
+    graphed.close()
+    with pytest.raises(ValueError):
+        codec.BatchCodec(v, learned, bin_widths, map_mean, probabilities, 67, 2, 64, 96, coder='host', use_graphs=True)

@@ -16,9 +16,9 @@
 //                one decision per lane and advances a three-register binarisation state (unary count, symbol index).
 //            (4) compare_kernel: decoded == encoded symbols (the assert of lossless/compression.py:146-153).
 //
-// Anything the fast kernels do not handle -- an error of any kind (their exact code and stage matter), a stream longer
-// than the LDS windows (64 / 16 words, 192 / 48 for maps of more than 4096 symbols, then 448 / 96 in a second pass),
-// L == 0 or L > 32 -- marks the map RETRY, and the general
+// A stream longer than the decoder's LDS windows (64 / 16 words; 192 / 48 for maps of more than 4096 symbols) is decoded by
+// a second launch of the same kernel that reads the words beyond the window from memory. Anything else the fast kernels do
+// not handle -- an error of any kind (their exact code and stage matter), L == 0 or L > 32 -- marks the map RETRY, and the general
 // per-lane kernel (the shared core of coder_core.h, statement for statement the reference) recodes that map from
 // scratch. Results are therefore identical to the host library's in every case; tests/test_coder_device.py compares
 // bytes, bit counts, symbols, statuses and stages.
@@ -53,7 +53,6 @@ constexpr uint32_t kBacWindowWords = 64, kBypassWindowWords = 16;
 // maps of more than kMediumMapSize symbols (latents of images beyond about 1 Mpixel) start with wider windows: their streams
 // would mostly overflow the small ones and the second pass costs a full serial decode of its own
 constexpr uint32_t kBacWindowWordsMedium = 192, kBypassWindowWordsMedium = 48, kMediumMapSize = 4096;
-constexpr uint32_t kBacWindowWordsBig = 448, kBypassWindowWordsBig = 96;
 // dynamic LDS of bac_decode_kernel<WB, WY>: probabilities [L + 1][64] doubles, windows [WB + 3][64] and [WY + 1][64] words
 constexpr size_t decode_lds_bytes(uint32_t L, uint32_t wb, uint32_t wy) {
     return ((size_t)L + 1u) * 64u * sizeof(double) + ((size_t)wb + 3u + wy + 1u) * 64u * sizeof(uint32_t);
@@ -290,12 +289,20 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
     double* probs = lds_dyn;
     uint32_t* wbac = reinterpret_cast<uint32_t*>(lds_dyn + ((size_t)L + 1u) * 64u);
     uint32_t* wbyp = wbac + (WB + 3u) * 64u;
+    // First pass (SECOND == false): the streams of the 64 maps must fit the LDS windows of WB / WY words; a map whose streams
+    // do not is marked RETRY. Second pass (same windows, so the same modest LDS request: a launch that asks for most of a
+    // CU's LDS waits for a CU to drain, 0.2 ms next to the transforms even when it has nothing to do): only the RETRY maps,
+    // and a lane whose stream is longer than the window fetches the words beyond it from memory itself, one load per word
+    // (the wave waits for that load: slower, but exact and unbounded).
     bool live = in_range && row >= 0 && p.status[m] == (SECOND ? RETRY : 0);
     if (SECOND && !__any(live)) return;                  // nothing was handed on to this pass in this group of 64 maps
     const uint32_t nbac = live ? p.bac_bits[m] : 0u;
     const uint32_t nbyp = live ? p.bypass_bits[m] : 0u;
+    const uint32_t* gbac = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)(in_range ? m : 0u) * p.stride);
+    const uint32_t* gbyp = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)(in_range ? m : 0u) * p.stride + p.stride / 2);
     bool retry = false;
-    if (live && (nbac > WB * 32u || nbyp > WY * 32u)) retry = true;   // longer than the window: next pass
+    if (live && (nbac > p.stride * 4u || nbyp > p.stride * 4u)) retry = true;    // beyond the buffer: not a stream of ours
+    if (!SECOND && live && (nbac > WB * 32u || nbyp > WY * 32u)) retry = true;   // longer than the window: second pass
     if (live) {
         for (uint32_t k = 0; k < L; k++) {
             const double pk = p.probs[(size_t)row * L + k];
@@ -317,7 +324,8 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
     {   // zeros behind the last word of this lane's stream: at most three window words are loaded beyond it (a refill happens
         // at 32 buffered bits or fewer and only stream bits are ever consumed: refills <= bits / 32 + 2)
         const uint32_t nwords = retry ? 0u : (nbac + 31u) >> 5;
-        for (uint32_t t = 0; t < 3u; t++) wbac[(nwords + t) * 64u + lane] = 0u;
+        if (nwords <= WB)
+            for (uint32_t t = 0; t < 3u; t++) wbac[(nwords + t) * 64u + lane] = 0u;
     }
     __syncthreads();
     int16_t* out = p.decoded + (size_t)(in_range ? m : 0u) * p.map_size;
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
     uint32_t rcount = 0, rword = 0;       // rword: next dword of the window to load
     auto refill = [&]() {                 // 32 more bits once at most 32 are left, zeros beyond the stream
         const bool need = rcount <= 32u;
-        const bool have = rword < WB && rword * 32u < nbac;
+        const bool have = rword < WB && rword * 32u < nbac;                  // priming reads word 0 only
         const uint32_t w = wbac[(have ? rword : 0u) * 64u + lane];
         rwin |= (unsigned long long)(need && have ? __builtin_bitreverse32(w) : 0u) << (need ? 32u - rcount : 0u);
         rcount += need ? 32u : 0u;
@@ -362,7 +370,28 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
     // bit): none of their latencies sits in the decision -> decision dependency chain.
     const double p0 = active ? probs[lane] : 0.5;
     double pk = p0;
-    uint32_t wnext = active ? wbac[rword * 64u + lane] : 0u;
+    uint32_t gw = 0, gw_row = 0xFFFFFFFFu, gy = 0, gy_row = 0xFFFFFFFFu;        // the words held from beyond the windows
+    // (macros, not lambdas: with the held words captured by reference the compiler kept them in scratch memory and turned
+    // the LDS read into a flat load selecting between LDS and scratch, waited for in every step)
+#define EAE_WINDOW_WORD(dst_)                                                                                         \
+    {                                                                                                                 \
+        dst_ = wbac[(!SECOND || rword < WB + 2u ? rword : WB + 2u) * 64u + lane];                                     \
+        if (SECOND && rword >= WB) {                                                                                  \
+            if (rword != gw_row) { gw = rword * 32u < nbac ? gbac[rword] : 0u; gw_row = rword; }                      \
+            dst_ = gw;                                                                                                \
+        }                                                                                                             \
+    }
+#define EAE_BYPASS_WORD(dst_, yrow_)                                                                                  \
+    {                                                                                                                 \
+        const uint32_t yr_ = (yrow_);                                                                                 \
+        dst_ = wbyp[(yr_ < WY ? yr_ : WY) * 64u + lane];                                                              \
+        if (SECOND && yr_ >= WY) {                                                                                    \
+            if (yr_ != gy_row) { gy = yr_ * 32u < nbyp ? gbyp[yr_] : 0u; gy_row = yr_; }                              \
+            dst_ = gy;                                                                                                \
+        }                                                                                                             \
+    }
+    uint32_t wnext = 0u;
+    if (active) EAE_WINDOW_WORD(wnext)
     uint32_t err = 0;
     while (active) {
         {   // refill: 32 more bits once at most 32 are left, zeros beyond the stream
@@ -371,10 +400,11 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
             rcount += need ? 32u : 0u;
             rword += need ? 1u : 0u;
         }
-        const uint32_t wload = wbac[rword * 64u + lane];
+        uint32_t wload;
+        EAE_WINDOW_WORD(wload)
         const double pspec = probs[(unary + 1u) * 64u + lane];
-        const uint32_t yrow = yidx >> 5;
-        uint32_t yword = wbyp[(yrow < WY ? yrow : WY) * 64u + lane];
+        uint32_t yword;
+        EAE_BYPASS_WORD(yword, yidx >> 5)
         // Bac::decode (BinaryArithmeticCoder.cpp:124-134, 254-320) with the closed-form renormalisation of coder_core.h
         const uint32_t mid = low + (uint32_t)(pk * (double)(high - low));
         const uint32_t bit = code > mid ? 1u : 0u;
@@ -420,7 +450,9 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
             uint32_t nn = 0;
             for (;;) {
                 if (yidx >= nbyp) { bad = true; break; }
-                const uint32_t b = (wbyp[(yidx >> 5) * 64u + lane] >> (yidx & 31u)) & 1u;
+                uint32_t yw;
+                EAE_BYPASS_WORD(yw, yidx >> 5)
+                const uint32_t b = (yw >> (yidx & 31u)) & 1u;
                 yidx++;
                 if (!b) break;
                 nn++;
@@ -429,11 +461,13 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
             uint32_t suffix = 0;
             for (uint32_t q = 0; q < nn && !bad; q++) {
                 if (yidx >= nbyp) { bad = true; break; }
-                suffix = (suffix << 1) | ((wbyp[(yidx >> 5) * 64u + lane] >> (yidx & 31u)) & 1u);
+                uint32_t yw;
+                EAE_BYPASS_WORD(yw, yidx >> 5)
+                suffix = (suffix << 1) | ((yw >> (yidx & 31u)) & 1u);
                 yidx++;
             }
             a = (L + ((suffix + (1u << nn) - 1u) & 0xFFFFu)) & 0xFFFFu;    // uint16 arithmetic of the reference
-            yword = wbyp[((yidx >> 5) < WY ? (yidx >> 5) : WY) * 64u + lane];   // the sign now sits further on
+            EAE_BYPASS_WORD(yword, yidx >> 5)                              // the sign now sits further on
             if (bad) err = 1u;
         }
         int v = (int)(int16_t)a;
@@ -452,6 +486,8 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
     }
     if (live && !retry && (err != 0u || yidx > nbyp || i < size)) retry = true;   // something only the general kernel reports
     if (live) p.status[m] = retry ? RETRY : 0;
+#undef EAE_WINDOW_WORD
+#undef EAE_BYPASS_WORD
 }
 
 // (4) decoded == encoded, one wavefront per map
@@ -549,26 +585,27 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
     if (symbols_out) p.decoded = symbols_out;
     if (!expected) (void)hipMemsetAsync(status, 0, (size_t)n_maps * sizeof(int32_t), s);   // a pure decode starts from a clean slate
     if (fast_applies(L) && map_size) {
+        const dim3 grid((n_maps + 63u) / 64u);
         if (map_size > kMediumMapSize) {
             const size_t lds = decode_lds_bytes(L, kBacWindowWordsMedium, kBypassWindowWordsMedium);
-            static const hipError_t medium_ok = hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, false>),
-                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            static const hipError_t medium_ok = [] {
+                hipError_t e = hipFuncSetAttribute(
+                    reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, false>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                if (e != hipSuccess) return e;
+                return hipFuncSetAttribute(
+                    reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, true>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            }();
             if (medium_ok != hipSuccess) return (int)medium_ok;
-            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, false>), dim3((n_maps + 63u) / 64u),
-                               dim3(64), lds, s, p);
+            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, false>), grid, dim3(64), lds, s, p);
+            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, true>), grid, dim3(64), lds, s, p);
         } else {
             const size_t lds = decode_lds_bytes(L, kBacWindowWords, kBypassWindowWords);
-            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, false>), dim3((n_maps + 63u) / 64u), dim3(64), lds, s, p);
+            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, false>), grid, dim3(64), lds, s, p);
+            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, true>), grid, dim3(64), lds, s, p);
         }
-        // maps whose streams did not fit the small windows: same kernel, big windows (waves with no such map exit at once)
-        const size_t lds_big = decode_lds_bytes(L, kBacWindowWordsBig, kBypassWindowWordsBig);
-        static const hipError_t big_ok = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsBig, kBypassWindowWordsBig, true>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (big_ok == hipSuccess)
-            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsBig, kBypassWindowWordsBig, true>), dim3((n_maps + 63u) / 64u), dim3(64),
-                               lds_big, s, p);
+        // whatever a map reported that only the general kernel can name (errors of any kind)
         const int rc = eae_coder_generic_decode(n_maps, map_size, p.decoded, L, probs, prob_row, streams, stride, bac_bits,
                                                 bypass_bits, status, stage, RETRY, s);
         if (rc) return rc;

@@ -16,7 +16,8 @@ inputs (tests/test_gpu_codec.py); `bench.py` times exactly this class.
 Concurrency: the coder is a few latency-bound wavefronts, so its launches go to side streams and overlap the synthesis
 transforms of the same batch and the analysis transforms of the next ones; `nb_in_flight` batches of coder work may be
 pending. Buffers that cross streams are preallocated per slot; results reach the host through a kernel that writes pinned
-memory (no hipMemcpyAsync on the launch thread) and a worker thread turns them into per-image numbers. For small batches the
+memory (no hipMemcpyAsync on the launch thread) and a worker thread turns them into per-image numbers; the events it waits
+on are blocking ones (the thread sleeps instead of spinning: eight ranks share one host CPU quota). For small batches the
 step can be replayed as three hipGraphs per slot (`use_graphs`) over several transform streams (`nb_transform_streams`).
 """
 import queue
@@ -267,11 +268,11 @@ class BatchCodec(object):
         with torch.cuda.stream(coder_stream):
             coder_stream.wait_event(quantized)
             graphs[1].replay()
-            coded = torch.cuda.Event()
+            coded = torch.cuda.Event(blocking=True)
             coded.record()
         with torch.cuda.stream(stream):
             graphs[2].replay()
-            decoded = torch.cuda.Event()
+            decoded = torch.cuda.Event(blocking=True)
             decoded.record()
         luminances_uint8.record_stream(stream)
         ticket = Ticket(self.batch_size)
@@ -294,10 +295,10 @@ class BatchCodec(object):
         with torch.cuda.stream(stream):
             stream.wait_event(quantized)
             self._launch_coder(slot)
-            coded = torch.cuda.Event()
+            coded = torch.cuda.Event(blocking=True)
             coded.record()
         reconstruction = self._launch_synthesis(latents, luminances_uint8, slot, hook)
-        decoded = torch.cuda.Event()
+        decoded = torch.cuda.Event(blocking=True)
         decoded.record()
         ticket = Ticket(self.batch_size)
         if self.keep_reconstruction:

@@ -16,12 +16,14 @@ inputs (tests/test_gpu_codec.py); `bench.py` times exactly this class.
 Concurrency: the coder is a few latency-bound wavefronts, so its launches go to side streams and overlap the synthesis
 transforms of the same batch and the analysis transforms of the next ones; `nb_in_flight` batches of coder work may be
 pending. Buffers that cross streams are preallocated per slot; results reach the host through a kernel that writes pinned
-memory (no hipMemcpyAsync on the launch thread) and a worker thread turns them into per-image numbers; the events it waits
-on are blocking ones (the thread sleeps instead of spinning: eight ranks share one host CPU quota). For small batches the
+memory (no hipMemcpyAsync on the launch thread) and a worker thread turns them into per-image numbers; it polls its events
+and sleeps in between instead of spinning in `synchronize()` (eight ranks share one host CPU quota). For small batches the
 step can be replayed as three hipGraphs per slot (`use_graphs`) over several transform streams (`nb_transform_streams`).
 """
+import os
 import queue
 import threading
+import time
 
 import numpy
 import torch
@@ -34,6 +36,9 @@ from .kodak.lossless import compression as lossless_compression
 # HIP multiplexes streams onto 4 hardware queues: side streams are shared by every codec of the process so that a coder
 # stream never ends up on the hardware queue of the stream the transforms run on.
 _SIDE_STREAMS = []
+# The result worker polls its events and sleeps in between: `Event.synchronize()` was measured to spin a whole CPU per
+# process (with blocking events too), and eight ranks share one 16-CPU quota. 0 restores synchronize().
+_POLL_SECONDS = float(os.environ.get('EAE_WORKER_POLL_SECONDS', '0.0002'))
 
 
 def _side_streams(count):
@@ -80,7 +85,11 @@ class _Worker(threading.Thread):
             (ticket, events, views, symbols_host, slot_free) = job
             try:
                 for event in events:
-                    event.synchronize()
+                    if _POLL_SECONDS > 0.:
+                        while not event.query():
+                            time.sleep(_POLL_SECONDS)
+                    else:
+                        event.synchronize()
                 (results, hist, overflow, flags, checks, sse) = [v.numpy() for v in views]
                 if symbols_host is not None:
                     # encode + decode + compare per map on the host cores, like compress_lossless + the caller's assert
@@ -251,11 +260,12 @@ class BatchCodec(object):
             static_input = torch.empty_like(luminances_uint8)
             caller.synchronize()
             graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
-            with torch.cuda.graph(graphs[0], stream=stream):
+            # thread_local: the result worker keeps querying its events while this thread captures
+            with torch.cuda.graph(graphs[0], stream=stream, capture_error_mode='thread_local'):
                 latents = self._launch_analysis(static_input, slot, None)
-            with torch.cuda.graph(graphs[1], stream=coder_stream):
+            with torch.cuda.graph(graphs[1], stream=coder_stream, capture_error_mode='thread_local'):
                 self._launch_coder(slot)
-            with torch.cuda.graph(graphs[2], stream=stream):
+            with torch.cuda.graph(graphs[2], stream=stream, capture_error_mode='thread_local'):
                 reconstruction = self._launch_synthesis(latents, static_input, slot, None)
             self._graphs[slot] = (graphs, static_input, latents, reconstruction)
         (graphs, static_input, _, reconstruction) = self._graphs[slot]
@@ -268,11 +278,11 @@ class BatchCodec(object):
         with torch.cuda.stream(coder_stream):
             coder_stream.wait_event(quantized)
             graphs[1].replay()
-            coded = torch.cuda.Event(blocking=True)
+            coded = torch.cuda.Event()
             coded.record()
         with torch.cuda.stream(stream):
             graphs[2].replay()
-            decoded = torch.cuda.Event(blocking=True)
+            decoded = torch.cuda.Event()
             decoded.record()
         luminances_uint8.record_stream(stream)
         ticket = Ticket(self.batch_size)
@@ -295,10 +305,10 @@ class BatchCodec(object):
         with torch.cuda.stream(stream):
             stream.wait_event(quantized)
             self._launch_coder(slot)
-            coded = torch.cuda.Event(blocking=True)
+            coded = torch.cuda.Event()
             coded.record()
         reconstruction = self._launch_synthesis(latents, luminances_uint8, slot, hook)
-        decoded = torch.cuda.Event(blocking=True)
+        decoded = torch.cuda.Event()
         decoded.record()
         ticket = Ticket(self.batch_size)
         if self.keep_reconstruction:

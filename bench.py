@@ -268,6 +268,15 @@ def main():
                                 'mpixels_per_s': round(300*H_IN*W_IN/one['elapsed']/1e6, 2), 'steps': 300, 'warmup': 30,
                                 'note': 'one 512x768 image per step; a step is a chain of short latency-bound kernels, so steps '
                                         'are pipelined: 6 transform streams, 8 coder streams, three hipGraph launches per step'}
+    if rank == 0 and world == 1 and not args.no_single_image and args.transform_streams == 1 and not args.graphs:
+        # the same batch in the opt-in overlapped mode (consecutive batches on alternating transform streams, three batches of
+        # coder work in flight, a step replayed as three hipGraphs): whole-job rate only -- launches share the GPU, so there
+        # are no per-launch durations to report
+        over = run_pipeline(args, args.batch, 100, 15, device, world, rank, cores, False, variables, coder_streams=3,
+                            transform_streams=2, use_graphs=True)
+        line['overlapped_mode'] = {'value': round(100*args.batch*H_IN*W_IN/over['elapsed']/1e6, 3), 'unit': 'Mpixels/s',
+                                   'ms_per_step': round(over['elapsed']/100*1e3, 4), 'steps': 100, 'warmup': 15,
+                                   'flags': '--transform-streams 2 --coder-streams 3 --graphs'}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(variables, probabilities, map_mean_host, cores)

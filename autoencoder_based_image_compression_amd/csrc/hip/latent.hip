@@ -5,7 +5,8 @@
 //   count_nb_deads flags, the three data checks     tools.py:294-320, 130-132, 372-375, compression.py:149-153
 //   + map_mean, inverse_gdn_4                       reconstructing_eae_kodak.py:192, components.py:53-58, tfutils.py:505-509
 // The separate kernels (conv epilogue / gdn_kernel, quantize_kernel, gdn_kernel) each stream the 128-channel latents
-// through HBM; here a block keeps 128 positions x 128 channels in LDS and runs both 128 x 128 contractions on the MFMA.
+// through HBM; here a wave keeps 32 positions x 128 channels in registers (latent_wave_kernel, the default; latent_kernel
+// keeps 64 positions per block in LDS) and runs both 128 x 128 contractions on the MFMA.
 // Arithmetic, operation by operation, is that of gdn.hip and quantize.hip (same helpers), so the results are the same bits.
 #include "common.h"
 

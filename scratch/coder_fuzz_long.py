@@ -1,0 +1,98 @@
+"""Extended fuzz of the 64-maps-per-wavefront coder against the host library (the committed test runs 150 cases; this one
+runs thousands with sizes and statistics chosen to hit the rare paths: long pending-E3 runs, Exp-Golomb escapes, streams
+longer than the LDS windows, empty / one-symbol maps, invalid probabilities). Exit code 1 on the first difference."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import test_coder_device as T
+from autoencoder_based_image_compression_amd import device as dev
+
+from autoencoder_based_image_compression_amd import _native
+import ctypes
+
+
+def host_decode_one(streams, m, size, prob_row):
+    lib = _native.coder()
+    raw = streams.streams[m].cpu().numpy()
+    half = streams.stride//2
+    (bac, byp) = (numpy.ascontiguousarray(raw[:half]), numpy.ascontiguousarray(raw[half:]))
+    out = numpy.zeros(size, dtype=numpy.int16)
+    stage = ctypes.c_int(0)
+    pp = numpy.ascontiguousarray(prob_row, dtype=numpy.float64)
+    status = lib.eae_coder_decode(size, _native.ptr(out, _native.c_i16p), pp.size, _native.ptr(pp, _native.c_f64p),
+                                  _native.ptr(bac, _native.c_u8p), int(streams.bac_bits[m].item()),
+                                  _native.ptr(byp, _native.c_u8p), int(streams.bypass_bits[m].item()), ctypes.byref(stage))
+    return (int(status), out)
+
+
+T.host_decode_one = host_decode_one
+rng = numpy.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.
+t0 = time.time()
+cases = 0
+seen = {}
+while time.time() - t0 < budget:
+    kind = rng.randint(6)
+    n_maps = int(rng.randint(1, 200))
+    L = int(rng.choice([1, 2, 3, 10, 10, 10, 31, 32]))
+    if kind == 0:        # tiny maps
+        size = int(rng.randint(1, 8))
+    elif kind == 1:      # very sparse long maps with very skewed p0: long E3 runs
+        size = int(rng.choice([4096, 16384, 20000]))
+        n_maps = int(rng.randint(1, 70))
+    elif kind == 2:      # dense: streams far beyond the windows, many escapes
+        size = int(rng.randint(200, 3000))
+    else:
+        size = int(rng.randint(1, 1800))
+    probs = numpy.clip(rng.beta(0.6, 0.6, size=(n_maps, L)), 1e-6, 1. - 1e-6)
+    if kind == 1:
+        probs[:, 0] = 1. - 10.**(-rng.uniform(1., 6., size=n_maps))
+        planar = numpy.zeros((n_maps, size), dtype=numpy.int16)
+        for m in range(n_maps):
+            k = int(rng.randint(0, 6))
+            planar[m, rng.randint(0, size, size=k)] = rng.randint(-3, 4, size=k)
+    else:
+        scale = rng.choice([0.05, 0.3, 1, 3, 20, 400, 20000], size=(n_maps, 1))
+        planar = numpy.clip(numpy.round(rng.laplace(size=(n_maps, size))*scale), -32768, 32767).astype(numpy.int16)
+    if rng.rand() < 0.15:
+        probs[rng.randint(n_maps), rng.randint(L)] = rng.choice([0., 1., numpy.nan, -0.2, 1.5])
+    rows = numpy.arange(n_maps, dtype=numpy.int32)
+    if rng.rand() < 0.2:
+        rows[rng.randint(n_maps)] = -1
+    (streams, sym, p, r) = T.batch_code(dev, planar, probs, rows)
+    ok = T.assert_equals_host(streams, planar, probs, rows, (cases, kind))
+    for v in streams.status.cpu().numpy():
+        seen[int(v)] = seen.get(int(v), 0) + 1
+    encode_status = streams.status.clone()
+    dev.coder_decode_batch(streams, p, r, expected=sym)
+    assert torch.equal(streams.status, encode_status), (cases, kind)
+    out = dev.coder_decode_batch(streams, p, r).cpu().numpy()
+    good = ok & (rows >= 0)
+    assert numpy.array_equal(out[good], planar[good]), (cases, kind)
+    # corrupt one coded stream: the device's verdict must be the host decoder's
+    before = streams.status.cpu().numpy().copy()          # after the pure decode: what every map decodes to on its own
+    cand = numpy.flatnonzero(good & (before == 0) & (streams.bac_bits.cpu().numpy() >= 24))
+    if cand.size:
+        m = int(cand[rng.randint(cand.size)])
+        byte = int(rng.randint(0, 3))
+        streams.streams[m, byte] ^= int(1 << rng.randint(0, 8))
+        dev.coder_decode_batch(streams, p, r, expected=sym)
+        st = streams.status.cpu().numpy()
+        if not numpy.array_equal(numpy.delete(st, m), numpy.delete(before, m)):
+            es_ = encode_status.cpu().numpy()
+            bad = [k for k in range(n_maps) if k != m and st[k] != before[k] and es_[k] == 0]
+            if not bad:
+                bad = None
+            if bad is not None:
+                print('case', cases, 'kind', kind, 'corrupted', m, 'differing', [(k, int(before[k]), int(st[k]), int(rows[k]), int(encode_status[k])) for k in bad[:8]],
+                      'size', size, 'L', L)
+                raise SystemExit(1)
+        # and the corrupted map: the host decoder's verdict on the same bytes (status, or a symbol mismatch)
+        host = T.host_decode_one(streams, m, planar.shape[1], probs[rows[m]]) if hasattr(T, 'host_decode_one') else None
+        if host is not None:
+            (h_status, h_symbols) = host
+            expect = h_status if h_status else (0 if numpy.array_equal(h_symbols, planar[m]) else 6)
+            assert int(st[m]) == expect, (cases, m, int(st[m]), expect)
+    cases += 1
+print('cases', cases, 'statuses seen', seen)

@@ -381,3 +381,4 @@ class BatchCodec(object):
     def close(self):
         self.drain()
         self._worker.jobs.put(None)
+        self._worker.join()         # a worker still unwinding while the interpreter finalises aborts the process at exit

@@ -1,0 +1,1 @@
+"""kodak/eae/graph: part of the MI355X build of the compression inference path."""

@@ -189,8 +189,9 @@ __global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
             // kernel sorts that out; here the whole map is handed over so that the steps below need no check.
             if (!(pk > 0. && pk < 1.)) retry = true;
         }
-    const uint32_t nd = live && !retry ? p.ndec[m] : 0u;
+    uint32_t nd = live && !retry ? p.ndec[m] : 0u;     // set to 0 when the map leaves for the general kernel: its steps stop
     const uint32_t steps = wave_max(nd);
+    uint32_t err = 0;                                  // a condition only the general kernel reports (kept out of the branches)
     Bac bac;
     bac.init();
     bac.bs.init_writer(p.streams + (uint64_t)(in_range ? m : 0u) * p.stride, required_bits(p.map_size, L));
@@ -202,11 +203,11 @@ __global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
         if (jb + 8 < steps) ahead = *reinterpret_cast<const uint2*>(dec + (size_t)((jb >> 3) + 1u) * 512u);
         // eight steps emit at most the pending E3 bits + 8 x (16 leaving bits + 15 new E3 bits): near the end of the stream's
         // capacity (Bitstream.cpp:32-35) the map goes to the general kernel, which reproduces the exact point of failure
-        if (bac.bs.write_index + e3 + 8u * 31u > bac.bs.size_bits) retry = true;
+        if (bac.bs.write_index + e3 + 8u * 31u > bac.bs.size_bits) { err = 1u; nd = 0u; }
 #pragma unroll
         for (uint32_t q = 0; q < 8; q++) {
             const uint32_t j = jb + q;
-            if (j < nd && !retry) {
+            if (j < nd) {
                 const uint32_t d = (uint32_t)(d8 >> (8u * q)) & 0xFFu;
                 const uint32_t bit = d & 1u;
                 const double pk = probs[(d >> 1) * 64u + lane];
@@ -214,11 +215,11 @@ __global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
                 const uint32_t mid = low + (uint32_t)(pk * (double)(high - low));
                 uint32_t nl = bit ? mid + 1u : low;
                 uint32_t nh = bit ? high : mid;
-                if (nl > kRangeMax) retry = true;                    // precision_error (cannot happen with 0 < p < 1)
+                err |= nl > kRangeMax ? 1u : 0u;                     // precision_error (cannot happen with 0 < p < 1)
                 // E1/E2 in closed form (as Bac::encode): n leading equal bits leave, with the pending E3 bits behind the first
                 const uint32_t diff = (nl ^ nh) & 0xFFFFu;
                 const uint32_t n = diff ? (uint32_t)__builtin_clz(diff) - 16u : 16u;
-                if (n && !retry) {
+                if (n) {
                     const uint32_t out = rev16(nh);
                     const unsigned long long first = out & 1u;
                     Bitstream& bs = bac.bs;
@@ -240,16 +241,17 @@ __global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
                         const unsigned long long rest = (out >> 1) & ((1u << (n - 1u)) - 1u);
                         put(run | (rest << e3), n - 1u + e3);
                     } else {
-                        const unsigned long long run = first ? 0ull : ((1ull << e3) - 1ull);
+                        // the leaving bit followed by e3 complements, first in time at bit 0: 1, or 0 then e3 ones = 2^(e3+1) - 2
+                        const unsigned long long head = first ? 1ull : ((2ull << e3) - 2ull);
                         const unsigned long long rest = (out >> 1) & ((1u << (n - 1u)) - 1u);
-                        put(first | (run << 1) | (rest << (1u + e3)), n + e3);
+                        put(head | (rest << (1u + e3)), n + e3);
                     }
                     e3 = 0;
                     nl = (nl << n) & 0xFFFFu;
                     nh = ((nh << n) & 0xFFFFu) | ((1u << n) - 1u);
                 }
                 // E3 (BinaryArithmeticCoder.cpp:238-245)
-                while (!retry && nl > kRangeQuarter && nh <= kRangeThreeQuarters) {
+                while (nl > kRangeQuarter && nh <= kRangeThreeQuarters) {
                     nh = ((nh - (kRangeQuarter + 1u)) << 1) | 1u;
                     nl = (nl - (kRangeQuarter + 1u)) << 1;
                     e3++;
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
             }
         }
     }
+    if (err) retry = true;
     if (live) {
         int s = OK;
         if (!retry) {

@@ -250,11 +250,15 @@ __global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
                     nl = (nl << n) & 0xFFFFu;
                     nh = ((nh << n) & 0xFFFFu) | ((1u << n) - 1u);
                 }
-                // E3 (BinaryArithmeticCoder.cpp:238-245)
-                while (nl > kRangeQuarter && nh <= kRangeThreeQuarters) {
-                    nh = ((nh - (kRangeQuarter + 1u)) << 1) | 1u;
-                    nl = (nl - (kRangeQuarter + 1u)) << 1;
-                    e3++;
+                // E3 (BinaryArithmeticCoder.cpp:238-245) in closed form, see bac_decode_kernel: the number of scalings is the run
+                // of positions below the top bit where `low` has a 1 and `high` a 0, capped where `high` would reach 0xBFFE
+                {
+                    const uint32_t e3_run = (uint32_t)__builtin_clz(~(((nl & ~nh) & 0x7FFFu) << 17));
+                    const uint32_t e3_cap = 14u - (uint32_t)__builtin_ctz(~nh);
+                    const uint32_t k3 = nh > kRangeThreeQuarters || nl <= kRangeQuarter ? 0u : (e3_run < e3_cap ? e3_run : e3_cap);
+                    nl = (((nl - 0x8000u) << k3) + 0x8000u) & kRangeMax;
+                    nh = (((nh - 0x8000u) << k3) + 0x8000u + ((1u << k3) - 1u)) & kRangeMax;
+                    e3 += k3;
                 }
                 low = nl;
                 high = nh;
@@ -415,31 +419,32 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
         uint32_t nh = bit ? high : mid;
         const uint32_t diff = (nl ^ nh) & 0xFFFFu;
         const uint32_t n = diff ? (uint32_t)__builtin_clz(diff) - 16u : 16u;
-        uint32_t sticky;
+        nl = (nl << n) & kRangeMax;
+        nh = ((nh << n) & kRangeMax) | ((1u << n) - 1u);
+        // E3 in closed form too. After E1/E2 the intervals' top bits are 0 / 1; one E3 scaling (BinaryArithmeticCoder.cpp:
+        // 238-245, 300-318) deletes the bit below them when it is 1 in `low` and 0 in `high`, so the loop runs once per
+        // leading position where that holds (e3_run) -- except that the reference compares `high` with 3 * 0x3FFF = 0xBFFD,
+        // not 0xBFFF: it also stops as soon as `high` has become 0xBFFE / 0xBFFF, i.e. after 14 - (trailing ones of high)
+        // scalings. k scalings map v to 2^k (v - 2^15) + 2^15 (+ 2^k - 1 for `high`, + the k new stream bits for the code
+        // register), all modulo 2^16 like the loop's masks.
+        const uint32_t e3_run = (uint32_t)__builtin_clz(~(((nl & ~nh) & 0x7FFFu) << 17));
+        const uint32_t e3_cap = 14u - (uint32_t)__builtin_ctz(~nh);
+        const uint32_t k3 = nh > kRangeThreeQuarters ? 0u : (e3_run < e3_cap ? e3_run : e3_cap);
         {
+            // the n bits that E1/E2 shift in and the k3 bits of the E3 scalings leave the window together (at most 30 of the
+            // 33 or more buffered); beyond the end of the stream the last real bit repeats, and no bit at all reads as 0
+            const uint32_t total = n + k3;
             const uint32_t avail = nbac - ridx;
-            const uint32_t k = n < avail ? n : avail;
+            const uint32_t k = total < avail ? total : avail;
             uint32_t bits = take(k);                                       // first in time most significant
-            sticky = bits & 1u;
-            const uint32_t ext = n - k;                                    // bits wanted beyond the end: the last one repeats
+            const uint32_t sticky = bits & 1u;
+            const uint32_t ext = total - k;
             bits = (bits << ext) | (sticky ? ((1u << ext) - 1u) : 0u);
             ridx += k;
-            nl = (nl << n) & kRangeMax;
-            nh = ((nh << n) & kRangeMax) | ((1u << n) - 1u);
-            code = ((code << n) & kRangeMax) | bits;
-        }
-        // E3: at most 15 scalings follow a decision and at least 17 bits are buffered here (33 after the refill, 16 leave
-        // above), so the window never runs dry inside this loop
-        while (nh <= kRangeThreeQuarters && nl > kRangeQuarter && nh > kRangeHalf && nl <= kRangeHalf) {
-            nh -= kRangeQuarter + 1u; nl -= kRangeQuarter + 1u; code -= kRangeQuarter + 1u;
-            const uint32_t more = ridx < nbac ? 1u : 0u;
-            sticky = more ? (uint32_t)(rwin >> 63) : sticky;
-            rwin <<= more;
-            rcount -= more;
-            ridx += more;
-            nh = ((nh << 1) & kRangeMax) | 1u;
-            nl = (nl << 1) & kRangeMax;
-            code = ((code << 1) & kRangeMax) | sticky;
+            code = ((code << n) & kRangeMax) | (bits >> k3);
+            code = (((code - 0x8000u) << k3) + 0x8000u + (bits & ((1u << k3) - 1u))) & kRangeMax;
+            nl = (((nl - 0x8000u) << k3) + 0x8000u) & kRangeMax;
+            nh = (((nh - 0x8000u) << k3) + 0x8000u + ((1u << k3) - 1u)) & kRangeMax;
         }
         low = nl;
         high = nh;

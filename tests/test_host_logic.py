@@ -265,3 +265,52 @@ def test_png_dump_helpers(tmp_path):
         tls.visualize_crops(image, positions, paths[:1])
     with pytest.raises(TypeError):
         tls.save_image(paths[0], image.astype(numpy.int32))
+
+
+def test_e3_closed_form_equals_the_reference_loop_for_every_interval():
+    """coder_simd.hip replaces the E3 loop of BinaryArithmeticCoder.cpp:238-245 / 300-318 by a closed form (run of positions
+    where `low` has a 1 and `high` a 0, capped where `high` reaches 0xBFFE because the reference's three-quarters constant is
+    3 * 0x3FFF). Exhaustive over every (low, high) with top bits 0 / 1 -- the state after E1/E2 -- in which E3 can start, and
+    over a code register value per pair: same count, same low / high / code as the loop."""
+    (quarter, three_quarters, top) = (0x3FFF, 49149, 0x8000)
+    highs = numpy.arange(0x8000, 0x10000, dtype=numpy.int64)
+    rng = numpy.random.RandomState(5)
+    checked = 0
+    for low0 in range(0x4000, 0x8000, 37):                      # every 37th `low` (443 values) x all 32768 `high`
+        low = numpy.full(highs.shape, low0, dtype=numpy.int64)
+        high = highs.copy()
+        code = rng.randint(0, 0x10000, size=highs.shape).astype(numpy.int64)
+        stream = rng.randint(0, 2, size=(15,) + highs.shape).astype(numpy.int64)       # the next stream bits, in order
+        # the reference loop
+        (l, h, c) = (low.copy(), high.copy(), code.copy())
+        count = numpy.zeros(highs.shape, dtype=numpy.int64)
+        for step in range(15):
+            go = (l > quarter) & (h <= three_quarters)
+            taken = numpy.take_along_axis(stream, numpy.minimum(count, 14)[None], axis=0)[0]
+            l = numpy.where(go, ((l - (quarter + 1)) << 1) & 0xFFFF, l)
+            h = numpy.where(go, (((h - (quarter + 1)) << 1) | 1) & 0xFFFF, h)
+            c = numpy.where(go, ((((c - (quarter + 1)) << 1) & 0xFFFF) | taken), c)
+            count += go
+        assert not ((l > quarter) & (h <= three_quarters)).any()
+        # the closed form
+        run_bits = (low & ~high) & 0x7FFF
+        run = numpy.zeros(highs.shape, dtype=numpy.int64)
+        alive = numpy.ones(highs.shape, dtype=bool)
+        for position in range(14, -1, -1):
+            alive &= ((run_bits >> position) & 1) == 1
+            run += alive
+        trailing_ones = numpy.zeros(highs.shape, dtype=numpy.int64)
+        alive = numpy.ones(highs.shape, dtype=bool)
+        for position in range(16):
+            alive &= ((high >> position) & 1) == 1
+            trailing_ones += alive
+        k = numpy.where((high > three_quarters) | (low <= quarter), 0, numpy.minimum(run, 14 - trailing_ones))
+        new_bits = numpy.zeros(highs.shape, dtype=numpy.int64)
+        for step in range(15):
+            new_bits = numpy.where(step < k, (new_bits << 1) | stream[step], new_bits)
+        assert numpy.array_equal(k, count)
+        assert numpy.array_equal((((low - top) << k) + top) & 0xFFFF, l)
+        assert numpy.array_equal((((high - top) << k) + top + ((1 << k) - 1)) & 0xFFFF, h)
+        assert numpy.array_equal((((code - top) << k) + top + new_bits) & 0xFFFF, c)
+        checked += highs.size
+    assert checked > 14_000_000

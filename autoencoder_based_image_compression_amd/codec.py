@@ -35,16 +35,17 @@ from .kodak.lossless import compression as lossless_compression
 
 # HIP multiplexes streams onto 4 hardware queues: side streams are shared by every codec of the process so that a coder
 # stream never ends up on the hardware queue of the stream the transforms run on.
-_SIDE_STREAMS = []
+_SIDE_STREAMS = {}          # device index -> list of streams
 # The result worker polls its events and sleeps in between: `Event.synchronize()` was measured to spin a whole CPU per
 # process (with blocking events too), and eight ranks share one 16-CPU quota. 0 restores synchronize().
 _POLL_SECONDS = float(os.environ.get('EAE_WORKER_POLL_SECONDS', '0.0002'))
 
 
-def _side_streams(count):
-    while len(_SIDE_STREAMS) < count:
-        _SIDE_STREAMS.append(torch.cuda.Stream())
-    return _SIDE_STREAMS[:count]
+def _side_streams(count, device):
+    streams = _SIDE_STREAMS.setdefault(device.index, [])
+    while len(streams) < count:
+        streams.append(torch.cuda.Stream(device=device))
+    return streams[:count]
 
 
 class Ticket(object):
@@ -56,6 +57,14 @@ class Ticket(object):
         self._error = None
         self._values = None
         self.reconstruction_uint8 = None      # device tensor when the codec keeps reconstructions
+        self._coder_span = None               # (start, stop) timing events on the coder stream (BatchCodec(time_coder=True))
+
+    def coder_ms(self):
+        """Milliseconds the coder launches of this batch took on their stream (from the moment the symbols were ready to the
+        publication of the results), other work sharing the GPU. Only with `BatchCodec(time_coder=True)`, after `result()`."""
+        if self._coder_span is None:
+            raise RuntimeError('the codec was not built with time_coder=True')
+        return self._coder_span[0].elapsed_time(self._coder_span[1])
 
     def result(self):
         """Blocks until the batch is through; dict of numpy arrays, one entry per image:
@@ -129,7 +138,8 @@ class BatchCodec(object):
 
     def __init__(self, variables, are_bin_widths_learned, bin_widths_test, map_mean, binary_probabilities, idx_map_exception,
                  batch_size, h_in, w_in, device='cuda', nb_in_flight=2, keep_reconstruction=False, launch_hook=None,
-                 coder='device', host_coder_threads=0, hist_radius=2047, nb_transform_streams=1, use_graphs=False):
+                 coder='device', host_coder_threads=0, hist_radius=2047, nb_transform_streams=1, use_graphs=False,
+                 time_coder=False):
         """coder: 'device' (the coder kernels on side streams), 'host' (ONE device -> host copy of the symbols per batch, then
         the host C-ABI coder `eae_coder_compress_maps` on `host_coder_threads` threads: the shape BASELINE.json sketches) or
         'none' (transforms only; the bit counts come back as zeros).
@@ -148,6 +158,11 @@ class BatchCodec(object):
         if h_in % csts.STRIDE_PROD != 0 or w_in % csts.STRIDE_PROD != 0:
             raise ValueError('The image size is not divisible by the product of the three strides.')
         self.device = torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        if self.device.index != torch.cuda.current_device():      # launches go to the current device's streams (device._stream)
+            raise ValueError('`device` is {0} but the current device is cuda:{1}: build and use the codec under '
+                             '`torch.cuda.device({0!r})`.'.format(self.device, torch.cuda.current_device()))
         self.learned = are_bin_widths_learned
         self.encoder = pipeline.DeviceEncoder(variables, are_bin_widths_learned, self.device)
         self.decoder = pipeline.DeviceDecoder(variables, are_bin_widths_learned, self.device)
@@ -172,6 +187,7 @@ class BatchCodec(object):
         self.keep_reconstruction = keep_reconstruction
         self.hist_radius = int(hist_radius)
         self.coder = coder
+        self.time_coder = bool(time_coder)      # Ticket.coder_ms(): the launch-by-launch path only
         self.launch_hook = launch_hook if launch_hook is not None else (lambda name, fn: fn())
         n_maps = batch_size*self.nb_maps
         nb_hist = batch_size if self.idx_map_exception >= 0 else 0
@@ -182,8 +198,8 @@ class BatchCodec(object):
         nb_words = sum(self._layout)
         assert nb_words % 2 == 0
         self.nb_slots = nb_in_flight + 2
-        self._streams = _side_streams(nb_in_flight)
-        self._transform_streams = _side_streams(nb_in_flight + nb_transform_streams)[nb_in_flight:] if nb_transform_streams > 1 else []
+        self._streams = _side_streams(nb_in_flight, self.device)
+        self._transform_streams = _side_streams(nb_in_flight + nb_transform_streams, self.device)[nb_in_flight:] if nb_transform_streams > 1 else []
         self._slot_all = [torch.zeros(nb_words + 2*batch_size, dtype=torch.int32, device=self.device) for _ in range(self.nb_slots)]
         self._slot_out = [t[:nb_words] for t in self._slot_all]
         self._pinned_out = [torch.zeros(nb_words, dtype=torch.int32).pin_memory() for _ in range(self.nb_slots)]
@@ -208,7 +224,7 @@ class BatchCodec(object):
         self._graphs = [None]*self.nb_slots          # per slot: (three graphs, static input, latents, reconstruction)
         self._warm = False
         if self.use_graphs and not self._transform_streams:
-            self._transform_streams = _side_streams(nb_in_flight + 1)[nb_in_flight:]     # replays never go to the caller's stream
+            self._transform_streams = _side_streams(nb_in_flight + 1, self.device)[nb_in_flight:]     # replays never go to the caller's stream
 
     def _views(self, t):
         out = []
@@ -302,15 +318,20 @@ class BatchCodec(object):
         latents = self._launch_analysis(luminances_uint8, slot, hook)
         quantized = torch.cuda.Event()
         quantized.record()
+        ticket = Ticket(self.batch_size)
         with torch.cuda.stream(stream):
             stream.wait_event(quantized)
+            if self.time_coder:
+                started = torch.cuda.Event(enable_timing=True)
+                started.record()
             self._launch_coder(slot)
-            coded = torch.cuda.Event()
+            coded = torch.cuda.Event(enable_timing=self.time_coder)
             coded.record()
+            if self.time_coder:
+                ticket._coder_span = (started, coded)
         reconstruction = self._launch_synthesis(latents, luminances_uint8, slot, hook)
         decoded = torch.cuda.Event()
         decoded.record()
-        ticket = Ticket(self.batch_size)
         if self.keep_reconstruction:
             ticket.reconstruction_uint8 = reconstruction
         self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],),
@@ -379,6 +400,26 @@ class BatchCodec(object):
             event.wait()
 
     def close(self):
-        self.drain()
-        self._worker.jobs.put(None)
-        self._worker.join()         # a worker still unwinding while the interpreter finalises aborts the process at exit
+        """Waits for the pending batches (whether or not their tickets failed) and joins the result worker: a worker still
+        unwinding while the interpreter finalises aborts the process at exit. Idempotent."""
+        if self._worker is None:
+            return
+        try:
+            self.drain()
+        finally:
+            self._worker.jobs.put(None)
+            self._worker.join()
+            self._worker = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, traceback):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: nothing left to report to
+            pass

@@ -26,6 +26,7 @@ import numpy
 import torch
 
 from . import device as dev
+from .kodak.eae.graph import constants as csts
 from .kodak.lossless import interface_cython
 from .kodak.lossless import stats as lossless_stats
 from .kodak.tools import tools as tls
@@ -52,6 +53,13 @@ def _exception_rows(symbols_planar, idx_map_exception, truncated_unary_length):
         p[p == 1.] = 0.99
         rows[i] = p
     return rows
+
+
+def stream_capacity_bits(map_size, truncated_unary_length):
+    """Bits a stream of the coder can hold at most: map_size * max(32, L) rounded up to a byte, the reference's own capacity
+    (compression.cpp:24, Bitstream.cpp:3-11); the coder writes into a region of at least that many bytes + 16 per stream
+    (eae_hip_coder_stream_stride_bytes / 2). Pure arithmetic -- the header check does not need the GPU library."""
+    return (map_size*max(32, truncated_unary_length) + 7)//8*8
 
 
 def _raise_for_statuses(results):
@@ -126,6 +134,15 @@ def read_header(blob):
         raise ValueError('The container does not start with the magic bytes.')
     if version != VERSION:
         raise ValueError('The container version {} is not supported.'.format(version))
+    # sizes first: they dimension device buffers (a crafted header must not get that far)
+    if nb_maps != csts.NB_MAPS_3:
+        raise ValueError('The container does not hold {} maps per image.'.format(csts.NB_MAPS_3))
+    if truncated_unary_length < 1:
+        raise ValueError('The truncated unary length does not belong to [1, 255].')
+    if nb_images < 1 or height < 1 or width < 1 or height % csts.STRIDE_PROD != 0 or width % csts.STRIDE_PROD != 0:
+        raise ValueError('The image sizes in the container are not positive multiples of {}.'.format(csts.STRIDE_PROD))
+    if not -1 <= idx_map_exception < nb_maps:
+        raise ValueError('The index of the exception map in the container is out of range.')
     pos = _HEADER.size
 
     def take(count, dtype):
@@ -147,6 +164,11 @@ def read_header(blob):
     header['exception_probabilities'] = take(nb_rows*truncated_unary_length, numpy.float64).reshape(nb_rows, truncated_unary_length)
     header['bits'] = take(nb_images*nb_maps*2, numpy.uint32).reshape(nb_images*nb_maps, 2)
     header['payload_offset'] = pos
+    # a stream can never be longer than the region the coder gives a map (compression.cpp:24): an inflated count would make
+    # the unpacking write past it
+    map_size = (height//csts.STRIDE_PROD)*(width//csts.STRIDE_PROD)
+    if int(header['bits'].max(initial=0)) > stream_capacity_bits(map_size, truncated_unary_length):
+        raise ValueError('A bit count of the header exceeds the capacity of a stream.')
     payload_bytes = int(((header['bits'].astype(numpy.int64) + 7)//8).sum())
     if pos + payload_bytes != len(blob):
         raise ValueError('The payload size does not match the bit counts of the header.')

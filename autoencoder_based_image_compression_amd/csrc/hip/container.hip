@@ -9,17 +9,20 @@
 namespace {
 
 // Streams of map m: arithmetic-coded bytes at streams[m * stride], bypass bytes at +stride / 2 (include/eae_coder.h).
-// offsets[2m], offsets[2m + 1]: byte offsets of the two pieces in the payload.
+// offsets[2m], offsets[2m + 1]: byte offsets of the two pieces in the payload. A piece never exceeds its half of the
+// region: bit counts come from an untrusted header when unpacking, so the copy is clamped to stride / 2 bytes (the host
+// side rejects such a header before it gets here, container.read_header).
 template <bool PACK>
 __global__ __launch_bounds__(64) void move_streams_kernel(uint8_t* __restrict__ streams, uint64_t stride, uint8_t* __restrict__ payload,
                                                           const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ bac_bits,
                                                           const uint32_t* __restrict__ bypass_bits) {
     const uint32_t m = blockIdx.x;
     for (int piece = 0; piece < 2; ++piece) {
-        const uint32_t bytes = ((piece ? bypass_bits[m] : bac_bits[m]) + 7u) >> 3;
+        uint64_t bytes = ((uint64_t)(piece ? bypass_bits[m] : bac_bits[m]) + 7u) >> 3;
+        if (bytes > stride / 2) bytes = stride / 2;
         uint8_t* region = streams + (uint64_t)m * stride + (piece ? stride / 2 : 0);
         uint8_t* packed = payload + offsets[2 * m + piece];
-        for (uint32_t i = threadIdx.x; i < bytes; i += 64) {
+        for (uint64_t i = threadIdx.x; i < bytes; i += 64) {
             if (PACK) packed[i] = region[i];
             else region[i] = packed[i];
         }
@@ -70,7 +73,7 @@ extern "C" int eae_hip_coder_pack_streams(uint32_t n_maps, const uint8_t* stream
 extern "C" int eae_hip_coder_unpack_streams(uint32_t n_maps, const uint8_t* payload, const uint64_t* offsets,
                                             const uint32_t* bac_bits, const uint32_t* bypass_bits, uint8_t* streams,
                                             uint64_t stride, void* stream) {
-    if (!streams || !bac_bits || !bypass_bits || !offsets || !payload) return EAE_HIP_BAD_ARGUMENT;
+    if (!streams || !bac_bits || !bypass_bits || !offsets || !payload || stride < 2) return EAE_HIP_BAD_ARGUMENT;
     if (n_maps == 0) return EAE_HIP_OK;
     hipLaunchKernelGGL(move_streams_kernel<false>, dim3(n_maps), dim3(64), 0, (hipStream_t)stream, streams, stride,
                        const_cast<uint8_t*>(payload), offsets, bac_bits, bypass_bits);

@@ -23,10 +23,16 @@ def _check(status, what):
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
-def _stream():
-    """hipStream_t of torch's current stream on the current device (every launch of this module goes there)."""
+def _stream(on=None):
+    """hipStream_t of torch's current stream on the current device (every launch of this module goes there). `on`: the
+    launch's main tensor -- it must live on the current device (a kernel launched on another device's stream with foreign
+    pointers faults or silently serialises): select the device with `torch.cuda.device(...)` / `set_device` first."""
+    current = torch.cuda.current_device()
+    if on is not None and on.device.index != current:
+        raise HipError('tensor on {0} but the current device is cuda:{1}: wrap the call in `with torch.cuda.device({0!r})`'.format(
+            on.device, current))
     if _raw_stream is not None:                      # one C call instead of building a torch.cuda.Stream object per launch
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(current)
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -58,7 +64,7 @@ def conv9x9s4_u8(x_u8, w_packed, bias, gamma_packed=None, beta=None, out=None):
     (n, h, wd) = x_u8.shape[:3]
     if out is None:
         out = torch.empty((n, h//4, wd//4, NB_MAPS), dtype=torch.float32, device=x_u8.device)
-    _check(_native.hip().eae_hip_conv9x9s4_u8(_p(x_u8), _p(w_packed), _p(bias), _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream()),
+    _check(_native.hip().eae_hip_conv9x9s4_u8(_p(x_u8), _p(w_packed), _p(bias), _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream(x_u8)),
            'eae_hip_conv9x9s4_u8')
     return out
 
@@ -67,7 +73,7 @@ def conv5x5s2(x, w_packed, bias, norm=NORM_NONE, gamma_packed=None, beta=None, o
     (n, h, wd, c) = x.shape
     if out is None:
         out = torch.empty((n, h//2, wd//2, NB_MAPS), dtype=torch.float32, device=x.device)
-    _check(_native.hip().eae_hip_conv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream()),
+    _check(_native.hip().eae_hip_conv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream(x)),
            'eae_hip_conv5x5s2')
     return out
 
@@ -76,7 +82,7 @@ def gdn(x, gamma_packed, beta, inverse=False, out=None):
     if out is None:
         out = torch.empty_like(x)
     rows = x.numel()//NB_MAPS
-    _check(_native.hip().eae_hip_gdn(_p(x), _p(gamma_packed), _p(beta), 1 if inverse else 0, _p(out), rows, _stream()), 'eae_hip_gdn')
+    _check(_native.hip().eae_hip_gdn(_p(x), _p(gamma_packed), _p(beta), 1 if inverse else 0, _p(out), rows, _stream(x)), 'eae_hip_gdn')
     return out
 
 
@@ -84,7 +90,7 @@ def tconv5x5s2(x, w_packed, bias, norm=NORM_NONE, gamma_packed=None, beta=None, 
     (n, h, wd, c) = x.shape
     if out is None:
         out = torch.empty((n, 2*h, 2*wd, NB_MAPS), dtype=torch.float32, device=x.device)
-    _check(_native.hip().eae_hip_tconv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream()),
+    _check(_native.hip().eae_hip_tconv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream(x)),
            'eae_hip_tconv5x5s2')
     return out
 
@@ -96,7 +102,7 @@ def tconv9x9s4_luma(x, w_phase, want_f32=False, want_u8=True, ref_u8=None, sse=N
     out_u8 = torch.empty((n, 4*h, 4*wd), dtype=torch.uint8, device=x.device) if want_u8 else None
     if ref_u8 is not None and sse is None:
         sse = torch.zeros(n, dtype=torch.int64, device=x.device)
-    _check(_native.hip().eae_hip_tconv9x9s4_luma(_p(x), _p(w_phase), _p(out_f32), _p(out_u8), _p(ref_u8), _p(sse), n, h, wd, _stream()),
+    _check(_native.hip().eae_hip_tconv9x9s4_luma(_p(x), _p(w_phase), _p(out_f32), _p(out_u8), _p(ref_u8), _p(sse), n, h, wd, _stream(x)),
            'eae_hip_tconv9x9s4_luma')
     return out_f32, out_u8, sse
 
@@ -166,7 +172,7 @@ def quantize_maps(y, bin_widths, map_mean=None, want_cq=False, want_shifted=Fals
     flags = (out_flags if out_flags is not None else torch.zeros((n, c), dtype=torch.int32, device=d)) if want_flags else None
     checks = out_checks if out_checks is not None else torch.zeros(3, dtype=torch.int32, device=d)
     _check(_native.hip().eae_hip_quantize_maps(_p(y), _p(map_mean), _p(bin_widths), _p(cq), _p(shifted), _p(symbols), _p(flags),
-                                               _p(checks), n, hw, c, _stream()), 'eae_hip_quantize_maps')
+                                               _p(checks), n, hw, c, _stream(y)), 'eae_hip_quantize_maps')
     return {'cq': cq, 'shifted': shifted, 'symbols': symbols, 'nonzero_flags': flags, 'checks': checks}
 
 
@@ -188,7 +194,7 @@ def latent_stage(x, bin_widths, map_mean=None, gdn_in=None, igdn_out=None, want_
     (g_in, b_in) = gdn_in if gdn_in is not None else (None, None)
     (g_out, b_out) = igdn_out if igdn_out is not None else (None, None)
     _check(_native.hip().eae_hip_latent_stage(_p(x), _p(g_in), _p(b_in), _p(map_mean), _p(bin_widths), _p(g_out), _p(b_out), _p(y),
-                                              _p(shifted), _p(t), _p(symbols), _p(flags), _p(checks), n, hw, _stream()),
+                                              _p(shifted), _p(t), _p(symbols), _p(flags), _p(checks), n, hw, _stream(x)),
            'eae_hip_latent_stage')
     return {'y': y, 'shifted': shifted, 't': t, 'symbols': symbols, 'nonzero_flags': flags, 'checks': checks}
 
@@ -198,7 +204,7 @@ def map_means(y):
     c = y.shape[-1]
     rows = y.numel()//c
     sums = torch.zeros(c, dtype=torch.float64, device=y.device)
-    _check(_native.hip().eae_hip_map_sums(_p(y), _p(sums), rows, c, _stream()), 'eae_hip_map_sums')
+    _check(_native.hip().eae_hip_map_sums(_p(y), _p(sums), rows, c, _stream(y)), 'eae_hip_map_sums')
     return (sums/rows).to(torch.float32)
 
 
@@ -253,7 +259,7 @@ def symbol_histograms(symbols_planar, radius, out=None, first_map=0, map_step=1,
             hist.zero_()
             overflow.zero_()
     _check(_native.hip().eae_hip_symbol_histograms_strided(_p(symbols_planar), _p(hist), radius, _p(overflow), n_maps, map_size,
-                                                           first_map, map_step, _stream()), 'eae_hip_symbol_histograms_strided')
+                                                           first_map, map_step, _stream(symbols_planar)), 'eae_hip_symbol_histograms_strided')
     return hist, overflow
 
 
@@ -319,7 +325,7 @@ def coder_compress_maps(symbols_planar, probabilities, prob_row, truncated_unary
     _check(_native.hip().eae_hip_coder_compress_maps(n_maps, map_size, _p(symbols_planar), _p(reconstruction) if reconstruction is not None else None,
                                                      truncated_unary_length, _p(probabilities), _p(prob_row) if prob_row is not None else None,
                                                      _p(out.streams), out.stride, _p(out.bac_bits), _p(out.bypass_bits), _p(out.status),
-                                                     _p(out.stage), mode, lanes_per_wave, _stream()), 'eae_hip_coder_compress_maps')
+                                                     _p(out.stage), mode, lanes_per_wave, _stream(symbols_planar)), 'eae_hip_coder_compress_maps')
     return out, reconstruction
 
 
@@ -372,7 +378,7 @@ def coder_encode_batch(symbols_planar, probabilities, prob_row, truncated_unary_
         workspace = coder_workspace(n_maps, map_size, truncated_unary_length, symbols_planar.device)
     _check(_native.hip().eae_hip_coder_encode_batch(n_maps, map_size, _p(symbols_planar), truncated_unary_length, _p(probabilities),
                                                     _p(prob_row), _p(out.streams), out.stride, _p(out.bac_bits), _p(out.bypass_bits),
-                                                    _p(out.status), _p(out.stage), _p(workspace), workspace.numel(), _stream()),
+                                                    _p(out.status), _p(out.stage), _p(workspace), workspace.numel(), _stream(symbols_planar)),
            'eae_hip_coder_encode_batch')
     return out
 
@@ -392,7 +398,7 @@ def coder_decode_batch(streams, probabilities, prob_row, expected=None, workspac
     _check(_native.hip().eae_hip_coder_decode_batch(streams.n_maps, streams.map_size, _p(out), _p(expected), streams.truncated_unary_length,
                                                     _p(probabilities), _p(prob_row), _p(streams.streams), streams.stride,
                                                     _p(streams.bac_bits), _p(streams.bypass_bits), _p(streams.status), _p(streams.stage),
-                                                    _p(workspace), workspace.numel() if workspace is not None else 0, _stream()),
+                                                    _p(workspace), workspace.numel() if workspace is not None else 0, _stream(streams.streams)),
            'eae_hip_coder_decode_batch')
     return out
 
@@ -422,7 +428,7 @@ def dequantize_maps(symbols_planar, bin_widths, map_mean=None, want_cq=False, wa
     (n, c, hw) = symbols_planar.shape
     cq = torch.empty((n, hw, c), dtype=torch.float32, device=symbols_planar.device) if want_cq else None
     shifted = torch.empty((n, hw, c), dtype=torch.float32, device=symbols_planar.device) if want_shifted else None
-    _check(_native.hip().eae_hip_dequantize_maps(_p(symbols_planar), _p(bin_widths), _p(map_mean), _p(cq), _p(shifted), n, hw, c, _stream()),
+    _check(_native.hip().eae_hip_dequantize_maps(_p(symbols_planar), _p(bin_widths), _p(map_mean), _p(cq), _p(shifted), n, hw, c, _stream(symbols_planar)),
            'eae_hip_dequantize_maps')
     return {'cq': cq, 'shifted': shifted}
 

@@ -51,7 +51,7 @@ def code_planar_symbols(symbols_planar, binary_probabilities, idx_map_exception=
         raise OverflowError('value too large to convert to numpy.uint8_t')   # interface_cython.pyx:49
     n = nb_images*nb_maps
     prob_row = numpy.tile(numpy.arange(nb_maps, dtype=numpy.int32), nb_images)
-    if idx_map_exception >= 0:
+    if 0 <= idx_map_exception < nb_maps:      # any other index is no exception at all (compression.py:68: `i == idx`)
         prob_row[idx_map_exception::nb_maps] = -1
     nb_bits = numpy.zeros(n, dtype=numpy.uint32)
     status = numpy.zeros(n, dtype=numpy.int32)
@@ -86,7 +86,7 @@ def code_planar_symbols_device(symbols_planar, binary_probabilities, idx_map_exc
         raise OverflowError('value too large to convert to numpy.uint8_t')   # interface_cython.pyx:49
     device = symbols_planar.device
     prob_row = numpy.tile(numpy.arange(nb_maps, dtype=numpy.int32), nb_images)
-    if idx_map_exception >= 0:
+    if 0 <= idx_map_exception < nb_maps:      # any other index is no exception at all (compression.py:68: `i == idx`)
         prob_row[idx_map_exception::nb_maps] = -1
     symbols = symbols_planar.reshape(nb_images*nb_maps, map_size)
     probabilities_device = torch.from_numpy(probabilities).to(device)

@@ -133,16 +133,15 @@ def fix_gamma_batched(reference_uint8, bin_width_init, multipliers, idx_training
         multiplier = multipliers[i].item()
         binary_probabilities = compression.load_binary_probabilities(
             os.path.join(path_to_stats, 'binary_probabilities_{}.npy'.format(tls.float_to_str(multiplier))))
-        batch_codec = codec.BatchCodec(variables, are_bin_widths_learned, multiplier*bin_widths, map_mean, binary_probabilities,
-                                       idx_map_exception, batch_size, h_in, w_in)
-        tickets = [batch_codec.submit(images[lo:lo + batch_size]) for lo in range(0, nb_images, batch_size)]
-        for (k, ticket) in enumerate(tickets):
-            values = ticket.result()
-            sl = slice(k*batch_size, (k + 1)*batch_size)
-            rate[i, sl] = values['nb_bits'].astype(numpy.float64)/(h_in*w_in)
-            psnr[i, sl] = [tls.psnr_from_sse(int(v), h_in*w_in) for v in values['sse']]
-            array_nb_deads[i, sl] = values['nb_deads']
-        batch_codec.close()
+        with codec.BatchCodec(variables, are_bin_widths_learned, multiplier*bin_widths, map_mean, binary_probabilities,
+                              idx_map_exception, batch_size, h_in, w_in) as batch_codec:
+            tickets = [batch_codec.submit(images[lo:lo + batch_size]) for lo in range(0, nb_images, batch_size)]
+            for (k, ticket) in enumerate(tickets):
+                values = ticket.result()      # raises what the image-by-image path raises; the codec is closed either way
+                sl = slice(k*batch_size, (k + 1)*batch_size)
+                rate[i, sl] = values['nb_bits'].astype(numpy.float64)/(h_in*w_in)
+                psnr[i, sl] = [tls.psnr_from_sse(int(v), h_in*w_in) for v in values['sse']]
+                array_nb_deads[i, sl] = values['nb_deads']
     if return_nb_deads:
         return (rate, psnr, array_nb_deads)
     return (rate, psnr)

@@ -16,9 +16,97 @@ Prints ONE JSON line on rank 0 (see DESIGN.md section 6 for the fields).
 import argparse
 import gc
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--gpus', type=int, default=1,
+                        help='ranks = GPUs of this node. N > 1 without a launcher (no WORLD_SIZE in the environment): this '
+                             'process starts N rank processes itself and waits for them; under torch.distributed.run it must '
+                             'equal WORLD_SIZE')
+    parser.add_argument('--steps', type=int, default=100)
+    parser.add_argument('--warmup', type=int, default=10)
+    parser.add_argument('--min-seconds', type=float, default=1.0,
+                        help='the block of --steps timed steps is repeated until this much time has been timed in total '
+                             '(every block bracketed by barrier + synchronize); the MEDIAN block is reported')
+    parser.add_argument('--max-blocks', type=int, default=25)
+    parser.add_argument('--batch', type=int, default=24, help='images per GPU per step (default: the Kodak set)')
+    parser.add_argument('--height', type=int, default=512, help='image height (default 512: Kodak)')
+    parser.add_argument('--width', type=int, default=768, help='image width (default 768: Kodak); e.g. --height 256 --width 256 --batch 64 is one rank of BASELINE.json configs[3]')
+    parser.add_argument('--bin-width', type=float, default=1.0,
+                        help='quantisation bin width of the headline run (1.0: BASELINE.json configs[1]). Random-init weights '
+                             'give a low-entropy latent at 1.0; the `realistic_entropy` side figures repeat the run at smaller '
+                             'widths (more bits per pixel for the coder)')
+    parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--no-single-image', action='store_true', help='skip the side measurements (one image per step, overlapped mode, realistic entropy, host coder)')
+    parser.add_argument('--coder', choices=('device', 'host'), default='device',
+                        help='device: the coder kernels on side streams (default). host: one device -> host copy of the symbols '
+                             'per batch and the host C-ABI coder on a thread pool (the shape BASELINE.json sketches)')
+    parser.add_argument('--coder-threads', type=int, default=0, help='host coder threads (0 = usable CPUs - 2)')
+    parser.add_argument('--coder-streams', type=int, default=int(os.environ.get('EAE_CODER_STREAMS', '2')),
+                        help='batches whose entropy coding may be in flight at once (each on its own HIP stream)')
+    parser.add_argument('--transform-streams', type=int, default=int(os.environ.get('EAE_TRANSFORM_STREAMS', '1')),
+                        help='1 (default): the transforms of consecutive batches run back to back on one stream, so that the HIP '
+                             'events around a launch time that kernel alone (the roofline figures). 2-3: consecutive batches '
+                             'alternate between private streams and their kernels overlap (fills the tails: +6-8 %% whole-job '
+                             'throughput with --coder-streams 3), but a launch then shares the GPU and its duration says little')
+    parser.add_argument('--graphs', action='store_true',
+                        help='replay one captured hipGraph per step instead of launching kernel by kernel (small batches: the '
+                             'launch thread is the bottleneck there). No per-launch events, so no roofline figures')
+    parser.add_argument('--seed-offset', type=int, default=0, help='rank r codes the images of seed 1000 + r + this (tests)')
+    parser.add_argument('--dry-launch', action='store_true',
+                        help='rendezvous check only (no GPU): every rank joins a gloo group, one all-reduce, rank 0 prints n_gpus')
+    args = parser.parse_args(argv)
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        parser.error('--gpus and --steps must be at least 1, --warmup at least 0')
+    return args
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start N FRESH rank processes (one per GPU; RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR, MASTER_PORT in their environment), wait for all of them and return the first non-zero exit
+    code. This process has not touched the GPU (torch is not even imported yet) and never does; nothing is re-exec'ed."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    children = []
+    for rank in range(args.gpus):
+        env = dict(os.environ)
+        env.update({'RANK': str(rank), 'LOCAL_RANK': str(rank), 'WORLD_SIZE': str(args.gpus), 'LOCAL_WORLD_SIZE': str(args.gpus),
+                    'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'EAE_BENCH_SPAWNED': '1'})
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    code = 0
+    try:
+        pending = list(children)
+        while pending:
+            for child in list(pending):
+                rc = child.poll()
+                if rc is None:
+                    continue
+                pending.remove(child)
+                if rc != 0 and code == 0:
+                    code = rc
+                    for other in pending:       # a rank died: the others would wait in a collective for ever
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for child in children:
+            if child.poll() is None:
+                child.kill()
+    return code
+
+
+if __name__ == '__main__':
+    _ARGS = parse_args()
+    if _ARGS.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(_ARGS, sys.argv[1:]))
 
 # The HIP runtime multiplexes streams onto 4 hardware queues by default; streams that land on the same queue serialise.
 # With a transform stream, 2-3 coder streams and optional extra transform streams that aliasing was measured to cost up to
@@ -43,6 +131,9 @@ H_IN, W_IN = 512, 768          # Kodak luminance (datasets/kodak/kodak.py:10-83:
 IDX_MAP_EXCEPTION = 67         # lossless/results/1_10000/training_index_10/idx_map_exception.pkl
 TRUNCATED_UNARY_LENGTH = 10    # collecting_stats_eae_extra.py:44
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+# bin widths of the `realistic_entropy` side figures: with the random-init weights of `synthetic_model` they put the rate
+# near 1 and 2 bits per pixel, the range SURVEY.md 8(d) expects from trained models (the rates are measured and printed)
+REALISTIC_BIN_WIDTHS = (0.25, 0.125)
 
 
 def usable_cpus():
@@ -75,21 +166,49 @@ def synthetic_model(bin_width=1.):
     return v
 
 
-def run_pipeline(args, batch, steps, warmup, device, world, rank, cores, tracing, variables, coder_streams=None,
-                 transform_streams=1, use_graphs=False):
+class Context(object):
+    """What every leg of the benchmark shares: the process group, the device, the CPU budget."""
+
+    def __init__(self, args, device, world, rank, cores):
+        (self.args, self.device, self.world, self.rank, self.cores) = (args, device, world, rank, cores)
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            if dist.get_backend() == 'nccl':
+                dist.barrier(device_ids=[self.device.index])      # RCCL: name the device, no guess from the rank
+            else:
+                dist.barrier()
+        torch.cuda.synchronize()
+
+    def all_reduce(self, tensor, op):
+        if self.world > 1:
+            import torch.distributed as dist
+            if dist.get_backend() != 'nccl':      # gloo (the shared-GPU test hook) reduces host tensors
+                host = tensor.cpu()
+                dist.all_reduce(host, op=getattr(dist.ReduceOp, op))
+                tensor.copy_(host)
+            else:
+                dist.all_reduce(tensor, op=getattr(dist.ReduceOp, op))
+        return tensor
+
+
+def run_pipeline(ctx, batch, steps, warmup, variables, coder='device', coder_streams=2, transform_streams=1, use_graphs=False,
+                 min_seconds=0., max_blocks=1, record_gemm=False, coder_events=False):
     """Builds the resident state for `batch` images per step (codec.BatchCodec: weights, tables, per-slot buffers), runs
-    `warmup` untimed and `steps` timed steps, and returns what the report needs. Everything in here up to the first barrier
+    `warmup` untimed steps, then BLOCKS of exactly `steps` timed steps -- each block bracketed by barrier + synchronize on
+    both sides, its wall time the MAX over ranks -- until `min_seconds` have been timed (at most `max_blocks` blocks; the
+    count is the same on every rank because it is decided from the all-reduced times). Everything up to the first barrier
     is outside the timed region."""
-    if world > 1:
-        import torch.distributed as dist
-    images = torch.from_numpy(synthetic_images(1000 + rank, batch, H_IN, W_IN)).to(device)
-    map_size = (H_IN//16)*(W_IN//16)
+    args = ctx.args
+    (device, world, rank) = (ctx.device, ctx.world, ctx.rank)
+    images = torch.from_numpy(synthetic_images(1000 + rank + args.seed_offset, batch, H_IN, W_IN)).to(device)
+    bin_widths = variables[var.BIN_WIDTHS_NAME]
     # statistics that feed the coder, from this build's own a26/a27 path on the first batch (lossless/stats.py:306, :13-68)
     encoder = pipeline.DeviceEncoder(variables, False, device)
     y0 = encoder(images)
     map_mean_host = dev.map_means(y0).cpu().numpy()
-    probabilities = lossless_stats.compute_binary_probabilities(y0.cpu().numpy(), variables[var.BIN_WIDTHS_NAME], map_mean_host,
-                                                                TRUNCATED_UNARY_LENGTH)
+    probabilities = lossless_stats.compute_binary_probabilities(y0.cpu().numpy(), bin_widths, map_mean_host, TRUNCATED_UNARY_LENGTH)
     del y0, encoder
     gemm_events = []            # (start, stop, launch name) around every conv_gemm launch of the timed region
     recording = [False]
@@ -104,120 +223,146 @@ def run_pipeline(args, batch, steps, warmup, device, world, rank, cores, tracing
         gemm_events.append((a, b, name))
         return out
 
-    coder_mode = 'none' if os.environ.get('EAE_BENCH_NO_CODER') else args.coder      # 'none': diagnostic only
-    coder_threads = args.coder_threads if args.coder_threads > 0 else max(1, cores//max(world, 1) - 2)
-    the_codec = codec.BatchCodec(variables, False, variables[var.BIN_WIDTHS_NAME], map_mean_host, probabilities, IDX_MAP_EXCEPTION,
-                                 batch, H_IN, W_IN, device=device, nb_in_flight=coder_streams or args.coder_streams,
-                                 launch_hook=timed_launch, coder=coder_mode, host_coder_threads=coder_threads,
-                                 nb_transform_streams=transform_streams, use_graphs=use_graphs)
+    coder_mode = 'none' if os.environ.get('EAE_BENCH_NO_CODER') else coder      # 'none': diagnostic only
+    coder_threads = args.coder_threads if args.coder_threads > 0 else max(1, ctx.cores//max(world, 1) - 2)
+    with codec.BatchCodec(variables, False, bin_widths, map_mean_host, probabilities, IDX_MAP_EXCEPTION, batch, H_IN, W_IN,
+                          device=device, nb_in_flight=coder_streams, launch_hook=timed_launch if record_gemm else None,
+                          coder=coder_mode, host_coder_threads=coder_threads, nb_transform_streams=transform_streams,
+                          use_graphs=use_graphs, time_coder=coder_events) as the_codec:
+        for _ in range(warmup):
+            the_codec.submit(images)
+        the_codec.drain()
+        # the launch thread allocates only short-lived wrappers: keep the cyclic collector (a 30 ms pause every ~75 steps) out of it
+        gc.collect()
+        gc.disable()
+        recording[0] = True
+        block_seconds = []
+        stats = torch.zeros(4, dtype=torch.float64, device=device)
+        coder_ms = []
+        while True:
+            ctx.barrier()
+            t0 = time.perf_counter()
+            tickets = [the_codec.submit(images) for _ in range(steps)]
+            the_codec.drain()
+            results = [t.result() for t in tickets]          # raises here if any map of any batch failed
+            # the path's only exchange step: sum the rate / PSNR accumulators over ranks
+            block_stats = torch.tensor([float(sum(int(r['nb_bits'].sum()) for r in results)), float(sum(int(r['sse'].sum()) for r in results)),
+                                        float(sum(int(r['nb_deads'].sum()) for r in results)), float(steps*batch)],
+                                       dtype=torch.float64, device=device)
+            ctx.all_reduce(block_stats, 'SUM')
+            ctx.barrier()
+            elapsed = time.perf_counter() - t0
+            te = ctx.all_reduce(torch.tensor([elapsed], dtype=torch.float64, device=device), 'MAX')
+            block_seconds.append(float(te.item()))
+            stats += block_stats
+            coder_ms.extend(t.coder_ms() for t in tickets if coder_events)
+            if sum(block_seconds) >= min_seconds or len(block_seconds) >= max_blocks:
+                break
+        gc.enable()
+    ordered = sorted(block_seconds)
+    median = ordered[(len(ordered) - 1)//2]      # an actual block (the lower median when the count is even)
+    return {'elapsed': median, 'block_seconds': block_seconds, 'stats': stats, 'gemm_events': gemm_events,
+            'probabilities': probabilities, 'map_mean_host': map_mean_host, 'host_coder': coder_mode == 'host',
+            'coder_threads': coder_threads, 'coder_ms': coder_ms}
 
-    def barrier():
-        if world > 1:
-            if dist.get_backend() == 'nccl':
-                dist.barrier(device_ids=[device.index])      # RCCL: name the device, no guess from the rank
-            else:
-                dist.barrier()
+
+def rate_and_psnr(stats):
+    nb_images = stats[3].item()
+    bpp = stats[0].item()/(nb_images*H_IN*W_IN)
+    psnr = float(tls.psnr_from_sse(stats[1].item(), nb_images*H_IN*W_IN))   # PSNR of the pooled MSE
+    return (bpp, psnr)
+
+
+def coder_alone_ms(ctx, batch, variables, repeats=20):
+    """The coder chain of one batch (binarise + encode, decode + compare) timed with HIP events on an otherwise idle GPU:
+    the serial depth the transforms of the batches in flight have to cover."""
+    device = ctx.device
+    images = torch.from_numpy(synthetic_images(1000 + ctx.rank, batch, H_IN, W_IN)).to(device)
+    bin_widths = variables[var.BIN_WIDTHS_NAME]
+    y = pipeline.DeviceEncoder(variables, False, device)(images)
+    map_mean = dev.map_means(y)
+    probabilities = lossless_stats.compute_binary_probabilities(y.cpu().numpy(), bin_widths, map_mean.cpu().numpy(), TRUNCATED_UNARY_LENGTH)
+    q = dev.quantize_maps(y, torch.from_numpy(bin_widths).to(device), map_mean, want_symbols=True)
+    symbols = q['symbols'].reshape(batch*128, -1)
+    prob_row = torch.arange(128, dtype=torch.int32).repeat(batch)
+    prob_row[IDX_MAP_EXCEPTION::128] = -1
+    prob_row = prob_row.to(device)
+    prob = torch.from_numpy(probabilities).to(device)
+    streams = dev.CoderStreams(batch*128, symbols.shape[1], TRUNCATED_UNARY_LENGTH, device)
+    workspace = dev.coder_workspace(batch*128, symbols.shape[1], TRUNCATED_UNARY_LENGTH, device)
+    (enc_ms, dec_ms) = ([], [])
+    for i in range(repeats + 3):
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        marks[0].record()
+        dev.coder_encode_batch(symbols, prob, prob_row, TRUNCATED_UNARY_LENGTH, out=streams, workspace=workspace)
+        marks[1].record()
+        dev.coder_decode_batch(streams, prob, prob_row, expected=symbols, workspace=workspace)
+        marks[2].record()
         torch.cuda.synchronize()
-
-    for _ in range(warmup):
-        the_codec.submit(images)
-    the_codec.drain()
-
-    # the launch thread allocates only short-lived wrappers: keep the cyclic collector (a 30 ms pause every ~75 steps) out of it
-    gc.collect()
-    gc.disable()
-    recording[0] = True
-    barrier()
-    t0 = time.perf_counter()
-    step_marks = []
-    tickets = []
-    for _ in range(steps):
-        if tracing:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            step_marks.append((time.perf_counter() - t0, ev))
-        tickets.append(the_codec.submit(images))
-    the_codec.drain()
-    results = [t.result() for t in tickets]          # raises here if any map of any batch failed
-    # the path's only exchange step: sum the rate / PSNR accumulators over ranks
-    stats = torch.tensor([float(sum(int(r['nb_bits'].sum()) for r in results)), float(sum(int(r['sse'].sum()) for r in results)),
-                          float(sum(int(r['nb_deads'].sum()) for r in results)), float(steps*batch)], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    the_codec.close()
-    return {'elapsed': elapsed, 'stats': stats, 'gemm_events': gemm_events, 'probabilities': probabilities,
-            'map_mean_host': map_mean_host, 'host_coder': coder_mode == 'host', 'coder_threads': coder_threads,
-            'step_marks': step_marks}
+        if i >= 3:
+            enc_ms.append(marks[0].elapsed_time(marks[1]))
+            dec_ms.append(marks[1].elapsed_time(marks[2]))
+    results = streams.results.cpu().numpy()
+    if results[2].any():
+        raise RuntimeError('the coder reported a status on the benchmark symbols')
+    return (sorted(enc_ms)[len(enc_ms)//2], sorted(dec_ms)[len(dec_ms)//2])
 
 
-def main():
+def main(args):
     global H_IN, W_IN
-    parser = argparse.ArgumentParser()
-    parser.add_argument('--gpus', type=int, default=1)
-    parser.add_argument('--steps', type=int, default=100)
-    parser.add_argument('--warmup', type=int, default=10)
-    parser.add_argument('--batch', type=int, default=24, help='images per GPU per step (default: the Kodak set)')
-    parser.add_argument('--height', type=int, default=H_IN, help='image height (default 512: Kodak)')
-    parser.add_argument('--width', type=int, default=W_IN, help='image width (default 768: Kodak); e.g. --height 256 --width 256 --batch 64 is one rank of BASELINE.json configs[3]')
-    parser.add_argument('--no-cpu-baseline', action='store_true')
-    parser.add_argument('--no-single-image', action='store_true', help='skip the one-image-per-step side measurement')
-    parser.add_argument('--coder', choices=('device', 'host'), default='device',
-                        help='device: the coder kernels on side streams (default). host: one device -> host copy of the symbols '
-                             'per batch and the host C-ABI coder on a thread pool (the shape BASELINE.json sketches)')
-    parser.add_argument('--coder-threads', type=int, default=0, help='host coder threads (0 = usable CPUs - 2)')
-    parser.add_argument('--coder-streams', type=int, default=int(os.environ.get('EAE_CODER_STREAMS', '2')),
-                        help='batches whose entropy coding may be in flight at once (each on its own HIP stream)')
-    parser.add_argument('--transform-streams', type=int, default=int(os.environ.get('EAE_TRANSFORM_STREAMS', '1')),
-                        help='1 (default): the transforms of consecutive batches run back to back on one stream, so that the HIP '
-                             'events around a launch time that kernel alone (the roofline figures). 2-3: consecutive batches '
-                             'alternate between private streams and their kernels overlap (fills the tails: +6-8 %% whole-job '
-                             'throughput with --coder-streams 3), but a launch then shares the GPU and its duration says little')
-    parser.add_argument('--graphs', action='store_true',
-                        help='replay one captured hipGraph per step instead of launching kernel by kernel (small batches: the '
-                             'launch thread is the bottleneck there). No per-launch events, so no roofline figures')
-    args = parser.parse_args()
     (H_IN, W_IN) = (args.height, args.width)
 
     # two Python threads share the GIL (kernel launches; the codec's result worker): hand it over quickly
     sys.setswitchinterval(1e-4)
-    tracing = bool(os.environ.get('EAE_BENCH_TRACE'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus {0} but WORLD_SIZE is {1}: run `python bench.py --gpus N` (it starts its own N ranks) '
+                         'or `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`.'.format(args.gpus, world))
+    share_gpu = bool(os.environ.get('EAE_BENCH_SHARE_GPU'))      # test hook: several ranks on one GPU (gloo instead of RCCL)
+    if args.dry_launch:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        if os.environ.get('EAE_BENCH_FAIL_RANK') == str(rank):      # test hook: a rank that dies before the rendezvous
+            raise SystemExit(3)
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        count = torch.tensor([1.], dtype=torch.float64)
+        dist.all_reduce(count)
+        if rank == 0:
+            print(json.dumps({'dry_launch': True, 'n_gpus': world, 'ranks_seen': int(count.item()), 'local_rank': local_rank}))
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the product path.')
-    if os.environ.get('EAE_BENCH_SHARE_GPU'):      # test hook: several ranks on one GPU (gloo instead of RCCL)
+    if share_gpu:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit('bench.py: rank {0} has no GPU (this node shows {1}); one process per GPU.'.format(local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='gloo' if os.environ.get('EAE_BENCH_SHARE_GPU') else 'nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend='gloo' if share_gpu else 'nccl', rank=rank, world_size=world)
     device = torch.device('cuda', local_rank)
     cores = usable_cpus()
     os.environ.setdefault('OMP_NUM_THREADS', str(cores))      # the oracle's OpenMP transforms (cpu_baseline only)
+    ctx = Context(args, device, world, rank, cores)
 
-    variables = synthetic_model(1.)
-    run = run_pipeline(args, args.batch, args.steps, args.warmup, device, world, rank, cores, tracing, variables,
-                       transform_streams=args.transform_streams, use_graphs=args.graphs)
+    variables = synthetic_model(args.bin_width)
+    run = run_pipeline(ctx, args.batch, args.steps, args.warmup, variables, coder=args.coder, coder_streams=args.coder_streams,
+                       transform_streams=args.transform_streams, use_graphs=args.graphs, min_seconds=args.min_seconds,
+                       max_blocks=args.max_blocks, record_gemm=True)
     (elapsed, stats, gemm_events, probabilities, map_mean_host) = (run['elapsed'], run['stats'], run['gemm_events'],
                                                                     run['probabilities'], run['map_mean_host'])
-    (host_coder, coder_threads, step_marks) = (run['host_coder'], run['coder_threads'], run['step_marks'])
+    (host_coder, coder_threads) = (run['host_coder'], run['coder_threads'])
 
     # ---- derived figures (outside the timed region) ------------------------------------------------------------------
     pixels_per_step = args.batch*H_IN*W_IN
-    total_pixels = pixels_per_step*args.steps*world
-    value = total_pixels/elapsed/1e6
+    value = pixels_per_step*args.steps*world/elapsed/1e6
     nb_images_total = stats[3].item()
-    bpp = stats[0].item()/(nb_images_total*H_IN*W_IN)
-    mean_psnr = float(tls.psnr_from_sse(stats[1].item(), nb_images_total*H_IN*W_IN))   # PSNR of the pooled MSE
+    (bpp, mean_psnr) = rate_and_psnr(stats)
     flops = {'conv2_gdn2': pipeline.FLOP_PER_PIXEL['conv2_gdn2'], 'conv3': 2*1600,      # gdn_3 runs in the latent-stage kernel
              'tconv1_igdn5': pipeline.FLOP_PER_PIXEL['tconv1_igdn5'], 'tconv2_igdn6': pipeline.FLOP_PER_PIXEL['tconv2_igdn6']}
     per_launch_ms = {}
@@ -232,56 +377,89 @@ def main():
     if os.path.isfile(traffic_file):
         with open(traffic_file) as f:
             traffic = json.load(f).get('hbm_bytes_per_launch')
+    blocks = run['block_seconds']
     line = {
         'metric': 'Mpixels/s encode+decode (Kodak 768x512 luma), bitstream bit-exact',
         'value': round(value, 3), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed/args.steps*1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': '{0}_{1}x{2}_luma_batch{3}_per_gpu_bin_width_1.0_lossless_roundtrip'.format(
-                       'kodak' if (H_IN, W_IN) == (512, 768) else 'synthetic', H_IN, W_IN, args.batch),
-                   'images_per_gpu_per_step': args.batch, 'height': H_IN, 'width': W_IN, 'bin_width_multiplier': 1.0,
+        'config': {'workload': '{0}_{1}x{2}_luma_batch{3}_per_gpu_bin_width_{4}_lossless_roundtrip'.format(
+                       'kodak' if (H_IN, W_IN) == (512, 768) else 'synthetic', H_IN, W_IN, args.batch, args.bin_width),
+                   'images_per_gpu_per_step': args.batch, 'height': H_IN, 'width': W_IN, 'bin_width_multiplier': args.bin_width,
                    'truncated_unary_length': TRUNCATED_UNARY_LENGTH, 'idx_map_exception': IDX_MAP_EXCEPTION,
                    'weights': 'random-init fixed-bin-width architecture (trained checkpoints absent from the reference)',
                    'parallelism': 'image shards, one process per GPU' if world > 1 else 'single GPU',
                    'coder': 'device, 64 maps per wavefront, encode + decode + compare' if not host_coder else
                             'host C-ABI coder, {} threads, after one device -> host copy of the symbols'.format(coder_threads)},
-        'images_per_s': round(nb_images_total/elapsed, 2),
+        'timing': {'blocks': len(blocks), 'steps_per_block': args.steps, 'reported': 'median block',
+                   'block_ms': [round(b*1e3, 3) for b in blocks], 'min_block_ms': round(min(blocks)*1e3, 3),
+                   'max_block_ms': round(max(blocks)*1e3, 3), 'spread_pct': round((max(blocks) - min(blocks))/elapsed*100., 2),
+                   'timed_seconds': round(sum(blocks), 4)},
+        'images_per_s': round(args.batch*args.steps*world/elapsed, 2),
+        # summed over ranks by the path's one all-reduce, over all timed blocks: exact integers (tests compare them across world sizes)
+        'totals': {'bits': int(stats[0].item()), 'sse': int(stats[1].item()), 'dead_maps': int(stats[2].item()), 'images': int(nb_images_total)},
         'rate_bpp': round(bpp, 5), 'psnr_db_pooled': round(mean_psnr, 4), 'dead_maps_per_image': round(stats[2].item()/nb_images_total, 3),
         'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_wave_kernel (conv2+GDN2, conv3, tconv1+IGDN5, tconv2+IGDN6)',
                      'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(achieved/PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
                      'avg_launch_ms': round(gemm_ms/max(gemm_launches, 1), 4),
                      'per_launch_ms': {k: round(sum(v)/len(v), 4) for (k, v) in per_launch_ms.items()},
+                     'per_launch_frac': {k: round(flops[k]*pixels_per_step/(sum(v)/len(v)*1e-3)/1e12/PEAK_F32_MFMA_TFLOPS, 4)
+                                         for (k, v) in per_launch_ms.items()},
                      'algorithmic_flop_per_launch': {k: flops[k]*pixels_per_step for k in flops}},
     }
-    if step_marks:
-        host = [round(m[0]*1e3, 2) for m in step_marks]
-        gpu = [round(step_marks[0][1].elapsed_time(m[1]), 2) for m in step_marks]
-        sys.stderr.write('TRACE host enqueue deltas (ms): {}\nTRACE gpu step deltas (ms): {}\nTRACE total ms {}\n'.format(
-            [round(b - a, 1) for (a, b) in zip(host[:-1], host[1:])], [round(b - a, 1) for (a, b) in zip(gpu[:-1], gpu[1:])], round(elapsed*1e3, 2)))
-    if rank == 0 and world == 1 and args.batch != 1 and not args.no_single_image and (H_IN, W_IN) == (512, 768):
+    del run, gemm_events
+    side = rank == 0 and world == 1 and not args.no_single_image
+    if side and args.batch != 1 and (H_IN, W_IN) == (512, 768):
         # BASELINE.json configs[1] is ONE Kodak image: the same path with one image per step (launch-bound, not the headline)
-        del run, gemm_events
-        one = run_pipeline(args, 1, 300, 30, device, world, rank, cores, False, variables, coder_streams=8, transform_streams=6,
-                           use_graphs=True)
+        one = run_pipeline(ctx, 1, 300, 30, variables, coder_streams=8, transform_streams=6, use_graphs=True)
         line['single_image'] = {'ms_per_image': round(one['elapsed']/300*1e3, 4),
                                 'mpixels_per_s': round(300*H_IN*W_IN/one['elapsed']/1e6, 2), 'steps': 300, 'warmup': 30,
                                 'note': 'one 512x768 image per step; a step is a chain of short latency-bound kernels, so steps '
                                         'are pipelined: 6 transform streams, 8 coder streams, three hipGraph launches per step'}
-    if rank == 0 and world == 1 and not args.no_single_image and args.transform_streams == 1 and not args.graphs:
+    if side and args.transform_streams == 1 and not args.graphs:
         # the same batch in the opt-in overlapped mode (consecutive batches on alternating transform streams, three batches of
         # coder work in flight, a step replayed as three hipGraphs): whole-job rate only -- launches share the GPU, so there
         # are no per-launch durations to report
-        over = run_pipeline(args, args.batch, 100, 15, device, world, rank, cores, False, variables, coder_streams=3,
-                            transform_streams=2, use_graphs=True)
+        over = run_pipeline(ctx, args.batch, 100, 15, variables, coder_streams=3, transform_streams=2, use_graphs=True)
         line['overlapped_mode'] = {'value': round(100*args.batch*H_IN*W_IN/over['elapsed']/1e6, 3), 'unit': 'Mpixels/s',
                                    'ms_per_step': round(over['elapsed']/100*1e3, 4), 'steps': 100, 'warmup': 15,
                                    'flags': '--transform-streams 2 --coder-streams 3 --graphs'}
+    if side and args.coder == 'device':
+        # north_star's original shape (one device -> host copy of the symbols, the host C-ABI coder on the CPUs the quota allows)
+        host = run_pipeline(ctx, args.batch, 30, 5, variables, coder='host', coder_streams=args.coder_streams, min_seconds=0.5, max_blocks=5)
+        line['host_coder'] = {'value': round(30*args.batch*H_IN*W_IN/host['elapsed']/1e6, 3), 'unit': 'Mpixels/s',
+                              'ms_per_step': round(host['elapsed']/30*1e3, 4), 'steps': 30, 'warmup': 5, 'blocks': len(host['block_seconds']),
+                              'threads': host['coder_threads'], 'usable_cpus': cores, 'rate_bpp': round(rate_and_psnr(host['stats'])[0], 5),
+                              'flags': '--coder host'}
+        # a latent with the entropy of a trained model: the same path at smaller bin widths. How long the coder chain of a batch
+        # is on its own, what a step costs with and without it, hence whether the transforms still hide it.
+        line['realistic_entropy'] = []
+        os.environ['EAE_BENCH_NO_CODER'] = '1'
+        bare = run_pipeline(ctx, args.batch, 30, 5, variables, coder_streams=args.coder_streams, min_seconds=0.3, max_blocks=5)
+        del os.environ['EAE_BENCH_NO_CODER']
+        for width in (args.bin_width,) + tuple(w for w in REALISTIC_BIN_WIDTHS if w < args.bin_width):
+            v_w = synthetic_model(width)
+            leg = run_pipeline(ctx, args.batch, 30, 5, v_w, coder_streams=args.coder_streams, min_seconds=0.5, max_blocks=5, coder_events=True)
+            (enc_ms, dec_ms) = coder_alone_ms(ctx, args.batch, v_w)
+            (leg_bpp, leg_psnr) = rate_and_psnr(leg['stats'])
+            ms_step = leg['elapsed']/30*1e3
+            ms_bare = bare['elapsed']/30*1e3
+            in_pipe = sorted(leg['coder_ms'])[len(leg['coder_ms'])//2]
+            line['realistic_entropy'].append({
+                'bin_width': width, 'rate_bpp': round(leg_bpp, 4), 'psnr_db_pooled': round(leg_psnr, 3),
+                'value': round(30*args.batch*H_IN*W_IN/leg['elapsed']/1e6, 3), 'ms_per_step': round(ms_step, 4),
+                'ms_per_step_without_coder': round(ms_bare, 4),
+                'coder_alone_ms_per_batch': {'binarise_encode': round(enc_ms, 4), 'decode_compare': round(dec_ms, 4)},
+                'coder_in_pipeline_ms_per_batch': round(in_pipe, 4), 'coder_streams': args.coder_streams,
+                'coder_on_critical_path': bool(in_pipe > args.coder_streams*ms_step*0.95)})
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(variables, probabilities, map_mean_host, cores)
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 
@@ -341,4 +519,4 @@ def cpu_baseline(variables, probabilities, map_mean, cores):
 
 
 if __name__ == '__main__':
-    main()
+    main(_ARGS)

@@ -1,7 +1,7 @@
 """BASELINE.json configs[2]: the 24-image Kodak-shaped set at bin-width multipliers {0.5, 1.0, 2.0}: rate (bits per pixel of
 the lossless code, exception map charged its entropy like compression.py:68-75) and PSNR per image from the MI355X path
 (codec.BatchCodec) next to the CPU evaluation (oracle/transforms_oracle.c for the transforms, the reference's own C++
-coder from oracle/_ref, numpy for the rest). Writes profiles/r01_rate_psnr_curve.json. Checker use of oracle/: this is a
+coder from oracle/_ref, numpy for the rest). Writes profiles/rate_psnr_curve.json. Checker use of oracle/: this is a
 test script, not product code."""
 import json, os, sys, time
 import numpy, torch
@@ -59,4 +59,4 @@ for m in (0.5, 1.0, 2.0):
                           'gpu_equals_cpu_bits_and_sse_for_all_images': same, 'gpu_wall_s_cold': round(t_gpu, 3), 'cpu_wall_s': round(t_cpu, 1),
                           'rate_bpp_per_image': [round(float(b)/(H*W), 5) for b in bits], 'psnr_db_per_image': [round(float(p), 4) for p in psnr]})
     print(out['points'][-1]['multiplier'], out['points'][-1]['rate_bpp_mean'], out['points'][-1]['psnr_db_mean'], same, t_gpu, t_cpu)
-json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'r01_rate_psnr_curve.json'), 'w'), indent=1)
+json.dump(out, open(os.path.join(ROOT, 'gpurun_out', 'rate_psnr_curve.json'), 'w'), indent=1)

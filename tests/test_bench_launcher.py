@@ -1,0 +1,74 @@
+"""`python bench.py --gpus N` must run N ranks (missing #1: the flag was parsed and ignored, so the
+driver's scaling run would have measured one GPU). The launcher starts N fresh rank processes before anything touches the
+GPU; under an external launcher a mismatch between --gpus and WORLD_SIZE is an error."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def run_bench(argv, env_extra=None, timeout=900):
+    env = {k: v for (k, v) in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(env_extra or {})
+    proc = subprocess.run([sys.executable, BENCH] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          universal_newlines=True, timeout=timeout, cwd=ROOT)
+    lines = [line for line in proc.stdout.splitlines() if line.startswith('{')]
+    return (proc, [json.loads(line) for line in lines])
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_launcher_starts_one_process_per_rank(world):
+    """CPU rendezvous check: N children, each with its own RANK / LOCAL_RANK, one JSON line from rank 0."""
+    (proc, lines) = run_bench(['--gpus', str(world), '--dry-launch'])
+    assert proc.returncode == 0, proc.stderr
+    assert len(lines) == 1
+    assert lines[0] == {'dry_launch': True, 'n_gpus': world, 'ranks_seen': world, 'local_rank': 0}
+
+
+def test_world_size_mismatch_is_an_error():
+    (proc, lines) = run_bench(['--gpus', '4', '--dry-launch'], {'WORLD_SIZE': '2', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert proc.returncode != 0 and not lines
+    assert '--gpus 4 but WORLD_SIZE is 2' in proc.stderr
+
+
+def test_a_failing_rank_fails_the_launch():
+    """A rank that dies must not leave the others waiting in a collective: non-zero exit, promptly."""
+    (proc, lines) = run_bench(['--gpus', '2', '--dry-launch'], {'EAE_BENCH_FAIL_RANK': '1'}, timeout=120)
+    assert proc.returncode != 0 and not lines
+
+
+def test_under_an_external_launcher_the_flag_must_agree():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` (the driver's form): no second level of children."""
+    env = {k: v for (k, v) in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    proc = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                           '--master-port', '29533', BENCH, '--gpus', '2', '--dry-launch'], env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, universal_newlines=True, timeout=600, cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr
+    lines = [json.loads(line) for line in proc.stdout.splitlines() if line.startswith('{')]
+    assert lines == [{'dry_launch': True, 'n_gpus': 2, 'ranks_seen': 2, 'local_rank': 0}]
+
+
+@pytest.mark.gpu
+def test_two_ranks_through_the_flag_on_one_gpu():
+    """The real path with two ranks sharing this box's one GPU (gloo instead of RCCL): n_gpus == 2, and the all-reduced
+    integer totals are the sum of the two one-rank runs on the same images."""
+    common = ['--steps', '3', '--warmup', '1', '--batch', '4', '--no-cpu-baseline', '--no-single-image', '--min-seconds', '0']
+    (proc, lines) = run_bench(['--gpus', '2'] + common, {'EAE_BENCH_SHARE_GPU': '1'})
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert len(lines) == 1
+    two = lines[0]
+    assert two['n_gpus'] == 2 and two['scaling'] == 'weak' and two['timing']['blocks'] == 1
+    singles = []
+    for offset in (0, 1):
+        (proc, lines) = run_bench(['--gpus', '1', '--seed-offset', str(offset)] + common)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        assert lines[0]['n_gpus'] == 1
+        singles.append(lines[0]['totals'])
+    for key in ('bits', 'sse', 'dead_maps', 'images'):
+        assert two['totals'][key] == singles[0][key] + singles[1][key], key
+    assert two['totals']['images'] == 2*3*4

@@ -89,6 +89,38 @@ def test_malformed_blobs_and_arguments(model):
         pass
 
 
+def test_mutated_header_bit_counts(model):
+    """Per-map bit counts are untrusted: above a stream's capacity -> ValueError on the host (nothing launched); within the
+    capacity but wrong (payload resized to match) -> the unpacking stays inside every map's region, decoding gives
+    something or raises the coder's error."""
+    from autoencoder_based_image_compression_amd import container
+    images = numpy.random.RandomState(3).randint(16, 236, size=(2, 32, 48)).astype(numpy.uint8)
+    ones = numpy.ones(128, dtype=numpy.float32)
+    (blob, _) = container.encode_images(images, model['encoder'], ones, 0*ones, model['probabilities'], 67)
+    header = container.read_header(blob)
+    start = header['payload_offset'] - header['bits'].nbytes
+    capacity = container.stream_capacity_bits(6, header['truncated_unary_length'])
+
+    def with_bits(bits):
+        payload = int(((bits.astype(numpy.int64) + 7)//8).sum())
+        body = blob[header['payload_offset']:]
+        body = body[:payload] + bytes(max(0, payload - len(body)))
+        return blob[:start] + bits.astype(numpy.uint32).tobytes() + body
+
+    for (row, col) in ((0, 0), (255, 1), (100, 0)):
+        bits = header['bits'].copy()
+        bits[row, col] = capacity + 1
+        with pytest.raises(ValueError):
+            container.decode_symbols(with_bits(bits))
+        bits[row, col] = capacity                     # legal size, wrong content
+        try:
+            container.decode_images(with_bits(bits), model['decoder'])
+        except RuntimeError:
+            pass
+    # the GPU is still in working order afterwards
+    assert numpy.array_equal(container.decode_images(blob, model['decoder']), in_memory_path(model, images, ones, 0*ones)[1])
+
+
 def test_full_kodak_image(model):
     """BASELINE.json configs[1] size: one 512x768 image through the file and back."""
     from autoencoder_based_image_compression_amd import container

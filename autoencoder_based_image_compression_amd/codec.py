@@ -211,6 +211,8 @@ class BatchCodec(object):
                                                 results=self._views(self._slot_out[i])[0]) for i in range(self.nb_slots)]
         self._workspaces = [dev.coder_workspace(n_maps, self.map_size, self.truncated_unary_length, self.device)
                             for _ in range(self.nb_slots)]
+        # scratch that lets the conv GEMM launches cut their last tiles (device.conv_workspace): a slot's launches never overlap each other
+        self._conv_ws = [dev.conv_workspace(self.device) for _ in range(self.nb_slots)]
         self._slot_free = [threading.Event() for _ in range(self.nb_slots)]
         for event in self._slot_free:
             event.set()
@@ -350,8 +352,9 @@ class BatchCodec(object):
         v = enc.v
         d = self.decoder.v
         gdn_1 = dev.conv9x9s4_u8(luminances_uint8, enc.w1, v['encoder/biases_1'], enc.g[1], v['encoder/beta_1'])
-        gdn_2 = hook('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, enc.w2, v['encoder/biases_2'], dev.NORM_GDN, enc.g[2], v['encoder/beta_2']))
-        y_raw = hook('conv3', lambda: dev.conv5x5s2(gdn_2, enc.w3, v['encoder/biases_3'], dev.NORM_NONE))
+        ws = self._conv_ws[slot]
+        gdn_2 = hook('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, enc.w2, v['encoder/biases_2'], dev.NORM_GDN, enc.g[2], v['encoder/beta_2'], workspace=ws))
+        y_raw = hook('conv3', lambda: dev.conv5x5s2(gdn_2, enc.w3, v['encoder/biases_3'], dev.NORM_NONE, workspace=ws))
         (_, hist, overflow, flags, checks) = self._views(self._slot_out[slot])
         self._slot_all[slot][4*self._n_maps:].zero_()    # histograms, overflow, flags, checks, squared errors: accumulated into
         # gdn_3 -> centre / quantise / symbols / dead-map flags -> de-centre -> inverse_gdn_4: one pass over the latents
@@ -386,8 +389,9 @@ class BatchCodec(object):
         hook = hook or self._no_hook
         dec = self.decoder
         d = dec.v
-        t = hook('tconv1_igdn5', lambda: dev.tconv5x5s2(latents, dec.w4, d['decoder/biases_4'], dev.NORM_IGDN, dec.g[5], d['decoder/beta_5']))
-        t = hook('tconv2_igdn6', lambda: dev.tconv5x5s2(t, dec.w5, d['decoder/biases_5'], dev.NORM_IGDN, dec.g[6], d['decoder/beta_6']))
+        ws = self._conv_ws[slot]
+        t = hook('tconv1_igdn5', lambda: dev.tconv5x5s2(latents, dec.w4, d['decoder/biases_4'], dev.NORM_IGDN, dec.g[5], d['decoder/beta_5'], workspace=ws))
+        t = hook('tconv2_igdn6', lambda: dev.tconv5x5s2(t, dec.w5, d['decoder/biases_5'], dev.NORM_IGDN, dec.g[6], d['decoder/beta_6'], workspace=ws))
         (_, reconstruction, _) = dev.tconv9x9s4_luma(t, dec.w6, want_f32=False, want_u8=True, ref_u8=luminances_uint8,
                                                      sse=self._slot_sse[slot])
         dev.publish_to_host(self._slot_sse[slot], self._pinned_sse[slot])

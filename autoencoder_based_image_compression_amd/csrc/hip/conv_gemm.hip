@@ -24,42 +24,14 @@
 //    after them, ONE barrier per K-step; two blocks per CU overlap each other's staging.
 // Roofline: f32 MFMA 157.3 TFLOP/s. Per 128-position tile and 25 taps: 105 MFLOP against 1.6 MB of weights
 // (L2-resident, shared by every block) and ~0.34 MB of activations.
-#include "common.h"
+#include "conv_gemm.h"
 
 #include <cstdlib>
 
+using namespace eae_conv_gemm;
+
 namespace {
 
-constexpr int KC = 32;           // K-step (input channels per LDS slab)
-constexpr int AS_STRIDE = 36;    // floats per position: [2 parities][16] + 4 pad (16-byte aligned, conflict-free b128)
-constexpr int XS_STRIDE = EAE_XS_STRIDE;   // epilogue tile [TM][128] (+1)
-constexpr int MAX_TAPS = 25;
-constexpr int TILE_H = 8;
-
-struct PhaseDesc {
-    int out_a, out_b;            // output pixel = position * out_stride + (out_a, out_b)
-    int ntaps;
-    // per tap, packed in one dword (sub-dword kernarg arrays get copied to scratch by the compiler):
-    //   bits 0-7 off_r + 8, bits 8-15 off_c + 8 (input pixel = position * in_stride + (off_r, off_c)),
-    //   bits 16-23 slab index into the packed weights [T][128][128]
-    int tap[MAX_TAPS];
-};
-inline int pack_tap(int off_r, int off_c, int widx) { return (off_r + 8) | ((off_c + 8) << 8) | (widx << 16); }
-
-struct ConvGemmParams {
-    const float* in;     // [N][Hin][Win][128]
-    float* out;          // [N][Hout][Wout][128]
-    const float* w;      // packed [T][128 ci][128 co permuted]
-    const float* bias;   // [128] or nullptr
-    const float* gamma;  // packed [128 k][128 c permuted] or nullptr
-    const float* beta;   // [128]
-    int norm;            // EAE_NORM_*
-    int n, hin, win, hp, wp, hout, wout;
-    int in_stride, out_stride;
-    int tiles_r, tiles_c, n_phases;
-    unsigned long long* stamps;   // diagnostic only (eae_hip_debug_set_stamp_buffer): 8 x u64 per wave, else nullptr
-    PhaseDesc phase[4];
-};
 unsigned long long* g_stamp_buffer = nullptr;
 
 template <int TM>
@@ -446,8 +418,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
 }
 
 int launch(ConvGemmParams& p, hipStream_t stream) {
-    static const int variant = [] { const char* e = std::getenv("EAE_HIP_GEMM"); return (e && e[0] == 'l') ? 0 : 1; }();
+    // EAE_HIP_GEMM (read per launch: the parity tests run every form and compare bits):
+    //   unset  conv_gemm_split.hip (one item per wave; the last tiles cut when the shape calls for it and the caller gave a
+    //          workspace) for layers with at least one 32-position tile per SIMD, the small-layer forms below otherwise;
+    //   's'    conv_gemm_split.hip with the cut forced, sized for EAE_HIP_SPLIT_WAVES (1..3, default 3) waves per SIMD;
+    //   'u'    conv_gemm_split.hip, whole tiles only;   'w'  conv_gemm_wave_kernel;   'l'  block-cooperative LDS slabs.
+    const char* form = std::getenv("EAE_HIP_GEMM");
+    const char f = form ? form[0] : 0;
+    const int variant = f == 'l' ? 0 : 1;
     p.stamps = g_stamp_buffer;
+    if (f == 's' || f == 'u' || f == 0) {
+        int cut = f == 'u' ? 0 : -1;
+        if (f == 's') {
+            const char* e = std::getenv("EAE_HIP_SPLIT_WAVES");
+            cut = e ? std::atoi(e) : 3;
+            if (cut < 1 || cut > 3) cut = 3;
+        }
+        const long tiles32 = ((long)p.n * ((p.hp + 3) / 4) * ((p.wp + 7) / 8)) * p.n_phases;
+        if (f != 0 || tiles32 >= 1024) {
+            const int rc = launch_split(p, stream, cut);
+            if (rc != 1) return rc;
+        }
+    }
     const long positions = (long)p.n * p.hp * p.wp;
     if (variant == 0) {          // block-cooperative LDS slabs (one barrier per K-step); phase is the fastest index
         bool big = positions * p.n_phases >= 128L * 512 && p.wp >= 16;
@@ -507,16 +499,16 @@ int launch(ConvGemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int eae_hip_conv5x5s2(const float* x, const float* w_packed, const float* bias, int norm,
-                                 const float* gamma_packed, const float* beta, float* out, int n, int h, int w_in,
-                                 void* stream) {
+namespace {
+int conv5x5s2(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma_packed, const float* beta,
+              float* out, int n, int h, int w_in, unsigned int* workspace, void* stream) {
     if (!x || !w_packed || !out || n <= 0 || h <= 0 || w_in <= 0) return EAE_HIP_BAD_ARGUMENT;
     if (norm != EAE_NORM_NONE && (!gamma_packed || !beta)) return EAE_HIP_BAD_ARGUMENT;
     if ((h & 1) || (w_in & 1)) return EAE_HIP_BAD_SHAPE;
     ConvGemmParams p{};
     p.in = x; p.out = out; p.w = w_packed; p.bias = bias; p.gamma = gamma_packed; p.beta = beta; p.norm = norm;
     p.n = n; p.hin = h; p.win = w_in; p.hp = h / 2; p.wp = w_in / 2; p.hout = h / 2; p.wout = w_in / 2;
-    p.in_stride = 2; p.out_stride = 1; p.n_phases = 1;
+    p.in_stride = 2; p.out_stride = 1; p.n_phases = 1; p.split_ws = workspace;
     PhaseDesc& pd = p.phase[0];
     pd.out_a = 0; pd.out_b = 0; pd.ntaps = 25;
     for (int u = 0; u < 5; ++u)
@@ -525,15 +517,14 @@ extern "C" int eae_hip_conv5x5s2(const float* x, const float* w_packed, const fl
     return launch(p, (hipStream_t)stream);
 }
 
-extern "C" int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const float* bias, int norm,
-                                  const float* gamma_packed, const float* beta, float* out, int n, int h, int w_in,
-                                  void* stream) {
+int tconv5x5s2(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma_packed, const float* beta,
+               float* out, int n, int h, int w_in, unsigned int* workspace, void* stream) {
     if (!x || !w_packed || !out || n <= 0 || h <= 0 || w_in <= 0) return EAE_HIP_BAD_ARGUMENT;
     if (norm != EAE_NORM_NONE && (!gamma_packed || !beta)) return EAE_HIP_BAD_ARGUMENT;
     ConvGemmParams p{};
     p.in = x; p.out = out; p.w = w_packed; p.bias = bias; p.gamma = gamma_packed; p.beta = beta; p.norm = norm;
     p.n = n; p.hin = h; p.win = w_in; p.hp = h; p.wp = w_in; p.hout = 2 * h; p.wout = 2 * w_in;
-    p.in_stride = 1; p.out_stride = 2; p.n_phases = 4;
+    p.in_stride = 1; p.out_stride = 2; p.n_phases = 4; p.split_ws = workspace;
     // Output pixel I = 2p' + a receives tap u from input row p = p' - (u - a - 1)/2 (appendix A.3, pad_before 1):
     //   a = 0: u = 1 (p'), 3 (p'-1);   a = 1: u = 0 (p'+1), 2 (p'), 4 (p'-1).   Taps in ascending (u, v).
     for (int a = 0; a < 2; ++a)
@@ -549,6 +540,32 @@ extern "C" int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const f
             }
         }
     return launch(p, (hipStream_t)stream);
+}
+
+}  // namespace
+
+extern "C" int eae_hip_conv5x5s2(const float* x, const float* w_packed, const float* bias, int norm,
+                                 const float* gamma_packed, const float* beta, float* out, int n, int h, int w_in,
+                                 void* stream) {
+    return conv5x5s2(x, w_packed, bias, norm, gamma_packed, beta, out, n, h, w_in, nullptr, stream);
+}
+extern "C" int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const float* bias, int norm,
+                                  const float* gamma_packed, const float* beta, float* out, int n, int h, int w_in,
+                                  void* stream) {
+    return tconv5x5s2(x, w_packed, bias, norm, gamma_packed, beta, out, n, h, w_in, nullptr, stream);
+}
+extern "C" uint64_t eae_hip_conv_workspace_bytes(void) { return (uint64_t)SPLIT_WORDS * sizeof(unsigned int); }
+extern "C" int eae_hip_conv5x5s2_ws(const float* x, const float* w_packed, const float* bias, int norm,
+                                    const float* gamma_packed, const float* beta, float* out, int n, int h, int w_in,
+                                    void* workspace, void* stream) {
+    if (!workspace) return EAE_HIP_BAD_ARGUMENT;
+    return conv5x5s2(x, w_packed, bias, norm, gamma_packed, beta, out, n, h, w_in, static_cast<unsigned int*>(workspace), stream);
+}
+extern "C" int eae_hip_tconv5x5s2_ws(const float* x, const float* w_packed, const float* bias, int norm,
+                                     const float* gamma_packed, const float* beta, float* out, int n, int h, int w_in,
+                                     void* workspace, void* stream) {
+    if (!workspace) return EAE_HIP_BAD_ARGUMENT;
+    return tconv5x5s2(x, w_packed, bias, norm, gamma_packed, beta, out, n, h, w_in, static_cast<unsigned int*>(workspace), stream);
 }
 
 namespace {

@@ -1,0 +1,307 @@
+// conv_gemm_split.hip -- the four dense 128->128 convolutions (conv_2, conv_3, transpose_conv_1, _2; components.py:126-136,
+// 63-75) with bias and (I)GDN epilogue: one work item per wave, where an item is a whole tile (32 positions x 128 channels x
+// all of K) or, for the last tiles of the launch, the head or the tail of a tile cut at a K-step boundary.
+//
+// Why. A batch of Kodak images is 4.5 whole tiles per SIMD for conv_2 and 1.1 for conv_3: the last round of tiles runs on
+// a half-empty machine (9 % of the step at batch 24). A tile cannot be cut across positions or
+// channels any finer without paying for it (a wave's 4 accumulators are what keeps the 64-cycle MFMA back to back), and it
+// cannot be cut along K and summed afterwards either: every output element must stay ONE f32 FMA chain in the documented
+// order. What CAN be done without touching a single bit: interrupt the chain at a K-step boundary,
+// write the 64 accumulator registers out, and let another wave reload them and continue. The chain, hence the result, is
+// the same.
+//
+// How. Per XCD (blocks b and b + 8 share one) the tiles are laid out as a sequence of items, one per wave of the grid:
+//     [ heads of the D last tiles ]  [ the other tiles, whole ]  [ the tails of the D tiles, longest first ]
+// D = min(tiles, waves the XCD holds at once), or 0 when the launch is not cut (then this is simply the one-tile-per-wave
+// kernel). Head d covers K-steps [0, h_d) of its tile with h_d spread evenly over the tile's length, parks its accumulators
+// in the tile's own output pixels (that region has exactly the size of the accumulator tile) and sets a flag; the matching
+// tail reloads them, runs [h_d, T) and finishes with the normal epilogue. Workgroups are dispatched in order, so the heads
+// start first and the tails last: a tail only ever waits for a wave that was dispatched before it (no residency assumption,
+// no deadlock), and by the time the tails come up the heads have long been published. The launch ends with many short
+// items that the dispatcher hands to whichever SIMD frees a slot, so all SIMDs run dry within a few K-steps of each other.
+// (A persistent form, waves pulling the same items from an atomic counter, was measured 3-4 % slower: a queue balances over
+// workers, the dispatcher over SIMDs, which is what matters once fewer items than workers are left.)
+//
+// Hand-off: the head stores its accumulators WRITE-THROUGH (sc1), waits for the stores (vmcnt(0)) and sets its flag with an
+// sc1 store; the tail polls the flag with sc1 loads and reloads the accumulators with sc1 loads (L1 bypassed). Nothing else
+// touches those bytes during the launch (the output is write-only), so no L2 holds a stale copy, and there is no release
+// fence: an agent-scope release writes back EVERY dirty line of the XCD's L2, which in these store-heavy kernels cost more
+// than the tile quantisation it was meant to remove (transpose_conv_2: 1.105 ms with fences against 1.041 uncut).
+//
+// Workspace (cut launches only): SPLIT_WORDS uint32, zero on entry, zero again on exit (a flag is reset by its consumer),
+// so a caller zeroes it once. Launches that may run concurrently need their own workspace.
+#include "conv_gemm.h"
+
+#include <cstdlib>
+
+using namespace eae_conv_gemm;
+
+namespace {
+
+constexpr int RING = 8;
+constexpr int ABUF = 32 * AS_STRIDE;                 // one activation buffer of one wave
+constexpr int WAVE_LDS = 2 * ABUF + 2 * EAE_C;       // + bias[128] + beta[128]
+constexpr int QT_H = 4, QT_W = 8;                    // a wave's tile: 4 x 8 positions
+constexpr int MIN_PIECE = 4;                         // K-steps: no head or tail shorter than this
+constexpr int SPIN_LIMIT = 1 << 22;                  // ~1 s of polling: a bug, not a wait; sets the error word
+
+// K-steps of head d of D on a tile of T steps: [MIN_PIECE, T - MIN_PIECE); T itself (no split) for very short tiles
+__device__ __forceinline__ int head_steps(int d, int D, int T) {
+    return T < 3 * MIN_PIECE ? T : MIN_PIECE + (d * (T - 2 * MIN_PIECE)) / D;
+}
+
+template <int NORM>
+__global__ __launch_bounds__(256, 3) void conv_gemm_split_kernel(const ConvGemmParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * WAVE_LDS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* wlds = lds + wave * WAVE_LDS;
+    float* vec_lds = wlds + 2 * ABUF;
+    {
+        const float2 bz = p.bias ? *reinterpret_cast<const float2*>(p.bias + 2 * lane) : make_float2(0.f, 0.f);
+        *reinterpret_cast<float2*>(vec_lds + 2 * lane) = bz;
+        if (NORM != EAE_NORM_NONE) *reinterpret_cast<float2*>(vec_lds + EAE_C + 2 * lane) = *reinterpret_cast<const float2*>(p.beta + 2 * lane);
+    }
+    const int hi = lane >> 5, lj = lane & 31, a_q = lane & 7;
+    const int cbase = 4 * hi;
+
+    // this XCD's share of the spatial tiles, and this wave's item
+    const int x = (int)blockIdx.x & 7;
+    const int wx = p.split_resident_waves_per_xcd;            // waves the XCD holds at once: how many tiles are cut
+    const int nsp = p.n * p.tiles_r * p.tiles_c;
+    const int q8 = nsp >> 3, r8 = nsp & 7;
+    const int cnt_sp = q8 + (x < r8 ? 1 : 0);
+    const int first_sp = x * q8 + (x < r8 ? x : r8);
+    const int ntt = cnt_sp * p.n_phases;                      // tiles of this share, phase-major (longest phase first)
+    const int D = p.split ? (ntt < wx ? ntt : wx) : 0;         // tiles cut in two (0: whole tiles only)
+    const int F = ntt - D;
+    const int n_items = 2 * D + F;
+    unsigned int* flags = p.split_ws + 256 + x * 1024;       // D > 0 only
+
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.w), 0, (int)((size_t)MAX_TAPS * EAE_C * EAE_C * sizeof(float)), 0x00020000);
+    const int w_lane = (hi * EAE_C + lj * 4) * 4;             // byte offset inside a k-pair of weight rows
+    const int a_off = lj * AS_STRIDE + hi * 16;
+
+    {
+        const int item = ((int)blockIdx.x >> 3) * 4 + wave;
+        if (item >= n_items) return;
+        int d = -1, tau;
+        bool is_tail = false;
+        if (item < D) { d = item; tau = ntt - D + d; }
+        else if (item < D + F) { tau = item - D; }
+        else { d = item - D - F; tau = ntt - D + d; is_tail = true; }
+        int ph = 0, sp = tau;
+        while (sp >= cnt_sp) { sp -= cnt_sp; ++ph; }
+        const PhaseDesc& pd = p.phase[ph];
+        const int ntaps = pd.ntaps;
+        const int T = (EAE_C / KC) * ntaps;
+        int s0 = 0, s1 = T;
+        if (d >= 0) {
+            const int h = head_steps(d, D, T);
+            if (is_tail) { if (h >= T) return; s0 = h; }
+            else s1 = h;
+        }
+        int b = first_sp + sp;
+        const int tc = b % p.tiles_c; b /= p.tiles_c;
+        const int tr = b % p.tiles_r;
+        const int img = b / p.tiles_r;
+
+        // activation loader: lane -> (position (lane >> 3) + 8 i of this tile, channel quad lane & 7)
+        int a_pr[4], a_pc[4], a_ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = (lane >> 3) + 8 * i;
+            a_pr[i] = tr * QT_H + m / QT_W;
+            a_pc[i] = tc * QT_W + m % QT_W;
+            a_ok[i] = (a_pr[i] < p.hp) & (a_pc[i] < p.wp);
+        }
+        const float* in_img = p.in + (size_t)img * p.hin * p.win * EAE_C;
+        const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(in_img), 0, (int)((size_t)p.hin * p.win * EAE_C * sizeof(float)), 0x00020000);
+        // this lane's output pixel (position lj of the tile): also where the accumulators of an interrupted tile wait
+        const int pr = tr * QT_H + lj / QT_W, pc = tc * QT_W + lj % QT_W;
+        const bool valid = pr < p.hp && pc < p.wp;
+        float* out_img = p.out + (size_t)img * p.hout * p.wout * EAE_C;
+        const int o_off = ((pr * p.out_stride + pd.out_a) * p.wout + (pc * p.out_stride + pd.out_b)) * EAE_C;   // floats, inside the image
+        float* o = out_img + o_off;
+        const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            out_img, 0, (int)((size_t)p.hout * p.wout * EAE_C * sizeof(float)), 0x00020000);
+        const int park = valid ? (o_off + cbase) * 4 : -1;      // byte offset of this lane's parked accumulators (-1: beyond the buffer)
+
+        float4 a_reg[4];
+#define EAE_Q_PREFETCH_A(packed_, ci0_)                                                                              \
+        {                                                                                                            \
+            const int dr_ = ((packed_) & 0xFF) - 8, dc_ = (((packed_) >> 8) & 0xFF) - 8;                             \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+                const int r_ = a_pr[i] * p.in_stride + dr_;                                                          \
+                const int c_ = a_pc[i] * p.in_stride + dc_;                                                          \
+                const int ok_ = a_ok[i] & ((unsigned)r_ < (unsigned)p.hin) & ((unsigned)c_ < (unsigned)p.win);       \
+                const int lin_ = ((r_ * p.win + c_) * EAE_C + (ci0_) + 4 * a_q) * 4;                                 \
+                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok_ ? lin_ : -1, 0, 0);              \
+                a_reg[i] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z),          \
+                                       __uint_as_float(v_.w));                                                       \
+            }                                                                                                        \
+        }
+#define EAE_Q_STAGE_A(buf_)                                                                                          \
+        {                                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+                float* dst_ = wlds + (buf_) * ABUF + ((lane >> 3) + 8 * i) * AS_STRIDE + 2 * a_q;                    \
+                *reinterpret_cast<float2*>(dst_) = make_float2(a_reg[i].x, a_reg[i].z);                              \
+                *reinterpret_cast<float2*>(dst_ + 16) = make_float2(a_reg[i].y, a_reg[i].w);                         \
+            }                                                                                                        \
+        }
+        // byte offset of the weight slab of (tap index, 32-channel chunk); K order: chunk (outer), then tap
+#define EAE_Q_SLAB(ti_, ch_) ((((pd.tap[ti_] >> 16) * EAE_C + (ch_) * KC) * EAE_C) * 4)
+#define EAE_Q_W_LOAD(dst_, slab_, kk_)                                                                               \
+        {                                                                                                            \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane + (kk_) * 2 * EAE_C * 4, (slab_), 0); \
+            dst_ = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z),                  \
+                               __uint_as_float(v_.w));                                                               \
+        }
+
+        f32x16 acc[4];
+        if (s0 == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        } else {
+            // the tail of an interrupted tile: wait for its head (published long ago, normally), then continue the chain
+            if (lane == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(flags + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > SPIN_LIMIT) { p.split_ws[255] = 1u; break; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    // sc1 (aux 16): served from L2 / memory, never from this CU's L1; lanes outside the image read 0
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(out_rsrc, park, (32 * t + 8 * g) * 4, 16);
+                    acc[t][4 * g + 0] = __uint_as_float(v.x); acc[t][4 * g + 1] = __uint_as_float(v.y);
+                    acc[t][4 * g + 2] = __uint_as_float(v.z); acc[t][4 * g + 3] = __uint_as_float(v.w);
+                }
+            if (lane == 0) __hip_atomic_store(flags + d, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
+        }
+
+        int tap_i = s0 % ntaps, chunk = s0 / ntaps;
+        float4 ring[RING];
+        {
+            const int slab0 = EAE_Q_SLAB(tap_i, chunk);
+#pragma unroll
+            for (int i = 0; i < RING; ++i) EAE_Q_W_LOAD(ring[i], slab0, i)
+        }
+        EAE_Q_PREFETCH_A(pd.tap[tap_i], chunk * KC)
+        EAE_Q_STAGE_A(0)
+        for (int step = s0; step < s1; ++step) {
+            int nti = tap_i + 1, nch = chunk;
+            if (nti == ntaps) { nti = 0; ++nch; }
+            if (step + 1 >= s1) { nti = tap_i; nch = chunk; }      // the last step re-loads itself: loads stay unconditional
+            const int slab_cur = EAE_Q_SLAB(tap_i, chunk);
+            const int slab_nxt = EAE_Q_SLAB(nti, nch);
+            EAE_Q_PREFETCH_A(pd.tap[nti], nch * KC)
+            const float4* a_rd = reinterpret_cast<const float4*>(wlds + ((step - s0) & 1) * ABUF + a_off);
+            const float4 a0 = a_rd[0], a1 = a_rd[1], a2 = a_rd[2], a3 = a_rd[3];
+            const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                const float4 wq = ring[kk % RING];
+                acc[0] = mfma32(wq.x, av[kk], acc[0]);      // A = W^T[co = 32 t + lj][k], B = X^T[k][pos = lj]
+                acc[1] = mfma32(wq.y, av[kk], acc[1]);
+                acc[2] = mfma32(wq.z, av[kk], acc[2]);
+                acc[3] = mfma32(wq.w, av[kk], acc[3]);
+                if (kk + RING < KC / 2) { EAE_Q_W_LOAD(ring[kk % RING], slab_cur, kk + RING) }
+                else { EAE_Q_W_LOAD(ring[kk % RING], slab_nxt, kk + RING - KC / 2) }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            EAE_Q_STAGE_A(((step - s0) + 1) & 1)
+            tap_i = nti;
+            chunk = nch;
+        }
+
+        if (s1 == T) {
+            wave_epilogue<NORM>(acc, vec_lds, p.bias != nullptr, p.gamma, o, valid, lane);
+        } else {
+            // a head: park the accumulators in the tile's own output pixels, write-through, and publish them
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const u32x4 v = {__float_as_uint(acc[t][4 * g]), __float_as_uint(acc[t][4 * g + 1]),
+                                     __float_as_uint(acc[t][4 * g + 2]), __float_as_uint(acc[t][4 * g + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, park, (32 * t + 8 * g) * 4, 16);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store of this wave has reached memory
+            if (lane == 0) __hip_atomic_store(flags + d, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#undef EAE_Q_PREFETCH_A
+#undef EAE_Q_STAGE_A
+#undef EAE_Q_SLAB
+#undef EAE_Q_W_LOAD
+    }
+}
+
+int compute_units() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (cached[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cached[dev] = prop.multiProcessorCount;
+    }
+    return cached[dev];
+}
+
+}  // namespace
+
+int eae_conv_gemm::launch_split(ConvGemmParams& p, hipStream_t stream, int cut) {
+    const int cus = compute_units();
+    if (cus < 8 || (cus & 7)) return 1;
+    p.tiles_r = (p.hp + QT_H - 1) / QT_H;
+    p.tiles_c = (p.wp + QT_W - 1) / QT_W;
+    const long nsp = (long)p.n * p.tiles_r * p.tiles_c;
+    const long tiles = nsp * p.n_phases;
+    const long simds = 4L * cus;
+    // cut: -1 = decide here, 0 = whole tiles, 1..3 = cut, sized for that many resident waves per SIMD (tests)
+    long k = tiles / simds;                     // whole tiles per SIMD
+    if (k > 3) k = 3;
+    if (k < 1) k = 1;
+    bool split = cut > 0;
+    if (cut > 0) k = cut > 3 ? 3 : cut;
+    if (cut < 0 && p.split_ws && p.n_phases == 1 && tiles >= simds) {
+        // Uncut, the launch takes as long as its busiest SIMD: ceil(tiles / SIMDs) tiles; cut, tiles / SIMDs plus ~2 % for
+        // the hand-offs. Only the convolutions: the tiles of the transposed ones are short (16-36 K-steps against 100), their
+        // last round costs little and cutting them was measured to lose (Kodak batch 24, bursts: transpose_conv_1 0.286 ms
+        // uncut, 0.295-0.310 cut; _2 1.009 / 1.014-1.031; conv_2 0.995 / 0.917; conv_3 0.382 / 0.249).
+        const long rounds = (tiles + simds - 1) / simds;
+        split = (double)rounds * simds > 1.03 * (double)tiles;
+    }
+    if (split && !p.split_ws) return EAE_HIP_BAD_ARGUMENT;
+    if ((cus / 8) * 4 * k > 1024) return 1;          // flag table: 1024 cut tiles per XCD
+    // longest phase first (insertion sort of <= 4 descriptors): every CU works through the same mix of phases, and the last
+    // tiles of the launch -- the ones that get cut -- are the short ones
+    for (int i = 1; i < p.n_phases; ++i)
+        for (int j = i; j > 0 && p.phase[j].ntaps > p.phase[j - 1].ntaps; --j) {
+            const PhaseDesc tmp = p.phase[j]; p.phase[j] = p.phase[j - 1]; p.phase[j - 1] = tmp;
+        }
+    p.split = split ? 1 : 0;
+    p.split_resident_waves_per_xcd = (cus / 8) * 4 * (int)k;
+    // one wave per item, blocks of 4 items, the 8 shares interleaved: the largest share decides the grid
+    const long cnt_max = (nsp + 7) / 8 * p.n_phases;
+    const long d_max = split ? (cnt_max < p.split_resident_waves_per_xcd ? cnt_max : p.split_resident_waves_per_xcd) : 0;
+    const int grid = (int)((cnt_max + d_max + 3) / 4) * 8;
+    if (p.norm == EAE_NORM_GDN) hipLaunchKernelGGL((conv_gemm_split_kernel<EAE_NORM_GDN>), dim3(grid), dim3(256), 0, stream, p);
+    else if (p.norm == EAE_NORM_IGDN) hipLaunchKernelGGL((conv_gemm_split_kernel<EAE_NORM_IGDN>), dim3(grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv_gemm_split_kernel<EAE_NORM_NONE>), dim3(grid), dim3(256), 0, stream, p);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}

@@ -281,7 +281,7 @@ extern "C" int eae_hip_latent_stage(const float* x, const float* gamma_in_packed
     if ((gamma_out_packed == nullptr) != (beta_out == nullptr) || (gamma_out_packed && !t_out)) return EAE_HIP_BAD_ARGUMENT;
     const long rows = (long)n * hw;
     hipStream_t s = (hipStream_t)stream;
-    static const bool lds_form = std::getenv("EAE_HIP_LATENT_LDS") != nullptr;      // the block-cooperative form, for comparison
+    const bool lds_form = std::getenv("EAE_HIP_LATENT_LDS") != nullptr;   // the block-cooperative form (read per launch: the parity tests run both)
     if (!lds_form) {
         const unsigned wgrid = (unsigned)((rows + 31) / 32);
 #define EAE_LATENT_W(A_, B_)                                                                                              \

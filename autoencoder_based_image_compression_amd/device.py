@@ -69,12 +69,26 @@ def conv9x9s4_u8(x_u8, w_packed, bias, gamma_packed=None, beta=None, out=None):
     return out
 
 
-def conv5x5s2(x, w_packed, bias, norm=NORM_NONE, gamma_packed=None, beta=None, out=None):
+def conv_workspace(device):
+    """Zeroed scratch that lets conv5x5s2 / tconv5x5s2 cut the last tiles of a launch (include/eae_hip.h): every launch leaves
+    it zeroed, so one allocation serves any number of launches that cannot overlap each other (one per stream / batch slot)."""
+    return torch.zeros(int(_native.hip().eae_hip_conv_workspace_bytes())//4, dtype=torch.int32, device=device)
+
+
+def conv5x5s2(x, w_packed, bias, norm=NORM_NONE, gamma_packed=None, beta=None, out=None, workspace=None):
+    """conv_2 / conv_3 + bias_add (+ gdn). workspace: `conv_workspace` (the launch may cut its last tiles: same bits, no
+    partly empty last round); None -> a fresh one per call; False -> the entry point without a workspace."""
     (n, h, wd, c) = x.shape
     if out is None:
         out = torch.empty((n, h//2, wd//2, NB_MAPS), dtype=torch.float32, device=x.device)
-    _check(_native.hip().eae_hip_conv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream(x)),
-           'eae_hip_conv5x5s2')
+    if workspace is False:
+        _check(_native.hip().eae_hip_conv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream(x)),
+               'eae_hip_conv5x5s2')
+        return out
+    if workspace is None:
+        workspace = conv_workspace(x.device)
+    _check(_native.hip().eae_hip_conv5x5s2_ws(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd,
+                                                  _p(workspace), _stream(x)), 'eae_hip_conv5x5s2_ws')
     return out
 
 
@@ -86,12 +100,19 @@ def gdn(x, gamma_packed, beta, inverse=False, out=None):
     return out
 
 
-def tconv5x5s2(x, w_packed, bias, norm=NORM_NONE, gamma_packed=None, beta=None, out=None):
+def tconv5x5s2(x, w_packed, bias, norm=NORM_NONE, gamma_packed=None, beta=None, out=None, workspace=None):
+    """transpose_conv_1 / _2 + bias_add (+ inverse gdn); `workspace` as in conv5x5s2."""
     (n, h, wd, c) = x.shape
     if out is None:
         out = torch.empty((n, 2*h, 2*wd, NB_MAPS), dtype=torch.float32, device=x.device)
-    _check(_native.hip().eae_hip_tconv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream(x)),
-           'eae_hip_tconv5x5s2')
+    if workspace is False:
+        _check(_native.hip().eae_hip_tconv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream(x)),
+               'eae_hip_tconv5x5s2')
+        return out
+    if workspace is None:
+        workspace = conv_workspace(x.device)
+    _check(_native.hip().eae_hip_tconv5x5s2_ws(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd,
+                                                   _p(workspace), _stream(x)), 'eae_hip_tconv5x5s2_ws')
     return out
 
 

@@ -75,6 +75,20 @@ int eae_hip_gdn(const float* x, const float* gamma_packed, const float* beta, in
 int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma_packed,
                        const float* beta, float* out, int n, int h, int w_in, void* stream);
 
+/* The same two ops with a workspace that lets the launch cut its last tiles (csrc/hip/conv_gemm_split.hip): identical
+ * results, no partly empty last round. A batch gives every SIMD a non-integer number of 32-position tiles (4.5 for conv_2
+ * and 1.1 for conv_3 on 24 Kodak images); with the workspace the last tiles of the launch are interrupted at a K-step
+ * boundary -- the accumulators parked in the tile's own output pixels -- and finished by a wave dispatched at the very end,
+ * so that every SIMD runs dry at the same time. The per-element f32 FMA chain, hence every bit of the result, is the one
+ * documented above. workspace: eae_hip_conv_workspace_bytes() bytes of device memory, ALL ZERO on entry and all zero again
+ * when the launch has completed (zero it once); launches that may run concurrently need their own. Whether a launch is cut
+ * is decided from its shape (only the convolutions, only when the last round would be less than ~97 % full). */
+uint64_t eae_hip_conv_workspace_bytes(void);
+int eae_hip_conv5x5s2_ws(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma_packed,
+                         const float* beta, float* out, int n, int h, int w_in, void* workspace, void* stream);
+int eae_hip_tconv5x5s2_ws(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma_packed,
+                          const float* beta, float* out, int n, int h, int w_in, void* workspace, void* stream);
+
 /* transpose_conv_3 (components.py:79-83; 9x9, 128->1, stride 4, 'SAME', no bias) fused with what follows it on the
  * path: tls.cast_bt601 (tools.py:93: uint8(round_half_even(clip(x,16,235)))) and the squared error of tls.psnr_2d
  * (tools.py:873-875). x: [N][h][w][128]; w_phase: 18432 floats from eae_hip_pack_tconv9x9s4_weights;

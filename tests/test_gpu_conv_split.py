@@ -1,0 +1,144 @@
+"""conv_gemm_split_kernel (csrc/hip/conv_gemm_split.hip): tiles interrupted at a K-step boundary and finished by another
+wave must give the bits of the uninterrupted chain. Small shapes with the cut forced are in tests/test_gpu_kernels.py
+(every tile cut, tails waiting on their heads); here: shapes large enough for the launch to decide by itself, against the
+CPU oracle and against the other kernels, the workspace contract (zero again after every launch, no timeout word), reuse
+of one workspace, and concurrent launches on two streams."""
+import numpy
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ENV = ('EAE_HIP_GEMM', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_FORCE_TILE', 'EAE_HIP_FORCE_NT')
+
+
+def _vars(seed):
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables
+    return variables.random_variables(1., False, seed=seed, bias_std=0.01)
+
+
+def _workspace_is_clean(ws):
+    return int(torch.count_nonzero(ws).item()) == 0
+
+
+def _forms(monkeypatch, call, ws, reference):
+    """The same launch in every other form: bits equal `reference`, workspace left zeroed."""
+    for (form, waves) in (('u', None), ('w', None), ('s', '1'), ('s', '2'), ('s', '3')):
+        monkeypatch.setenv('EAE_HIP_GEMM', form)
+        if waves:
+            monkeypatch.setenv('EAE_HIP_SPLIT_WAVES', waves)
+        assert torch.equal(call(ws), reference), (form, waves)
+        assert _workspace_is_clean(ws)
+    for name in ENV:
+        monkeypatch.delenv(name, raising=False)
+
+
+@pytest.mark.parametrize('norm', [0, 1])
+def test_conv_against_the_oracle(norm, monkeypatch):
+    """6 x 128x192 inputs = 1152 tiles of 32 positions on 1024 SIMDs: the launch cuts its last tiles by itself."""
+    from autoencoder_based_image_compression_amd import device as dev
+    from oracle import transforms as orc
+    for name in ENV:
+        monkeypatch.delenv(name, raising=False)
+    v = _vars(31)
+    x = numpy.random.RandomState(32).standard_normal(size=(6, 128, 192, 128)).astype(numpy.float32)
+    ref = orc.conv2d_same(x, v['encoder/weights_2'], 2, v['encoder/biases_2'])
+    if norm:
+        ref = orc.gdn(ref, v['encoder/gamma_2'], v['encoder/beta_2'])
+    ws = dev.conv_workspace('cuda')
+    args = (torch.from_numpy(x).cuda(), dev.pack_conv_weights(torch.from_numpy(v['encoder/weights_2']).cuda()),
+            torch.from_numpy(v['encoder/biases_2']).cuda(), norm, dev.pack_gamma(torch.from_numpy(v['encoder/gamma_2']).cuda()),
+            torch.from_numpy(v['encoder/beta_2']).cuda())
+    got = dev.conv5x5s2(*args, workspace=ws)
+    assert numpy.array_equal(got.cpu().numpy(), ref)
+    assert _workspace_is_clean(ws)
+    assert torch.equal(dev.conv5x5s2(*args, workspace=False), got)          # no workspace: whole tiles
+    _forms(monkeypatch, lambda w: dev.conv5x5s2(*args, workspace=w), ws, got)
+
+
+@pytest.mark.parametrize('norm', [0, 2])
+def test_tconv_against_the_oracle(norm, monkeypatch):
+    """3 x 48x72 sites x 4 output phases = 1296 tiles of four lengths (36 / 24 / 24 / 16 K-steps)."""
+    from autoencoder_based_image_compression_amd import device as dev
+    from oracle import transforms as orc
+    for name in ENV:
+        monkeypatch.delenv(name, raising=False)
+    v = _vars(33)
+    x = numpy.random.RandomState(34).standard_normal(size=(3, 48, 72, 128)).astype(numpy.float32)
+    ref = orc.conv2d_transpose_same(x, v['decoder/weights_4'], 2, v['decoder/biases_4'])
+    if norm:
+        ref = orc.gdn(ref, v['decoder/gamma_5'], v['decoder/beta_5'], inverse=True)
+    ws = dev.conv_workspace('cuda')
+    args = (torch.from_numpy(x).cuda(), dev.pack_tconv_weights(torch.from_numpy(v['decoder/weights_4']).cuda()),
+            torch.from_numpy(v['decoder/biases_4']).cuda(), norm, dev.pack_gamma(torch.from_numpy(v['decoder/gamma_5']).cuda()),
+            torch.from_numpy(v['decoder/beta_5']).cuda())
+    got = dev.tconv5x5s2(*args, workspace=ws)
+    assert numpy.array_equal(got.cpu().numpy(), ref)
+    assert _workspace_is_clean(ws)
+    assert torch.equal(dev.tconv5x5s2(*args, workspace=False), got)
+    _forms(monkeypatch, lambda w: dev.tconv5x5s2(*args, workspace=w), ws, got)
+
+
+def test_kodak_batch_layers_in_every_form(monkeypatch):
+    """The four launches of the benchmark's step (24 x 512x768), GPU against GPU: ragged shares (4608 tiles / 8 XCDs), one
+    workspace reused by all four launches, then the same again on two streams at once with a workspace each."""
+    import bench
+    from autoencoder_based_image_compression_amd import device as dev, pipeline
+    for name in ENV:
+        monkeypatch.delenv(name, raising=False)
+    variables = bench.synthetic_model(1.)
+    enc = pipeline.DeviceEncoder(variables, False)
+    dec = pipeline.DeviceDecoder(variables, False)
+    (v, d) = (enc.v, dec.v)
+    images = torch.from_numpy(bench.synthetic_images(5, 24, 512, 768)).cuda()
+    gdn_1 = dev.conv9x9s4_u8(images, enc.w1, v['encoder/biases_1'], enc.g[1], v['encoder/beta_1'])
+
+    def chain(workspace):
+        gdn_2 = dev.conv5x5s2(gdn_1, enc.w2, v['encoder/biases_2'], dev.NORM_GDN, enc.g[2], v['encoder/beta_2'], workspace=workspace)
+        conv_3 = dev.conv5x5s2(gdn_2, enc.w3, v['encoder/biases_3'], dev.NORM_NONE, workspace=workspace)
+        t1 = dev.tconv5x5s2(conv_3, dec.w4, d['decoder/biases_4'], dev.NORM_IGDN, dec.g[5], d['decoder/beta_5'], workspace=workspace)
+        t2 = dev.tconv5x5s2(t1, dec.w5, d['decoder/biases_5'], dev.NORM_IGDN, dec.g[6], d['decoder/beta_6'], workspace=workspace)
+        return (gdn_2, conv_3, t1, t2)
+
+    monkeypatch.setenv('EAE_HIP_GEMM', 'w')
+    plain = chain(False)                         # conv_gemm_wave_kernel, pinned to the oracle at this size by test_gpu_full_size
+    monkeypatch.delenv('EAE_HIP_GEMM')
+    ws = dev.conv_workspace('cuda')
+    for _ in range(3):
+        for (a, b) in zip(plain, chain(ws)):
+            assert torch.equal(a, b)
+        assert _workspace_is_clean(ws)
+    monkeypatch.setenv('EAE_HIP_GEMM', 's')      # every layer cut, the transposed convolutions too
+    for (a, b) in zip(plain, chain(ws)):
+        assert torch.equal(a, b)
+    assert _workspace_is_clean(ws)
+    monkeypatch.delenv('EAE_HIP_GEMM')
+    # two chains at once: their waves compete for the SIMDs, every tile is still one uninterrupted-equivalent chain
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    spaces = [dev.conv_workspace('cuda') for _ in streams]
+    torch.cuda.synchronize()
+    results = []
+    for (stream, space) in zip(streams, spaces):
+        with torch.cuda.stream(stream):
+            results.append(chain(space))
+    torch.cuda.synchronize()
+    for queued in results:
+        for (a, b) in zip(plain, queued):
+            assert torch.equal(a, b)
+    assert all(_workspace_is_clean(space) for space in spaces)
+
+
+def test_workspace_entry_points_check_their_arguments(monkeypatch):
+    from autoencoder_based_image_compression_amd import _native
+    lib = _native.hip()
+    assert int(lib.eae_hip_conv_workspace_bytes()) >= 4*(256 + 8*128)
+    x = torch.zeros((1, 4, 4, 128), device='cuda')
+    out = torch.zeros((1, 2, 2, 128), device='cuda')
+    w = torch.zeros((25, 128, 128), device='cuda')
+    assert lib.eae_hip_conv5x5s2_ws(x.data_ptr(), w.data_ptr(), None, 0, None, None, out.data_ptr(), 1, 4, 4, None, None) == -1
+    assert lib.eae_hip_tconv5x5s2_ws(x.data_ptr(), w.data_ptr(), None, 0, None, None, out.data_ptr(), 1, 4, 4, None, None) == -1
+    ws = torch.zeros(int(lib.eae_hip_conv_workspace_bytes())//4, dtype=torch.int32, device='cuda')
+    assert lib.eae_hip_conv5x5s2_ws(x.data_ptr(), w.data_ptr(), None, 1, None, None, out.data_ptr(), 1, 4, 4, ws.data_ptr(), None) == -1
+    assert lib.eae_hip_conv5x5s2_ws(x.data_ptr(), w.data_ptr(), None, 0, None, None, out.data_ptr(), 1, 3, 4, ws.data_ptr(), None) == -2
+    monkeypatch.setenv('EAE_HIP_GEMM', 's')      # a forced cut needs the workspace
+    assert lib.eae_hip_conv5x5s2(x.data_ptr(), w.data_ptr(), None, 0, None, None, out.data_ptr(), 1, 4, 4, None) == -1

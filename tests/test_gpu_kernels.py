@@ -58,11 +58,36 @@ def test_conv1_gdn1(T, dev, orc, shape, with_gdn):
     assert numpy.array_equal(got, ref)
 
 
-@pytest.mark.parametrize('tile', ['32', '64', '128'])
+def _select_form(monkeypatch, form, tile):
+    """Every form of the conv GEMM must give the same bits (EAE_HIP_GEMM, csrc/hip/conv_gemm.hip: launch):
+    'wave' = conv_gemm_wave_kernel, one tile per wave (32 / 64 / 128-position blocks); 'nt1' / 'nt2' = the same with a
+    wave's output channels spread over 4 / 2 blocks (small layers); 'lds' = the block-cooperative LDS form (64- or
+    128-position blocks); 'whole' = conv_gemm_split_kernel with whole tiles; 'cut1..3' = conv_gemm_split_kernel with the cut
+    forced onto these small shapes (every tile is then cut in two and the tails wait for their heads)."""
+    for name in ('EAE_HIP_GEMM', 'EAE_HIP_FORCE_NT', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_FORCE_TILE'):
+        monkeypatch.delenv(name, raising=False)
+    if form.startswith('cut'):
+        monkeypatch.setenv('EAE_HIP_GEMM', 's')
+        monkeypatch.setenv('EAE_HIP_SPLIT_WAVES', form[3:])
+        return
+    if form == 'whole':
+        monkeypatch.setenv('EAE_HIP_GEMM', 'u')
+        return
+    monkeypatch.setenv('EAE_HIP_GEMM', 'l' if form == 'lds' else 'w')
+    monkeypatch.setenv('EAE_HIP_FORCE_TILE', tile)
+    if form.startswith('nt'):
+        monkeypatch.setenv('EAE_HIP_FORCE_NT', form[2:])
+
+
+FORMS = [('wave', '32'), ('wave', '64'), ('wave', '128'), ('lds', '64'), ('lds', '128'), ('nt1', '32'), ('nt2', '32'),
+         ('whole', ''), ('cut1', ''), ('cut2', ''), ('cut3', '')]
+
+
+@pytest.mark.parametrize('form,tile', FORMS)
 @pytest.mark.parametrize('shape', [(2, 16, 24), (1, 32, 64), (1, 6, 10), (2, 2, 2), (1, 20, 36)])
 @pytest.mark.parametrize('norm', [0, 1])
-def test_conv5x5s2(T, dev, orc, shape, norm, tile, monkeypatch):
-    monkeypatch.setenv('EAE_HIP_FORCE_TILE', tile)
+def test_conv5x5s2(T, dev, orc, shape, norm, form, tile, monkeypatch):
+    _select_form(monkeypatch, form, tile)
     v = _vars(3)
     rng = numpy.random.RandomState(4)
     x = rng.standard_normal(size=shape + (128,)).astype(numpy.float32)
@@ -79,11 +104,11 @@ def test_conv5x5s2(T, dev, orc, shape, norm, tile, monkeypatch):
     assert numpy.array_equal(got, ref)
 
 
-@pytest.mark.parametrize('tile', ['32', '64', '128'])
+@pytest.mark.parametrize('form,tile', FORMS)
 @pytest.mark.parametrize('shape', [(2, 8, 12), (1, 16, 32), (1, 3, 5), (2, 1, 1), (1, 10, 18)])
 @pytest.mark.parametrize('norm', [0, 2])
-def test_tconv5x5s2(T, dev, orc, shape, norm, tile, monkeypatch):
-    monkeypatch.setenv('EAE_HIP_FORCE_TILE', tile)
+def test_tconv5x5s2(T, dev, orc, shape, norm, form, tile, monkeypatch):
+    _select_form(monkeypatch, form, tile)
     v = _vars(5)
     rng = numpy.random.RandomState(6)
     x = rng.standard_normal(size=shape + (128,)).astype(numpy.float32)

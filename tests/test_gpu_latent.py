@@ -9,8 +9,14 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize('shape', [(2, 32, 48), (3, 5, 7), (1, 1, 1), (5, 16, 16)])
 @pytest.mark.parametrize('learned', [False, True])
-def test_latent_stage_equals_the_separate_kernels(shape, learned):
+@pytest.mark.parametrize('form', ['wave', 'lds'])
+def test_latent_stage_equals_the_separate_kernels(shape, learned, form, monkeypatch):
+    """form: the register-resident wave kernel (default) and the block-cooperative LDS kernel (EAE_HIP_LATENT_LDS)."""
     from autoencoder_based_image_compression_amd import device as dev
+    if form == 'lds':
+        monkeypatch.setenv('EAE_HIP_LATENT_LDS', '1')
+    else:
+        monkeypatch.delenv('EAE_HIP_LATENT_LDS', raising=False)
     rng = numpy.random.RandomState(shape[1]*7 + int(learned))
     (n, h, w) = shape
     x = torch.from_numpy((rng.laplace(size=(n, h, w, 128))*rng.uniform(0.1, 6., size=128)).astype(numpy.float32)).cuda()

@@ -72,29 +72,58 @@ def gdn(x, gamma, beta, inverse=False):
     return out
 
 
+# The forward path as data: (kind, filter or gamma, stride or beta, bias) in graph order. `encoder` / `decoder` below interpret
+# these tables; tests/test_oracle_graph.py holds them against the op graph of the reference's own `.ckpt.meta` files
+# (tests/golden/ckpt_graph.json, extracted by oracle/gen_ckpt_graph.py): same kinds, order, variables, strides, 'SAME' / NHWC.
+# A trailing True marks the normalisation that only the fixed-bin-width model has (components.py:137-142, 53-58).
+ENCODER_LAYERS = (
+    ('conv2d', 'encoder/weights_1', 4, 'encoder/biases_1'),
+    ('gdn', 'encoder/gamma_1', 'encoder/beta_1'),
+    ('conv2d', 'encoder/weights_2', 2, 'encoder/biases_2'),
+    ('gdn', 'encoder/gamma_2', 'encoder/beta_2'),
+    ('conv2d', 'encoder/weights_3', 2, 'encoder/biases_3'),
+    ('gdn', 'encoder/gamma_3', 'encoder/beta_3', True),
+)
+DECODER_LAYERS = (
+    ('inverse_gdn', 'decoder/gamma_4', 'decoder/beta_4', True),
+    ('conv2d_transpose', 'decoder/weights_4', 2, 'decoder/biases_4'),
+    ('inverse_gdn', 'decoder/gamma_5', 'decoder/beta_5'),
+    ('conv2d_transpose', 'decoder/weights_5', 2, 'decoder/biases_5'),
+    ('inverse_gdn', 'decoder/gamma_6', 'decoder/beta_6'),
+    ('conv2d_transpose', 'decoder/weights_6', 4, None),
+)
+
+
+def layers_of(table, are_bin_widths_learned):
+    """The rows of a table that the model has."""
+    return tuple(row for row in table if not (are_bin_widths_learned and len(row) == 4 and row[3] is True))
+
+
+def _run(x, table, variables, are_bin_widths_learned):
+    outputs = []
+    for row in layers_of(table, are_bin_widths_learned):
+        if row[0] == 'conv2d':
+            x = conv2d_same(x, variables[row[1]], row[2], variables[row[3]] if row[3] else None)
+        elif row[0] == 'conv2d_transpose':
+            x = conv2d_transpose_same(x, variables[row[1]], row[2], variables[row[3]] if row[3] else None)
+        else:
+            x = gdn(x, variables[row[1]], variables[row[2]], inverse=row[0] == 'inverse_gdn')
+        outputs.append(x)
+    return (x, outputs)
+
+
 def encoder(visible_units_float32, variables, are_bin_widths_learned, return_intermediates=False):
     """components.encoder (components.py:86-142). `variables`: dict keyed by the TF variable names."""
-    v = variables
-    conv_1 = conv2d_same(visible_units_float32, v['encoder/weights_1'], 4, v['encoder/biases_1'])
-    gdn_1 = gdn(conv_1, v['encoder/gamma_1'], v['encoder/beta_1'])
-    conv_2 = conv2d_same(gdn_1, v['encoder/weights_2'], 2, v['encoder/biases_2'])
-    gdn_2 = gdn(conv_2, v['encoder/gamma_2'], v['encoder/beta_2'])
-    conv_3 = conv2d_same(gdn_2, v['encoder/weights_3'], 2, v['encoder/biases_3'])
-    y = conv_3 if are_bin_widths_learned else gdn(conv_3, v['encoder/gamma_3'], v['encoder/beta_3'])
+    (y, outputs) = _run(visible_units_float32, ENCODER_LAYERS, variables, are_bin_widths_learned)
     if return_intermediates:
-        return y, {'gdn_1': gdn_1, 'gdn_2': gdn_2, 'conv_3': conv_3}
+        return y, {'gdn_1': outputs[1], 'gdn_2': outputs[3], 'conv_3': outputs[4]}
     return y
 
 
 def decoder(y_tilde, variables, are_bin_widths_learned, return_intermediates=False):
     """components.decoder (components.py:11-84)."""
-    v = variables
-    t = y_tilde if are_bin_widths_learned else gdn(y_tilde, v['decoder/gamma_4'], v['decoder/beta_4'], inverse=True)
-    tc1 = conv2d_transpose_same(t, v['decoder/weights_4'], 2, v['decoder/biases_4'])
-    igdn_2 = gdn(tc1, v['decoder/gamma_5'], v['decoder/beta_5'], inverse=True)
-    tc2 = conv2d_transpose_same(igdn_2, v['decoder/weights_5'], 2, v['decoder/biases_5'])
-    igdn_3 = gdn(tc2, v['decoder/gamma_6'], v['decoder/beta_6'], inverse=True)
-    tc3 = conv2d_transpose_same(igdn_3, v['decoder/weights_6'], 4, None)
+    (tc3, outputs) = _run(y_tilde, DECODER_LAYERS, variables, are_bin_widths_learned)
     if return_intermediates:
-        return tc3, {'igdn_1': t, 'igdn_2': igdn_2, 'igdn_3': igdn_3}
+        first = 0 if are_bin_widths_learned else 1          # igdn_1 is the input itself when the model has no inverse_gdn #4
+        return tc3, {'igdn_1': y_tilde if are_bin_widths_learned else outputs[0], 'igdn_2': outputs[first + 1], 'igdn_3': outputs[first + 3]}
     return tc3

@@ -28,6 +28,8 @@ class NativeLibraryMissing(ImportError):
 
 def _load(name):
     path = os.path.join(LIB_DIR, name)
+    if name == 'libeae_coder.so' and os.environ.get('EAE_CODER_LIB'):
+        path = os.environ['EAE_CODER_LIB']      # e.g. the sanitizer build (`make -C csrc sanitize-test`); same ABI, same checks
     if not os.path.isfile(path):
         raise NativeLibraryMissing(
             '{0} not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` '

@@ -113,18 +113,21 @@ __global__ void cast_int16_kernel(const float* __restrict__ x, int16_t* __restri
     }
 }
 
-// Per-map sums over all rows (lossless/stats.py:306 `numpy.mean(y, axis=(0, 1, 2))` is sums / rows). float64
-// accumulation: thread-private partial over a strided set of rows, then one f64 atomic per (block, channel).
-__global__ __launch_bounds__(256) void map_sums_kernel(const float* __restrict__ y, double* __restrict__ sums, long rows,
+// Per-map means over all rows, EXACTLY lossless/stats.py:306 `numpy.mean(y_float32, axis=(0, 1, 2))`: numpy reduces the
+// leading axes of a C-contiguous array row by row into a float32 accumulator per map (out[c] += y[row][c], rows ascending;
+// no pairwise summation, that only applies along a contiguous reduction axis) and then divides by the float32 row count.
+// One thread per map runs that chain; consecutive threads read consecutive floats, so every row is one coalesced line.
+// (The mean feeds `y - mean` before the quantiser: one ulp of difference can flip a symbol relative to statistics the
+// reference saved, so this is arithmetic to reproduce, not to improve.)
+__global__ __launch_bounds__(64) void map_means_kernel(const float* __restrict__ y, float* __restrict__ means, long rows,
                                                        int c_count) {
-    const int c = threadIdx.x % c_count;
-    const int lanes_per_c = 256 / c_count;          // 2 for 128 maps
-    const int sub = threadIdx.x / c_count;
-    if (sub >= lanes_per_c) return;
-    double acc = 0.0;
-    for (long r = (long)blockIdx.x * lanes_per_c + sub; r < rows; r += (long)gridDim.x * lanes_per_c)
-        acc += (double)y[r * c_count + c];
-    atomicAdd(&sums[c], acc);
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= c_count) return;
+    float acc = 0.f;
+    const float* p = y + c;
+#pragma unroll 8
+    for (long r = 0; r < rows; ++r) acc = acc + p[r * c_count];
+    means[c] = acc / (float)rows;
 }
 
 // One block per map. LDS histogram when the bins fit, global atomics otherwise (caller zeroed hist/overflow).
@@ -279,13 +282,9 @@ __global__ void rgb_to_ycbcr_kernel(const uint8_t* __restrict__ rgb, uint8_t* __
     }
 }
 
-extern "C" int eae_hip_map_sums(const float* y, double* sums, int64_t rows, int c, void* stream) {
-    if (!y || !sums || rows <= 0 || c <= 0 || c > 256) return EAE_HIP_BAD_ARGUMENT;
-    const long per_block = 256 / c;
-    long blocks = (rows + per_block * 64 - 1) / (per_block * 64);
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(map_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, sums, (long)rows, c);
+extern "C" int eae_hip_map_means(const float* y, float* means, int64_t rows, int c, void* stream) {
+    if (!y || !means || rows <= 0 || c <= 0) return EAE_HIP_BAD_ARGUMENT;
+    hipLaunchKernelGGL(map_means_kernel, dim3((unsigned)((c + 63) / 64)), dim3(64), 0, (hipStream_t)stream, y, means, (long)rows, c);
     EAE_HIP_CHECK_LAUNCH();
     return EAE_HIP_OK;
 }

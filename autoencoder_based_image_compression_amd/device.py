@@ -221,12 +221,13 @@ def latent_stage(x, bin_widths, map_mean=None, gdn_in=None, igdn_out=None, want_
 
 
 def map_means(y):
-    """float32 per-map means over every other axis of y [..., C] (lossless/stats.py:306), float64 accumulation."""
+    """float32 per-map means over every other axis of y [..., C]: `numpy.mean(y, axis=(0, 1, 2))` of lossless/stats.py:306 bit
+    for bit (float32 accumulator per map, rows ascending, then / float32(rows))."""
     c = y.shape[-1]
     rows = y.numel()//c
-    sums = torch.zeros(c, dtype=torch.float64, device=y.device)
-    _check(_native.hip().eae_hip_map_sums(_p(y), _p(sums), rows, c, _stream(y)), 'eae_hip_map_sums')
-    return (sums/rows).to(torch.float32)
+    means = torch.empty(c, dtype=torch.float32, device=y.device)
+    _check(_native.hip().eae_hip_map_means(_p(y), _p(means), rows, c, _stream(y)), 'eae_hip_map_means')
+    return means
 
 
 def map_minmax(y):

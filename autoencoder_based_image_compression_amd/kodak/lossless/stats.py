@@ -42,7 +42,8 @@ def _abs_histograms(quantized, bin_widths):
 def compute_map_mean(y_float32):
     """Per-map mean of the latent variables, `numpy.mean(y_float32, axis=(0, 1, 2))` of stats.py:306, on the device.
 
-    float64 accumulation then rounding to float32: within a few float32 ulps of numpy's float32 pairwise mean.
+    Bit for bit numpy's result: one float32 accumulator per map, rows added in order, divided by float32(rows)
+    (eae_hip_map_means; tests/test_gpu_full_size.py::test_map_means compares with `numpy.mean` using `array_equal`).
     """
     from ... import device as dev
     return bk.to_host(dev.map_means(bk.to_device(y_float32, numpy.float32)))

@@ -148,11 +148,10 @@ int eae_hip_latent_stage(const float* x, const float* gamma_in_packed, const flo
                          float* shifted_out, float* t_out, int16_t* symbols_planar, uint32_t* nonzero_flags, uint32_t* checks,
                          int n, int hw, void* stream);
 
-/* Per-map sums for the map means of lossless/stats.py:306 (`numpy.mean(y_float32, axis=(0, 1, 2))`): sums[c] += sum over
- * rows of y[row][c], accumulated in float64 (caller zeroes; the mean is sums / rows, rounded to float32 by the caller).
- * The reference's float32 accumulation is not reproduced (it carries ~1e-6 relative error itself): the result is the
- * exact mean rounded to float32, within 1e-5 relative of numpy's float32 `mean`. */
-int eae_hip_map_sums(const float* y, double* sums, int64_t rows, int c, void* stream);
+/* The map means of lossless/stats.py:306, `numpy.mean(y_float32, axis=(0, 1, 2))`, bit for bit: means[c] = (the float32
+ * sum of y[row][c] accumulated row by row, rows ascending) / float32(rows) -- the order numpy reduces the leading axes of a
+ * C-contiguous float32 array in (tests/test_host_logic.py pins that order against numpy itself). y: [rows][c] f32. */
+int eae_hip_map_means(const float* y, float* means, int64_t rows, int c, void* stream);
 
 /* The two device passes of lossless/stats.py:197-241 (find_index_map_exception), whose per-map loop calls
  * compute_probabilities_intervals(map, 1.) (stats.py:70-134): numpy.amin / amax per map, then a histogram over the

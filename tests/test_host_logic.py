@@ -314,3 +314,17 @@ def test_e3_closed_form_equals_the_reference_loop_for_every_interval():
         assert numpy.array_equal((((code - top) << k) + top + new_bits) & 0xFFFF, c)
         checked += highs.size
     assert checked > 14_000_000
+
+
+def test_numpy_mean_over_leading_axes_is_a_row_by_row_float32_sum():
+    """What eae_hip_map_means reproduces (lossless/stats.py:306): numpy reduces the leading axes of a C-contiguous float32
+    array into one float32 accumulator per map, row after row, and divides by the float32 count. If a numpy release ever
+    changed that order this test, not the GPU test, says so."""
+    rng = numpy.random.RandomState(0)
+    for shape in ((5, 32, 48, 128), (3, 7, 5, 128), (1, 1, 1, 128), (2, 64, 64, 128)):
+        y = (rng.standard_normal(shape)*3 + 0.7).astype(numpy.float32)
+        rows = y.reshape(-1, 128)
+        acc = numpy.zeros(128, dtype=numpy.float32)
+        for row in rows:
+            acc = acc + row
+        assert numpy.array_equal(numpy.mean(y, axis=(0, 1, 2)), acc/numpy.float32(rows.shape[0]))

@@ -56,6 +56,74 @@ def device_info():
     return {'name': name.value.decode(), 'compute_units': cus.value, 'clock_mhz': mhz.value, 'hbm_bytes': mem.value}
 
 
+class Model(object):
+    """eae_hip_model (include/eae_hip.h, whole-path entry points): the variables of one trained entropy autoencoder resident
+    on the current device in the kernels' layouts. `variables`: dict of numpy arrays keyed by the TensorFlow variable names
+    (kodak/eae/graph/variables.py); encoder-only and decoder-only dicts are accepted."""
+
+    _FIELDS = ('weights_1', 'biases_1', 'gamma_1', 'beta_1', 'weights_2', 'biases_2', 'gamma_2', 'beta_2', 'weights_3', 'biases_3',
+               'gamma_3', 'beta_3', 'gamma_4', 'beta_4', 'weights_4', 'biases_4', 'gamma_5', 'beta_5', 'weights_5', 'biases_5',
+               'gamma_6', 'beta_6', 'weights_6')
+
+    def __init__(self, variables, are_bin_widths_learned):
+        import ctypes
+        import numpy
+        self.are_bin_widths_learned = bool(are_bin_widths_learned)
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        pointers = (ctypes.c_void_p*len(self._FIELDS))()
+        keep = []
+        for (i, field) in enumerate(self._FIELDS):
+            name = ('encoder/' if int(field[-1]) <= 3 else 'decoder/') + field
+            if name in variables and not (self.are_bin_widths_learned and field in ('gamma_3', 'beta_3', 'gamma_4', 'beta_4')):
+                array = numpy.ascontiguousarray(variables[name], dtype=numpy.float32)
+                keep.append(array)
+                pointers[i] = array.ctypes.data
+        handle = ctypes.c_void_p()
+        _check(_native.hip().eae_hip_model_create(ctypes.cast(pointers, ctypes.c_void_p), 1 if self.are_bin_widths_learned else 0,
+                                                  ctypes.byref(handle)), 'eae_hip_model_create')
+        self._handle = handle
+
+    def close(self):
+        if getattr(self, '_handle', None):
+            _native.hip().eae_hip_model_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode(self, images_u8):
+        """uint8 [N,H,W] (device) -> latents f32 [N,H/16,W/16,128]: `sess.run(node_y)` of eae/batching.py:96-99 in one call."""
+        if images_u8.dtype != torch.uint8:
+            raise TypeError('`images_u8.dtype` is not `torch.uint8`.')
+        (n, h, wd) = images_u8.shape[:3]
+        nbytes = int(_native.hip().eae_hip_encode_scratch_bytes(n, h, wd))
+        if nbytes == 0:
+            raise ValueError('The image size is not divisible by the product of the three strides.')
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=images_u8.device)
+        latents = torch.empty((n, h//16, wd//16, NB_MAPS), dtype=torch.float32, device=images_u8.device)
+        _check(_native.hip().eae_hip_encode(self._handle, _p(images_u8), n, h, wd, _p(latents), _p(scratch), nbytes, _stream(images_u8)),
+               'eae_hip_encode')
+        return latents
+
+    def decode(self, quantized_latents, want_f32=False, want_u8=True, ref_u8=None, sse=None):
+        """f32 [N,h,w,128] (device) -> (f32 [N,16h,16w] or None, uint8 or None, sse or None): `sess.run(node_reconstruction)` +
+        `tls.cast_bt601` of eae/batching.py:49-53 (+ the squared error of tls.psnr_2d) in one call."""
+        (n, h, wd, c) = quantized_latents.shape
+        d = quantized_latents.device
+        nbytes = int(_native.hip().eae_hip_decode_scratch_bytes(n, h, wd))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=d)
+        out_f32 = torch.empty((n, 16*h, 16*wd), dtype=torch.float32, device=d) if want_f32 else None
+        out_u8 = torch.empty((n, 16*h, 16*wd), dtype=torch.uint8, device=d) if want_u8 else None
+        if ref_u8 is not None and sse is None:
+            sse = torch.zeros(n, dtype=torch.int64, device=d)
+        _check(_native.hip().eae_hip_decode(self._handle, _p(quantized_latents), n, h, wd, _p(out_f32), _p(out_u8), _p(ref_u8), _p(sse),
+                                            _p(scratch), nbytes, _stream(quantized_latents)), 'eae_hip_decode')
+        return out_f32, out_u8, sse
+
+
 def conv9x9s4_u8(x_u8, w_packed, bias, gamma_packed=None, beta=None, out=None):
     """conv_1 + bias_add (+ gdn_1). x_u8: uint8 [N,H,W] or [N,H,W,1] -> f32 [N,H/4,W/4,128].
     w_packed from `pack_conv9x9s4_weights`, gamma_packed from `pack_gamma`."""

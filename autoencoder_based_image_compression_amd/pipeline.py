@@ -31,6 +31,10 @@ class DeviceEncoder(object):
         self.w2 = dev.pack_conv_weights(self.v['encoder/weights_2'])
         self.w3 = dev.pack_conv_weights(self.v['encoder/weights_3'])
         self.g = {i: dev.pack_gamma(self.v['encoder/gamma_{}'.format(i)]) for i in ((1, 2) if are_bin_widths_learned else (1, 2, 3))}
+        # the same variables behind the library's whole-path entry point (include/eae_hip.h: eae_hip_encode); the per-layer
+        # layouts above are what codec.BatchCodec chains itself (it fuses gdn_3 into the latent stage and times every launch)
+        with torch.cuda.device(self.device if self.device.index is not None else torch.cuda.current_device()):
+            self.model = dev.Model({name: variables[name] for name in names}, are_bin_widths_learned)
 
     def __call__(self, luminances_uint8):
         """uint8 [N,H,W] or [N,H,W,1] (device) -> float32 latents [N,H/16,W/16,128] (device)."""
@@ -41,12 +45,9 @@ class DeviceEncoder(object):
             raise ValueError('The height of the input images is not divisible by the product of the three strides.')
         if w_in % csts.STRIDE_PROD != 0:
             raise ValueError('The width of the input images is not divisible by the product of the three strides.')
-        v = self.v
-        gdn_1 = dev.conv9x9s4_u8(luminances_uint8, self.w1, v['encoder/biases_1'], self.g[1], v['encoder/beta_1'])
-        gdn_2 = dev.conv5x5s2(gdn_1, self.w2, v['encoder/biases_2'], dev.NORM_GDN, self.g[2], v['encoder/beta_2'])
-        if self.are_bin_widths_learned:
-            return dev.conv5x5s2(gdn_2, self.w3, v['encoder/biases_3'], dev.NORM_NONE)
-        return dev.conv5x5s2(gdn_2, self.w3, v['encoder/biases_3'], dev.NORM_GDN, self.g[3], v['encoder/beta_3'])
+        if luminances_uint8.dim() == 4:
+            luminances_uint8 = luminances_uint8[:, :, :, 0]
+        return self.model.encode(luminances_uint8.contiguous())
 
 
 class DeviceDecoder(object):
@@ -63,16 +64,12 @@ class DeviceDecoder(object):
         self.w5 = dev.pack_tconv_weights(self.v['decoder/weights_5'])
         self.w6 = dev.pack_tconv9x9s4_weights(self.v['decoder/weights_6'])
         self.g = {i: dev.pack_gamma(self.v['decoder/gamma_{}'.format(i)]) for i in ((5, 6) if are_bin_widths_learned else (4, 5, 6))}
+        with torch.cuda.device(self.device if self.device.index is not None else torch.cuda.current_device()):
+            self.model = dev.Model({name: variables[name] for name in names}, are_bin_widths_learned)      # eae_hip_decode
 
     def __call__(self, quantized_y, want_float=False, want_uint8=True, reference_uint8=None, sse=None):
         """float32 [N,h,w,128] (device) -> (float32 [N,16h,16w] or None, uint8 [N,16h,16w] or None, sse or None)."""
-        v = self.v
-        t = quantized_y
-        if not self.are_bin_widths_learned:
-            t = dev.gdn(t, self.g[4], v['decoder/beta_4'], inverse=True)
-        t = dev.tconv5x5s2(t, self.w4, v['decoder/biases_4'], dev.NORM_IGDN, self.g[5], v['decoder/beta_5'])
-        t = dev.tconv5x5s2(t, self.w5, v['decoder/biases_5'], dev.NORM_IGDN, self.g[6], v['decoder/beta_6'])
-        return dev.tconv9x9s4_luma(t, self.w6, want_f32=want_float, want_u8=want_uint8, ref_u8=reference_uint8, sse=sse)
+        return self.model.decode(quantized_y.contiguous(), want_f32=want_float, want_u8=want_uint8, ref_u8=reference_uint8, sse=sse)
 
 
 # Algorithmic work per INPUT pixel of each launch (SURVEY.md 8(d), BASELINE.md section 2), fixed-bin-width model.

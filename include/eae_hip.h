@@ -45,6 +45,49 @@ int eae_hip_device_info(char* name, int name_cap, int* compute_units, int* clock
  * after synchronising an event recorded behind it. Unlike hipMemcpyAsync this never blocks the calling thread. */
 int eae_hip_publish_to_host(const void* src_device, void* dst_host_mapped, uint64_t bytes, void* stream);
 
+/* ---- whole-path entry points (csrc/hip/model.hip) --------------------------------------------------------------------
+ * What `sess.run(entropy_ae.node_y, feed_dict={node_visible_units: batch})` (eae/batching.py:96-99) and
+ * `sess.run(isolated_decoder.node_reconstruction, feed_dict={node_quantized_y: batch})` followed by `tls.cast_bt601`
+ * (batching.py:49-53) are to the reference: one model object per trained entropy autoencoder, one call per mini-batch.
+ * The numpy steps the reference runs between the two (centring, quantiser, statistics: reconstructing_eae_kodak.py:170-192)
+ * are eae_hip_latent_stage / eae_hip_quantize_maps below; the per-layer ops that encode / decode chain follow further down.
+ *
+ * eae_hip_variables: HOST pointers to the variables of `EntropyAutoencoder` / `IsolatedDecoder` in TensorFlow's layouts, as a
+ * checkpoint holds them (float32, C-contiguous): weights_1 [9][9][1][128], weights_2/3 [5][5][128 in][128 out],
+ * weights_4/5 [5][5][128 out][128 in], weights_6 [9][9][1][128], gamma_i [128][128], biases_i / beta_i [128].
+ * gamma_3, beta_3, gamma_4, beta_4 exist only in the fixed-bin-width model (components.py:137-142, 53-58): NULL when
+ * are_bin_widths_learned != 0. Either side may be left out entirely (all its pointers NULL): an encoder-only model for
+ * eae_hip_encode, a decoder-only one (the reference's IsolatedDecoder, IsolatedDecoder.py:21-129) for eae_hip_decode; a side
+ * that is given must be complete, else EAE_HIP_BAD_ARGUMENT.
+ * eae_hip_model_create uploads and re-lays them out on the current device (7 MB resident) and returns when that is done.
+ * eae_hip_encode:  images uint8 [n][h][w] (device) -> latents f32 [n][h/16][w/16][128] (device). h, w multiples of 16.
+ * eae_hip_decode:  quantised latents f32 [n][h_latent][w_latent][128] (after the de-centring of
+ *   reconstructing_eae_kodak.py:192) -> out_f32 [n][16 h_latent][16 w_latent] (nullable: the float reconstruction),
+ *   out_u8 (nullable: its BT.601 cast), and with ref_u8 + sse the squared error per image as in eae_hip_tconv9x9s4_luma.
+ * scratch: device memory of eae_hip_{encode,decode}_scratch_bytes(...) bytes for the activations between the layers;
+ * contents need not survive between calls, calls that may overlap (different streams) need different blocks. Everything is
+ * asynchronous on `stream`; results are bit-identical to the per-layer entry points and to oracle/transforms_oracle.c. */
+typedef struct eae_hip_model eae_hip_model;
+typedef struct eae_hip_variables {
+    const float *weights_1, *biases_1, *gamma_1, *beta_1;
+    const float *weights_2, *biases_2, *gamma_2, *beta_2;
+    const float *weights_3, *biases_3, *gamma_3, *beta_3;
+    const float *gamma_4, *beta_4;
+    const float *weights_4, *biases_4, *gamma_5, *beta_5;
+    const float *weights_5, *biases_5, *gamma_6, *beta_6;
+    const float *weights_6;
+} eae_hip_variables;
+int eae_hip_model_create(const eae_hip_variables* host_variables, int are_bin_widths_learned, eae_hip_model** model);
+void eae_hip_model_destroy(eae_hip_model* model);
+int eae_hip_model_are_bin_widths_learned(const eae_hip_model* model);
+uint64_t eae_hip_encode_scratch_bytes(int n, int h, int w);                 /* 0 for sizes eae_hip_encode rejects */
+uint64_t eae_hip_decode_scratch_bytes(int n, int h_latent, int w_latent);
+int eae_hip_encode(const eae_hip_model* model, const uint8_t* images, int n, int h, int w, float* latents, void* scratch,
+                   uint64_t scratch_bytes, void* stream);
+int eae_hip_decode(const eae_hip_model* model, const float* quantized_latents, int n, int h_latent, int w_latent,
+                   float* out_f32, uint8_t* out_u8, const uint8_t* ref_u8, uint64_t* sse, void* scratch,
+                   uint64_t scratch_bytes, void* stream);
+
 /* ---- analysis transform (eae/graph/components.py:86-142) ---------------------------------------------------------*/
 
 /* conv_1 + bias_add + gdn_1  (components.py:119-125; tf.nn.conv2d 9x9, 1->128, stride 4, 'SAME' = pad 2/3;

@@ -1,0 +1,108 @@
+"""The whole-path C entry points (include/eae_hip.h: eae_hip_model_create / eae_hip_encode / eae_hip_decode), called through
+ctypes exactly as a C or Cython maintainer would: host pointers to the TensorFlow-layout variables in, device buffers in and
+out, a caller-provided scratch block, a stream. Compared with the CPU oracle (tolerance zero) and with the per-layer entry
+points; argument checking mirrors the reference's own errors (sizes not divisible by 16)."""
+import ctypes
+
+import numpy
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ('weights_1', 'biases_1', 'gamma_1', 'beta_1', 'weights_2', 'biases_2', 'gamma_2', 'beta_2', 'weights_3', 'biases_3',
+          'gamma_3', 'beta_3', 'gamma_4', 'beta_4', 'weights_4', 'biases_4', 'gamma_5', 'beta_5', 'weights_5', 'biases_5',
+          'gamma_6', 'beta_6', 'weights_6')
+
+
+def variables_struct(v, learned, sides=('encoder', 'decoder')):
+    """eae_hip_variables as an array of 23 host pointers in declaration order (+ the arrays, to keep them alive)."""
+    pointers = (ctypes.c_void_p*len(FIELDS))()
+    keep = []
+    for (i, field) in enumerate(FIELDS):
+        side = 'encoder' if int(field[-1]) <= 3 else 'decoder'
+        if side not in sides or (learned and field in ('gamma_3', 'beta_3', 'gamma_4', 'beta_4')):
+            continue
+        keep.append(numpy.ascontiguousarray(v[side + '/' + field], dtype=numpy.float32))
+        pointers[i] = keep[-1].ctypes.data
+    return (pointers, keep)
+
+
+def _model(learned, seed=50):
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    v = var.random_variables(1., learned, seed=seed, bias_std=0.01)
+    v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
+    return v
+
+
+@pytest.mark.parametrize('learned', [False, True])
+@pytest.mark.parametrize('shape', [(2, 64, 96), (1, 16, 16), (3, 48, 32)])
+def test_encode_and_decode_through_the_c_abi(learned, shape):
+    from autoencoder_based_image_compression_amd import _native
+    from oracle import transforms as T
+    lib = _native.hip()
+    v = _model(learned)
+    (pointers, keep) = variables_struct(v, learned)
+    handle = ctypes.c_void_p()
+    assert lib.eae_hip_model_create(ctypes.cast(pointers, ctypes.c_void_p), int(learned), ctypes.byref(handle)) == 0
+    try:
+        assert lib.eae_hip_model_are_bin_widths_learned(handle) == int(learned)
+        (n, h, w) = shape
+        x = numpy.random.RandomState(51).randint(16, 236, size=shape).astype(numpy.uint8)
+        images = torch.from_numpy(x).cuda()
+        scratch = torch.empty(int(lib.eae_hip_encode_scratch_bytes(n, h, w)), dtype=torch.uint8, device='cuda')
+        latents = torch.empty((n, h//16, w//16, 128), dtype=torch.float32, device='cuda')
+        stream = torch.cuda.current_stream().cuda_stream
+        assert lib.eae_hip_encode(handle, images.data_ptr(), n, h, w, latents.data_ptr(), scratch.data_ptr(), scratch.numel(), stream) == 0
+        y_ref = T.encoder(x.astype(numpy.float32)[..., None], v, learned)
+        assert numpy.array_equal(latents.cpu().numpy(), y_ref)
+        # quantise on the host like the reference does between its two sess.run calls, then decode
+        q = numpy.round(y_ref).astype(numpy.float32)
+        q_device = torch.from_numpy(q).cuda()
+        scratch = torch.empty(int(lib.eae_hip_decode_scratch_bytes(n, h//16, w//16)), dtype=torch.uint8, device='cuda')
+        out_f32 = torch.empty((n, h, w), dtype=torch.float32, device='cuda')
+        out_u8 = torch.empty((n, h, w), dtype=torch.uint8, device='cuda')
+        sse = torch.zeros(n, dtype=torch.int64, device='cuda')
+        assert lib.eae_hip_decode(handle, q_device.data_ptr(), n, h//16, w//16, out_f32.data_ptr(), out_u8.data_ptr(), images.data_ptr(),
+                                  sse.data_ptr(), scratch.data_ptr(), scratch.numel(), stream) == 0
+        rec_ref = T.decoder(q, v, learned)[..., 0]
+        rec_u8 = numpy.round(rec_ref.clip(min=16., max=235.)).astype(numpy.uint8)
+        assert numpy.array_equal(out_f32.cpu().numpy(), rec_ref)
+        assert numpy.array_equal(out_u8.cpu().numpy(), rec_u8)
+        expected = ((x.astype(numpy.int64) - rec_u8.astype(numpy.int64))**2).reshape(n, -1).sum(axis=1)
+        assert numpy.array_equal(sse.cpu().numpy(), expected)
+        # argument checks
+        assert lib.eae_hip_encode(handle, images.data_ptr(), n, h + 8, w, latents.data_ptr(), scratch.data_ptr(), scratch.numel(), stream) == -2
+        assert lib.eae_hip_encode_scratch_bytes(n, h + 8, w) == 0
+        assert lib.eae_hip_encode(handle, images.data_ptr(), n, h, w, latents.data_ptr(), scratch.data_ptr(), 16, stream) == -1
+        assert lib.eae_hip_decode(handle, q_device.data_ptr(), n, h//16, w//16, None, None, None, None, scratch.data_ptr(), scratch.numel(), stream) == -1
+    finally:
+        lib.eae_hip_model_destroy(handle)
+
+
+def test_one_sided_and_incomplete_models():
+    from autoencoder_based_image_compression_amd import _native
+    lib = _native.hip()
+    v = _model(False)
+    handle = ctypes.c_void_p()
+    # decoder only (the reference's IsolatedDecoder): decodes, refuses to encode
+    (pointers, keep) = variables_struct(v, False, sides=('decoder',))
+    assert lib.eae_hip_model_create(ctypes.cast(pointers, ctypes.c_void_p), 0, ctypes.byref(handle)) == 0
+    images = torch.zeros((1, 16, 16), dtype=torch.uint8, device='cuda')
+    latents = torch.zeros((1, 1, 1, 128), dtype=torch.float32, device='cuda')
+    scratch = torch.empty(int(lib.eae_hip_encode_scratch_bytes(1, 16, 16)) + int(lib.eae_hip_decode_scratch_bytes(1, 1, 1)), dtype=torch.uint8, device='cuda')
+    assert lib.eae_hip_encode(handle, images.data_ptr(), 1, 16, 16, latents.data_ptr(), scratch.data_ptr(), scratch.numel(), None) == -1
+    out = torch.empty((1, 16, 16), dtype=torch.uint8, device='cuda')
+    assert lib.eae_hip_decode(handle, latents.data_ptr(), 1, 1, 1, None, out.data_ptr(), None, None, scratch.data_ptr(), scratch.numel(), None) == 0
+    torch.cuda.synchronize()
+    lib.eae_hip_model_destroy(handle)
+    # a side with a hole in it, no side at all, a fixed-bin-width model without gamma_3: rejected
+    (pointers, keep) = variables_struct(v, False)
+    pointers[5] = None
+    assert lib.eae_hip_model_create(ctypes.cast(pointers, ctypes.c_void_p), 0, ctypes.byref(handle)) == -1
+    empty = (ctypes.c_void_p*len(FIELDS))()
+    assert lib.eae_hip_model_create(ctypes.cast(empty, ctypes.c_void_p), 0, ctypes.byref(handle)) == -1
+    (pointers, keep) = variables_struct(v, True)
+    assert lib.eae_hip_model_create(ctypes.cast(pointers, ctypes.c_void_p), 0, ctypes.byref(handle)) == -1
+    assert lib.eae_hip_model_create(None, 0, ctypes.byref(handle)) == -1
+    lib.eae_hip_model_destroy(None)                           # like free(NULL)

@@ -36,7 +36,6 @@ from .kodak.lossless import compression as lossless_compression
 # HIP multiplexes streams onto 4 hardware queues: side streams are shared by every codec of the process so that a coder
 # stream never ends up on the hardware queue of the stream the transforms run on.
 _SIDE_STREAMS = {}          # device index -> list of streams
-_PARTITIONS = {}            # (device index, coder CUs per XCD) -> (coder streams, transform streams), CU-masked
 # The result worker polls its events and sleeps in between: `Event.synchronize()` was measured to spin a whole CPU per
 # process (with blocking events too), and eight ranks share one 16-CPU quota. 0 restores synchronize().
 _POLL_SECONDS = float(os.environ.get('EAE_WORKER_POLL_SECONDS', '0.0002'))
@@ -140,7 +139,7 @@ class BatchCodec(object):
     def __init__(self, variables, are_bin_widths_learned, bin_widths_test, map_mean, binary_probabilities, idx_map_exception,
                  batch_size, h_in, w_in, device='cuda', nb_in_flight=2, keep_reconstruction=False, launch_hook=None,
                  coder='device', host_coder_threads=0, hist_radius=2047, nb_transform_streams=1, use_graphs=False,
-                 time_coder=False, coder_cus_per_xcd=0):
+                 time_coder=False):
         """coder: 'device' (the coder kernels on side streams), 'host' (ONE device -> host copy of the symbols per batch, then
         the host C-ABI coder `eae_coder_compress_maps` on `host_coder_threads` threads: the shape BASELINE.json sketches) or
         'none' (transforms only; the bit counts come back as zeros).
@@ -149,9 +148,6 @@ class BatchCodec(object):
         use_graphs: capture the launches of one step into three hipGraphs per slot on first use (analysis side, coder,
         synthesis side) and replay them afterwards: three host launches per step instead of about twenty. For small batches, where the launch thread is the
         bottleneck (one Kodak image per step); `launch_hook` is not called for replayed steps. Not for coder='host'.
-        coder_cus_per_xcd: > 0 = the coder launches go to streams that may only use the first that many CUs of every XCD and
-        the transforms to a stream that may only use the others (device.partition_stream): the coder's latency-bound wavefronts
-        stop sharing SIMDs with the MFMA waves. For latents of realistic entropy.
         hist_radius: the exception map's entropy is formed from an exact histogram of its symbols over [-hist_radius,
         hist_radius]; a symbol outside it makes `Ticket.result()` raise (the image-by-image functions of `kodak/` widen the
         histogram instead)."""
@@ -204,17 +200,6 @@ class BatchCodec(object):
         self.nb_slots = nb_in_flight + 2
         self._streams = _side_streams(nb_in_flight, self.device)
         self._transform_streams = _side_streams(nb_in_flight + nb_transform_streams, self.device)[nb_in_flight:] if nb_transform_streams > 1 else []
-        if coder_cus_per_xcd > 0:
-            key = (self.device.index, int(coder_cus_per_xcd))
-            if key not in _PARTITIONS:
-                _PARTITIONS[key] = ([], [])
-            (coder_side, transform_side) = _PARTITIONS[key]
-            while len(coder_side) < nb_in_flight:
-                coder_side.append(dev.partition_stream(coder_cus_per_xcd, False))
-            while len(transform_side) < max(1, nb_transform_streams):
-                transform_side.append(dev.partition_stream(coder_cus_per_xcd, True))
-            self._streams = coder_side[:nb_in_flight]
-            self._transform_streams = transform_side[:max(1, nb_transform_streams)]
         self._slot_all = [torch.zeros(nb_words + 2*batch_size, dtype=torch.int32, device=self.device) for _ in range(self.nb_slots)]
         self._slot_out = [t[:nb_words] for t in self._slot_all]
         self._pinned_out = [torch.zeros(nb_words, dtype=torch.int32).pin_memory() for _ in range(self.nb_slots)]

@@ -38,35 +38,3 @@ extern "C" int eae_hip_publish_to_host(const void* src_device, void* dst_host_ma
                        (uint32_t*)dst_host_mapped, words);
     return (int)hipGetLastError();
 }
-
-// Streams restricted to part of the machine (hipExtStreamCreateWithCUMask). Mask bit i selects CU i / 8 of XCD i % 8 (probed on
-// MI355X, scratch/probe_cumask.hip); an XCD with no bit set runs on all of its CUs, so every partition keeps at least one CU per
-// XCD. complement == 0: the first `cus_per_xcd` CUs of every XCD; != 0: all the others.
-extern "C" int eae_hip_stream_create_partition(int cus_per_xcd, int complement, void** stream) {
-    if (!stream) return -1;
-    *stream = nullptr;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    hipDeviceProp_t prop;
-    e = hipGetDeviceProperties(&prop, dev);
-    if (e != hipSuccess) return (int)e;
-    const int cus = prop.multiProcessorCount;
-    if (cus < 16 || (cus & 7) || cus > 1024) return -2;
-    const int per_xcd = cus / 8;
-    if (cus_per_xcd < 1 || cus_per_xcd >= per_xcd) return -1;
-    uint32_t mask[32] = {0};
-    for (int i = 0; i < cus; ++i) {
-        const bool first = i / 8 < cus_per_xcd;
-        if (first != (complement != 0)) mask[i >> 5] |= 1u << (i & 31);
-    }
-    hipStream_t s = nullptr;
-    e = hipExtStreamCreateWithCUMask(&s, (uint32_t)((cus + 31) / 32), mask);
-    if (e != hipSuccess) return (int)e;
-    *stream = s;
-    return 0;
-}
-extern "C" int eae_hip_stream_destroy(void* stream) {
-    if (!stream) return 0;
-    return (int)hipStreamDestroy((hipStream_t)stream);
-}

@@ -56,16 +56,6 @@ def device_info():
     return {'name': name.value.decode(), 'compute_units': cus.value, 'clock_mhz': mhz.value, 'hbm_bytes': mem.value}
 
 
-def partition_stream(cus_per_xcd, complement):
-    """A torch stream restricted to the first `cus_per_xcd` CUs of every XCD (or, with `complement`, to all the others) on the
-    current device (include/eae_hip.h: eae_hip_stream_create_partition). The stream lives as long as the process."""
-    import ctypes
-    handle = ctypes.c_void_p()
-    _check(_native.hip().eae_hip_stream_create_partition(int(cus_per_xcd), 1 if complement else 0, ctypes.byref(handle)),
-           'eae_hip_stream_create_partition')
-    return torch.cuda.ExternalStream(handle.value, device=torch.device('cuda', torch.cuda.current_device()))
-
-
 class Model(object):
     """eae_hip_model (include/eae_hip.h, whole-path entry points): the variables of one trained entropy autoencoder resident
     on the current device in the kernels' layouts. `variables`: dict of numpy arrays keyed by the TensorFlow variable names

@@ -57,9 +57,6 @@ def parse_args(argv=None):
                              'events around a launch time that kernel alone (the roofline figures). 2-3: consecutive batches '
                              'alternate between private streams and their kernels overlap (fills the tails: +6-8 %% whole-job '
                              'throughput with --coder-streams 3), but a launch then shares the GPU and its duration says little')
-    parser.add_argument('--coder-cus', type=int, default=int(os.environ.get('EAE_CODER_CUS', '0')),
-                        help='CUs per XCD set aside for the coder (0 = none: coder and transforms share every CU). The coder '
-                             'streams are then restricted to those CUs and the transforms to the others')
     parser.add_argument('--graphs', action='store_true',
                         help='replay one captured hipGraph per step instead of launching kernel by kernel (small batches: the '
                              'launch thread is the bottleneck there). No per-launch events, so no roofline figures')
@@ -198,7 +195,7 @@ class Context(object):
 
 
 def run_pipeline(ctx, batch, steps, warmup, variables, coder='device', coder_streams=2, transform_streams=1, use_graphs=False,
-                 min_seconds=0., max_blocks=1, record_gemm=False, coder_events=False, coder_cus=0):
+                 min_seconds=0., max_blocks=1, record_gemm=False, coder_events=False):
     """Builds the resident state for `batch` images per step (codec.BatchCodec: weights, tables, per-slot buffers), runs
     `warmup` untimed steps, then BLOCKS of exactly `steps` timed steps -- each block bracketed by barrier + synchronize on
     both sides, its wall time the MAX over ranks -- until `min_seconds` have been timed (at most `max_blocks` blocks; the
@@ -232,7 +229,7 @@ def run_pipeline(ctx, batch, steps, warmup, variables, coder='device', coder_str
     with codec.BatchCodec(variables, False, bin_widths, map_mean_host, probabilities, IDX_MAP_EXCEPTION, batch, H_IN, W_IN,
                           device=device, nb_in_flight=coder_streams, launch_hook=timed_launch if record_gemm else None,
                           coder=coder_mode, host_coder_threads=coder_threads, nb_transform_streams=transform_streams,
-                          use_graphs=use_graphs, time_coder=coder_events, coder_cus_per_xcd=coder_cus) as the_codec:
+                          use_graphs=use_graphs, time_coder=coder_events) as the_codec:
         for _ in range(warmup):
             the_codec.submit(images)
         the_codec.drain()
@@ -357,7 +354,7 @@ def main(args):
     variables = synthetic_model(args.bin_width)
     run = run_pipeline(ctx, args.batch, args.steps, args.warmup, variables, coder=args.coder, coder_streams=args.coder_streams,
                        transform_streams=args.transform_streams, use_graphs=args.graphs, min_seconds=args.min_seconds,
-                       max_blocks=args.max_blocks, record_gemm=True, coder_cus=args.coder_cus)
+                       max_blocks=args.max_blocks, record_gemm=True)
     (elapsed, stats, gemm_events, probabilities, map_mean_host) = (run['elapsed'], run['stats'], run['gemm_events'],
                                                                     run['probabilities'], run['map_mean_host'])
     (host_coder, coder_threads) = (run['host_coder'], run['coder_threads'])

@@ -88,14 +88,6 @@ int eae_hip_decode(const eae_hip_model* model, const float* quantized_latents, i
                    float* out_f32, uint8_t* out_u8, const uint8_t* ref_u8, uint64_t* sse, void* scratch,
                    uint64_t scratch_bytes, void* stream);
 
-/* Streams that may only use part of the compute units (hipExtStreamCreateWithCUMask): cus_per_xcd in [1, CUs per XCD - 1];
- * complement == 0 -> the first cus_per_xcd CUs of every XCD, != 0 -> all the other CUs. For giving the lossless coder CUs of
- * its own: its few long-lived, latency-bound wavefronts run about four times slower on a SIMD they share with f32 MFMA
- * waves (a vector instruction waits for the 64-cycle MFMA ahead of it), and the transforms lose less from 1/16 fewer CUs than
- * from hosting them. Returns 0, -1 (bad argument), -2 (device not divisible into 8 XCDs) or a hipError_t. */
-int eae_hip_stream_create_partition(int cus_per_xcd, int complement, void** stream);
-int eae_hip_stream_destroy(void* stream);
-
 /* ---- analysis transform (eae/graph/components.py:86-142) ---------------------------------------------------------*/
 
 /* conv_1 + bias_add + gdn_1  (components.py:119-125; tf.nn.conv2d 9x9, 1->128, stride 4, 'SAME' = pad 2/3;

@@ -23,17 +23,37 @@ def rows_of(directory):
     return rows
 
 
-# template arguments <waves per block, epilogue> of the four launches at Kodak batch sizes (conv_gemm.hip, launch())
-# <waves per block, epilogue (0 none / 1 GDN / 2 IGDN), 32-channel tiles per wave>
-INSTANCES = {'conv2_gdn2': 'conv_gemm_wave_kernel<2, 1, 4>', 'conv3': 'conv_gemm_wave_kernel<1, 0, 2>',
-             'tconv1_igdn5': 'conv_gemm_wave_kernel<1, 2, 4>', 'tconv2_igdn6': 'conv_gemm_wave_kernel<2, 2, 4>'}
+# The four launches of a step are instances of conv_gemm_split_kernel<epilogue> (0 none / 1 GDN / 2 IGDN); the two transposed
+# convolutions share an instance, so a launch is identified by (instance, grid size in work-items). Grid of a layer
+# (conv_gemm_split.hip: launch_split): 8 x ceil((tiles of the largest XCD share + cut tiles) / 4) blocks of 256 threads.
+def grid_items(batch, positions_per_image, phases, cut, cus=256):
+    tiles = batch*positions_per_image//32
+    share = -(-tiles//8)*phases
+    simds = 4*cus
+    d = 0
+    if cut:
+        k = max(1, min(3, tiles*phases//simds))
+        d = min(share, (cus//8)*4*k)
+    return -(-(share + d)//4)*8*256
+
+
+def instances(batch):
+    px = 512*768
+    return {'conv2_gdn2': ('conv_gemm_split_kernel<1>', grid_items(batch, px//64, 1, True)),
+            'conv3': ('conv_gemm_split_kernel<0>', grid_items(batch, px//256, 1, True)),
+            'tconv1_igdn5': ('conv_gemm_split_kernel<2>', grid_items(batch, px//256, 4, False)),
+            'tconv2_igdn6': ('conv_gemm_split_kernel<2>', grid_items(batch, px//64, 4, False))}
+
+
+INSTANCES = {}
 
 
 def per_kernel(directory, counter, name):
-    """Counter values of every dispatch of one conv GEMM instance."""
+    """Counter values of every dispatch of one conv GEMM launch of the step."""
+    (instance, grid) = INSTANCES[name]
     out = collections.OrderedDict()
     for r in rows_of(directory):
-        if r['Counter_Name'] != counter or INSTANCES[name] not in r['Kernel_Name']:
+        if r['Counter_Name'] != counter or instance not in r['Kernel_Name'] or int(r['Grid_Size']) != grid:
             continue
         out[int(r['Dispatch_Id'])] = out.get(int(r['Dispatch_Id']), 0.) + float(r['Counter_Value'])
     return [out[k] for k in sorted(out)]
@@ -41,6 +61,7 @@ def per_kernel(directory, counter, name):
 
 def main():
     (root, batch) = (sys.argv[1], int(sys.argv[2]))
+    INSTANCES.update(instances(batch))
     names = ['conv2_gdn2', 'conv3', 'tconv1_igdn5', 'tconv2_igdn6']     # launch order inside one step
     pixels = batch*512*768
     # algorithmic bytes per launch: input activations + output activations, float32, each read / written once
@@ -64,7 +85,7 @@ def main():
     result['hbm_bytes_per_launch'] = sum(result[n]['hbm_read_bytes'] + result[n]['hbm_write_bytes'] for n in names)/4.
     result['algorithmic_bytes_per_launch'] = sum(algorithmic.values())/4.
     result['note'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE (separate passes) on `python3 bench.py '
-                      '--steps 3 --warmup 1 --no-cpu-baseline` (batch {}); counters are in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md '
+                      '--steps 3 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-single-image` (batch {}); counters are in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md '
                       '(16-B/lane loads are tallied at half); FETCH_SIZE counts L2 misses including Infinity Cache hits; per-launch average '
                       'over the four conv GEMM launches of a step. MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs).'
                       .format(batch))

@@ -400,7 +400,7 @@ def main(args):
         # summed over ranks by the path's one all-reduce, over all timed blocks: exact integers (tests compare them across world sizes)
         'totals': {'bits': int(stats[0].item()), 'sse': int(stats[1].item()), 'dead_maps': int(stats[2].item()), 'images': int(nb_images_total)},
         'rate_bpp': round(bpp, 5), 'psnr_db_pooled': round(mean_psnr, 4), 'dead_maps_per_image': round(stats[2].item()/nb_images_total, 3),
-        'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_wave_kernel (conv2+GDN2, conv3, tconv1+IGDN5, tconv2+IGDN6)',
+        'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_split_kernel (conv2+GDN2, conv3, tconv1+IGDN5, tconv2+IGDN6)',
                      'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': round(achieved/PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
                      'avg_launch_ms': round(gemm_ms/max(gemm_launches, 1), 4),

@@ -139,7 +139,7 @@ class BatchCodec(object):
     def __init__(self, variables, are_bin_widths_learned, bin_widths_test, map_mean, binary_probabilities, idx_map_exception,
                  batch_size, h_in, w_in, device='cuda', nb_in_flight=2, keep_reconstruction=False, launch_hook=None,
                  coder='device', host_coder_threads=0, hist_radius=2047, nb_transform_streams=1, use_graphs=False,
-                 time_coder=False):
+                 time_coder=False, fuse_latent=False):
         """coder: 'device' (the coder kernels on side streams), 'host' (ONE device -> host copy of the symbols per batch, then
         the host C-ABI coder `eae_coder_compress_maps` on `host_coder_threads` threads: the shape BASELINE.json sketches) or
         'none' (transforms only; the bit counts come back as zeros).
@@ -148,6 +148,10 @@ class BatchCodec(object):
         use_graphs: capture the launches of one step into three hipGraphs per slot on first use (analysis side, coder,
         synthesis side) and replay them afterwards: three host launches per step instead of about twenty. For small batches, where the launch thread is the
         bottleneck (one Kodak image per step); `launch_hook` is not called for replayed steps. Not for coder='host'.
+        fuse_latent: run the latent stage (gdn_3, quantiser, inverse_gdn_4) as the epilogue of the conv_3 launch instead of as
+        its own kernel (device.conv5x5s2_latent; same bits). One launch fewer, but at Kodak batch sizes conv_3 has one tile per
+        SIMD and nothing to hide that epilogue behind: 3.41 against 3.44 ms per 24 images, with the conv_3 launch at 0.36 ms
+        instead of 0.27 + 0.12. Pays for batches that give conv_3 several tiles per SIMD.
         hist_radius: the exception map's entropy is formed from an exact histogram of its symbols over [-hist_radius,
         hist_radius]; a symbol outside it makes `Ticket.result()` raise (the image-by-image functions of `kodak/` widen the
         histogram instead)."""
@@ -188,6 +192,7 @@ class BatchCodec(object):
         self.hist_radius = int(hist_radius)
         self.coder = coder
         self.time_coder = bool(time_coder)      # Ticket.coder_ms(): the launch-by-launch path only
+        self.fuse_latent = bool(fuse_latent)
         self.launch_hook = launch_hook if launch_hook is not None else (lambda name, fn: fn())
         n_maps = batch_size*self.nb_maps
         nb_hist = batch_size if self.idx_map_exception >= 0 else 0
@@ -354,15 +359,21 @@ class BatchCodec(object):
         gdn_1 = dev.conv9x9s4_u8(luminances_uint8, enc.w1, v['encoder/biases_1'], enc.g[1], v['encoder/beta_1'])
         ws = self._conv_ws[slot]
         gdn_2 = hook('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, enc.w2, v['encoder/biases_2'], dev.NORM_GDN, enc.g[2], v['encoder/beta_2'], workspace=ws))
-        y_raw = hook('conv3', lambda: dev.conv5x5s2(gdn_2, enc.w3, v['encoder/biases_3'], dev.NORM_NONE, workspace=ws))
         (_, hist, overflow, flags, checks) = self._views(self._slot_out[slot])
         self._slot_all[slot][4*self._n_maps:].zero_()    # histograms, overflow, flags, checks, squared errors: accumulated into
-        # gdn_3 -> centre / quantise / symbols / dead-map flags -> de-centre -> inverse_gdn_4: one pass over the latents
-        q = dev.latent_stage(y_raw, self.bin_widths, self.map_mean,
-                             gdn_in=None if self.learned else (enc.g[3], v['encoder/beta_3']),
-                             igdn_out=None if self.learned else (self.decoder.g[4], d['decoder/beta_4']),
-                             want_shifted=self.learned, want_symbols=True, want_flags=True, out_symbols=self._symbols[slot],
-                             out_flags=flags, out_checks=checks[:3])
+        gdn_in = None if self.learned else (enc.g[3], v['encoder/beta_3'])
+        igdn_out = None if self.learned else (self.decoder.g[4], d['decoder/beta_4'])
+        if self.fuse_latent:
+            # conv_3 with the latent stage as its epilogue: one launch, the latents never go through HBM in between
+            q = hook('conv3', lambda: dev.conv5x5s2_latent(gdn_2, enc.w3, v['encoder/biases_3'], self.bin_widths, self.map_mean, gdn_in=gdn_in,
+                                                           igdn_out=igdn_out, want_flags=True, out_symbols=self._symbols[slot],
+                                                           out_flags=flags, out_checks=checks[:3], workspace=ws))
+        else:
+            y_raw = hook('conv3', lambda: dev.conv5x5s2(gdn_2, enc.w3, v['encoder/biases_3'], dev.NORM_NONE, workspace=ws))
+            # gdn_3 -> centre / quantise / symbols / dead-map flags -> de-centre -> inverse_gdn_4: one pass over the latents
+            q = dev.latent_stage(y_raw, self.bin_widths, self.map_mean, gdn_in=gdn_in, igdn_out=igdn_out, want_shifted=self.learned,
+                                 want_symbols=True, want_flags=True, out_symbols=self._symbols[slot], out_flags=flags,
+                                 out_checks=checks[:3])
         if self.idx_map_exception >= 0:
             dev.symbol_histograms(self._symbols[slot].view(self._n_maps, self.map_size), self.hist_radius, out=(hist, overflow),
                                   first_map=self.idx_map_exception, map_step=self.nb_maps, zero=False)

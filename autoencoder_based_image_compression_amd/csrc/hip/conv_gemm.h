@@ -2,6 +2,7 @@
 // layers too small to fill the machine; conv_gemm_split.hip: one item per wave, the launch's last tiles cut at a K-step boundary).
 #pragma once
 #include "common.h"
+#include "latent_body.h"
 
 namespace eae_conv_gemm {
 
@@ -36,8 +37,16 @@ struct ConvGemmParams {
     unsigned int* split_ws;             // conv_gemm_split.hip: zeroed workspace of SPLIT_WORDS words (left zeroed), or nullptr
     int split;                          // conv_gemm_split.hip: 1 = the last tiles of each XCD's share are cut in two
     int split_resident_waves_per_xcd;   // conv_gemm_split.hip: how many tiles get cut (the waves an XCD holds at once)
+    // conv_gemm_split.hip, norm == NORM_LATENT / NORM_LATENT_PLAIN: the latent stage behind conv_3 (latent_body.h)
+    const float* map_mean;              // [128] or nullptr
+    const float* bin_widths;            // [128]
+    const float* gamma_out;             // packed, inverse_gdn_4 (NORM_LATENT)
+    const float* beta_out;
+    LatentOut latent;
     PhaseDesc phase[4];
 };
+// epilogues beyond EAE_NORM_*: conv_3 + bias -> gdn_3 -> quantiser -> inverse_gdn_4 (fixed bin widths), or -> quantiser only
+constexpr int NORM_LATENT = 3, NORM_LATENT_PLAIN = 4;
 
 // conv_gemm_split.hip
 constexpr int SPLIT_WORDS = 256 + 8 * 1024;     // [255] timeout word; 8 x 1024 "head published" flags

@@ -417,6 +417,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
     }
 }
 
+// conv_gemm_split.hip when EAE_HIP_GEMM asks for it or the layer has at least one 32-position tile per SIMD; 1 = not taken
+int try_split(ConvGemmParams& p, hipStream_t stream) {
+    const char* form = std::getenv("EAE_HIP_GEMM");
+    const char f = form ? form[0] : 0;
+    if (!(f == 's' || f == 'u' || f == 0)) return 1;
+    int cut = f == 'u' ? 0 : -1;
+    if (f == 's') {
+        const char* e = std::getenv("EAE_HIP_SPLIT_WAVES");
+        cut = e ? std::atoi(e) : 3;
+        if (cut < 1 || cut > 3) cut = 3;
+    }
+    const long tiles32 = ((long)p.n * ((p.hp + 3) / 4) * ((p.wp + 7) / 8)) * p.n_phases;
+    if (f == 0 && tiles32 < 1024) return 1;
+    return launch_split(p, stream, cut);
+}
+
 int launch(ConvGemmParams& p, hipStream_t stream) {
     // EAE_HIP_GEMM (read per launch: the parity tests run every form and compare bits):
     //   unset  conv_gemm_split.hip (one item per wave; the last tiles cut when the shape calls for it and the caller gave a
@@ -427,18 +443,9 @@ int launch(ConvGemmParams& p, hipStream_t stream) {
     const char f = form ? form[0] : 0;
     const int variant = f == 'l' ? 0 : 1;
     p.stamps = g_stamp_buffer;
-    if (f == 's' || f == 'u' || f == 0) {
-        int cut = f == 'u' ? 0 : -1;
-        if (f == 's') {
-            const char* e = std::getenv("EAE_HIP_SPLIT_WAVES");
-            cut = e ? std::atoi(e) : 3;
-            if (cut < 1 || cut > 3) cut = 3;
-        }
-        const long tiles32 = ((long)p.n * ((p.hp + 3) / 4) * ((p.wp + 7) / 8)) * p.n_phases;
-        if (f != 0 || tiles32 >= 1024) {
-            const int rc = launch_split(p, stream, cut);
-            if (rc != 1) return rc;
-        }
+    {
+        const int rc = try_split(p, stream);
+        if (rc != 1) return rc;
     }
     const long positions = (long)p.n * p.hp * p.wp;
     if (variant == 0) {          // block-cooperative LDS slabs (one barrier per K-step); phase is the fastest index
@@ -554,6 +561,42 @@ extern "C" int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const f
                                   void* stream) {
     return tconv5x5s2(x, w_packed, bias, norm, gamma_packed, beta, out, n, h, w_in, nullptr, stream);
 }
+// conv_3 + bias with the latent stage behind it (latent_body.h) in ONE launch when the layer is large enough for
+// conv_gemm_split_kernel; otherwise the convolution followed by eae_hip_latent_stage in place: same bits either way.
+extern "C" int eae_hip_conv5x5s2_latent(const float* x, const float* w_packed, const float* bias, const float* gamma_in_packed,
+                                        const float* beta_in, const float* map_mean, const float* bin_widths,
+                                        const float* gamma_out_packed, const float* beta_out, float* y_out, float* shifted_out,
+                                        float* t_out, int16_t* symbols_planar, uint32_t* nonzero_flags, uint32_t* checks, int n,
+                                        int h, int w_in, void* workspace, void* stream) {
+    if (!x || !w_packed || !bin_widths || n <= 0 || h <= 0 || w_in <= 0) return EAE_HIP_BAD_ARGUMENT;
+    if ((gamma_in_packed == nullptr) != (beta_in == nullptr)) return EAE_HIP_BAD_ARGUMENT;
+    if ((gamma_out_packed == nullptr) != (beta_out == nullptr) || (gamma_in_packed == nullptr) != (gamma_out_packed == nullptr))
+        return EAE_HIP_BAD_ARGUMENT;                      // both normalisations (fixed bin widths) or neither (learned)
+    const bool fixed = gamma_in_packed != nullptr;
+    float* main_out = fixed ? t_out : shifted_out;        // the decoder's input: also where a cut tile's accumulators wait
+    if (!main_out) return EAE_HIP_BAD_ARGUMENT;
+    if ((h & 1) || (w_in & 1)) return EAE_HIP_BAD_SHAPE;
+    ConvGemmParams p{};
+    p.in = x; p.out = main_out; p.w = w_packed; p.bias = bias; p.gamma = gamma_in_packed; p.beta = beta_in;
+    p.norm = fixed ? NORM_LATENT : NORM_LATENT_PLAIN;
+    p.n = n; p.hin = h; p.win = w_in; p.hp = h / 2; p.wp = w_in / 2; p.hout = h / 2; p.wout = w_in / 2;
+    p.in_stride = 2; p.out_stride = 1; p.n_phases = 1; p.split_ws = static_cast<unsigned int*>(workspace);
+    p.map_mean = map_mean; p.bin_widths = bin_widths; p.gamma_out = gamma_out_packed; p.beta_out = beta_out;
+    p.latent = LatentOut{y_out, shifted_out, t_out, symbols_planar, nonzero_flags, checks};
+    PhaseDesc& pd = p.phase[0];
+    pd.out_a = 0; pd.out_b = 0; pd.ntaps = 25;
+    for (int u = 0; u < 5; ++u)
+        for (int v = 0; v < 5; ++v) pd.tap[u * 5 + v] = pack_tap(u - 1, v - 1, u * 5 + v);
+    p.stamps = g_stamp_buffer;
+    int rc = try_split(p, (hipStream_t)stream);
+    if (rc != 1) return rc;
+    // small layer (or another kernel form forced): the two launches, the stage in place on the convolution's output
+    rc = conv5x5s2(x, w_packed, bias, EAE_NORM_NONE, nullptr, nullptr, main_out, n, h, w_in, static_cast<unsigned int*>(workspace), stream);
+    if (rc) return rc;
+    return eae_hip_latent_stage(main_out, gamma_in_packed, beta_in, map_mean, bin_widths, gamma_out_packed, beta_out, y_out,
+                                shifted_out, t_out, symbols_planar, nonzero_flags, checks, n, (h / 2) * (w_in / 2), stream);
+}
+
 extern "C" uint64_t eae_hip_conv_workspace_bytes(void) { return (uint64_t)SPLIT_WORDS * sizeof(unsigned int); }
 extern "C" int eae_hip_conv5x5s2_ws(const float* x, const float* w_packed, const float* bias, int norm,
                                     const float* gamma_packed, const float* beta, float* out, int n, int h, int w_in,

@@ -40,7 +40,9 @@ namespace {
 
 constexpr int RING = 8;
 constexpr int ABUF = 32 * AS_STRIDE;                 // one activation buffer of one wave
-constexpr int WAVE_LDS = 2 * ABUF + 2 * EAE_C;       // + bias[128] + beta[128]
+// per wave: two activation buffers + the per-channel vectors of the epilogue: bias | beta, or, with the latent stage behind
+// conv_3, bias | beta_in | beta_out | map_mean | bin_widths
+constexpr int wave_lds(int norm) { return 2 * ABUF + (norm >= NORM_LATENT ? 5 : 2) * EAE_C; }
 constexpr int QT_H = 4, QT_W = 8;                    // a wave's tile: 4 x 8 positions
 constexpr int MIN_PIECE = 4;                         // K-steps: no head or tail shorter than this
 constexpr int SPIN_LIMIT = 1 << 22;                  // ~1 s of polling: a bug, not a wait; sets the error word
@@ -50,17 +52,28 @@ __device__ __forceinline__ int head_steps(int d, int D, int T) {
     return T < 3 * MIN_PIECE ? T : MIN_PIECE + (d * (T - 2 * MIN_PIECE)) / D;
 }
 
+// Three waves per SIMD (<= 168 registers) for the plain epilogues; the latent-stage epilogue (two normalisations and the
+// quantiser on the register tile) needs ~190 and gets two: conv_3 has a quarter of conv_2's tiles, at Kodak batch sizes its
+// SIMDs hold one or two waves anyway.
 template <int NORM>
-__global__ __launch_bounds__(256, 3) void conv_gemm_split_kernel(const ConvGemmParams p) {
+__global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_split_kernel(const ConvGemmParams p) {
+    constexpr int WAVE_LDS = wave_lds(NORM);
     __shared__ __attribute__((aligned(16))) float lds[4 * WAVE_LDS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* wlds = lds + wave * WAVE_LDS;
     float* vec_lds = wlds + 2 * ABUF;
     {
-        const float2 bz = p.bias ? *reinterpret_cast<const float2*>(p.bias + 2 * lane) : make_float2(0.f, 0.f);
-        *reinterpret_cast<float2*>(vec_lds + 2 * lane) = bz;
-        if (NORM != EAE_NORM_NONE) *reinterpret_cast<float2*>(vec_lds + EAE_C + 2 * lane) = *reinterpret_cast<const float2*>(p.beta + 2 * lane);
+        const float2 z = make_float2(0.f, 0.f);
+        *reinterpret_cast<float2*>(vec_lds + 2 * lane) = p.bias ? *reinterpret_cast<const float2*>(p.bias + 2 * lane) : z;
+        if (NORM == EAE_NORM_GDN || NORM == EAE_NORM_IGDN || NORM == NORM_LATENT)
+            *reinterpret_cast<float2*>(vec_lds + EAE_C + 2 * lane) = *reinterpret_cast<const float2*>(p.beta + 2 * lane);
+        if (NORM >= NORM_LATENT) {
+            if (NORM == NORM_LATENT_PLAIN) *reinterpret_cast<float2*>(vec_lds + EAE_C + 2 * lane) = z;
+            *reinterpret_cast<float2*>(vec_lds + 2 * EAE_C + 2 * lane) = NORM == NORM_LATENT ? *reinterpret_cast<const float2*>(p.beta_out + 2 * lane) : z;
+            *reinterpret_cast<float2*>(vec_lds + 3 * EAE_C + 2 * lane) = p.map_mean ? *reinterpret_cast<const float2*>(p.map_mean + 2 * lane) : z;
+            *reinterpret_cast<float2*>(vec_lds + 4 * EAE_C + 2 * lane) = *reinterpret_cast<const float2*>(p.bin_widths + 2 * lane);
+        }
     }
     const int hi = lane >> 5, lj = lane & 31, a_q = lane & 7;
     const int cbase = 4 * hi;
@@ -228,7 +241,26 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_split_kernel(const ConvGemmP
         }
 
         if (s1 == T) {
-            wave_epilogue<NORM>(acc, vec_lds, p.bias != nullptr, p.gamma, o, valid, lane);
+            if constexpr (NORM >= NORM_LATENT) {
+                // conv_3: bias_add, then the whole latent stage on the register tile (latent_body.h); the tile's pixels in
+                // p.out (where a cut tile's accumulators waited) receive the decoder's input
+                if (p.bias) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 bv = *reinterpret_cast<const float4*>(vec_lds + 32 * t + 8 * g + cbase);
+                            acc[t][4 * g + 0] = acc[t][4 * g + 0] + bv.x;
+                            acc[t][4 * g + 1] = acc[t][4 * g + 1] + bv.y;
+                            acc[t][4 * g + 2] = acc[t][4 * g + 2] + bv.z;
+                            acc[t][4 * g + 3] = acc[t][4 * g + 3] + bv.w;
+                        }
+                }
+                wave_latent_body<NORM == NORM_LATENT, NORM == NORM_LATENT>(acc, vec_lds + EAE_C, p.gamma, p.gamma_out, p.latent, valid,
+                                                                           (long)img, pr * p.wp + pc, p.hp * p.wp, lane);
+            } else {
+                wave_epilogue<NORM>(acc, vec_lds, p.bias != nullptr, p.gamma, o, valid, lane);
+            }
         } else {
             // a head: park the accumulators in the tile's own output pixels, write-through, and publish them
 #pragma unroll
@@ -286,6 +318,7 @@ int eae_conv_gemm::launch_split(ConvGemmParams& p, hipStream_t stream, int cut) 
         split = (double)rounds * simds > 1.03 * (double)tiles;
     }
     if (split && !p.split_ws) return EAE_HIP_BAD_ARGUMENT;
+    if (p.norm >= NORM_LATENT && k > 2) k = 2;       // that instance holds two waves per SIMD
     if ((cus / 8) * 4 * k > 1024) return 1;          // flag table: 1024 cut tiles per XCD
     // longest phase first (insertion sort of <= 4 descriptors): every CU works through the same mix of phases, and the last
     // tiles of the launch -- the ones that get cut -- are the short ones
@@ -299,7 +332,9 @@ int eae_conv_gemm::launch_split(ConvGemmParams& p, hipStream_t stream, int cut) 
     const long cnt_max = (nsp + 7) / 8 * p.n_phases;
     const long d_max = split ? (cnt_max < p.split_resident_waves_per_xcd ? cnt_max : p.split_resident_waves_per_xcd) : 0;
     const int grid = (int)((cnt_max + d_max + 3) / 4) * 8;
-    if (p.norm == EAE_NORM_GDN) hipLaunchKernelGGL((conv_gemm_split_kernel<EAE_NORM_GDN>), dim3(grid), dim3(256), 0, stream, p);
+    if (p.norm == NORM_LATENT) hipLaunchKernelGGL((conv_gemm_split_kernel<NORM_LATENT>), dim3(grid), dim3(256), 0, stream, p);
+    else if (p.norm == NORM_LATENT_PLAIN) hipLaunchKernelGGL((conv_gemm_split_kernel<NORM_LATENT_PLAIN>), dim3(grid), dim3(256), 0, stream, p);
+    else if (p.norm == EAE_NORM_GDN) hipLaunchKernelGGL((conv_gemm_split_kernel<EAE_NORM_GDN>), dim3(grid), dim3(256), 0, stream, p);
     else if (p.norm == EAE_NORM_IGDN) hipLaunchKernelGGL((conv_gemm_split_kernel<EAE_NORM_IGDN>), dim3(grid), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((conv_gemm_split_kernel<EAE_NORM_NONE>), dim3(grid), dim3(256), 0, stream, p);
     EAE_HIP_CHECK_LAUNCH();

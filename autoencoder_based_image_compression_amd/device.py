@@ -288,6 +288,35 @@ def latent_stage(x, bin_widths, map_mean=None, gdn_in=None, igdn_out=None, want_
     return {'y': y, 'shifted': shifted, 't': t, 'symbols': symbols, 'nonzero_flags': flags, 'checks': checks}
 
 
+def conv5x5s2_latent(x, w_packed, bias, bin_widths, map_mean=None, gdn_in=None, igdn_out=None, want_y=False, want_shifted=False,
+                     want_flags=False, out_symbols=None, out_flags=None, out_checks=None, workspace=None):
+    """conv_3 + bias followed by `latent_stage` in one launch (include/eae_hip.h: eae_hip_conv5x5s2_latent): x is the gdn_2
+    output [N,h,w,128]; returns latent_stage's dict ('t' for the fixed-bin-width model, 'shifted' for the learned one is the
+    synthesis transform's input). Same bits as conv5x5s2(..., NORM_NONE) + latent_stage."""
+    (n, h, wd, c) = x.shape
+    d = x.device
+    hw = (h//2)*(wd//2)
+    fixed = gdn_in is not None
+    if fixed != (igdn_out is not None):
+        raise ValueError('`gdn_in` and `igdn_out` go together (the fixed-bin-width model has both, the learned one neither).')
+    shape = (n, h//2, wd//2, c)
+    y = torch.empty(shape, dtype=torch.float32, device=d) if want_y else None
+    shifted = torch.empty(shape, dtype=torch.float32, device=d) if (want_shifted or not fixed) else None
+    t = torch.empty(shape, dtype=torch.float32, device=d) if fixed else None
+    symbols = out_symbols if out_symbols is not None else torch.empty((n, c, hw), dtype=torch.int16, device=d)
+    flags = (out_flags if out_flags is not None else torch.zeros((n, c), dtype=torch.int32, device=d)) if want_flags else None
+    checks = out_checks if out_checks is not None else torch.zeros(3, dtype=torch.int32, device=d)
+    (g_in, b_in) = gdn_in if fixed else (None, None)
+    (g_out, b_out) = igdn_out if fixed else (None, None)
+    if workspace is None:
+        workspace = conv_workspace(d)
+    _check(_native.hip().eae_hip_conv5x5s2_latent(_p(x), _p(w_packed), _p(bias), _p(g_in), _p(b_in), _p(map_mean), _p(bin_widths), _p(g_out),
+                                                  _p(b_out), _p(y), _p(shifted), _p(t), _p(symbols), _p(flags), _p(checks), n, h, wd,
+                                                  _p(workspace) if workspace is not False else None, _stream(x)),
+           'eae_hip_conv5x5s2_latent')
+    return {'y': y, 'shifted': shifted, 't': t, 'symbols': symbols, 'nonzero_flags': flags, 'checks': checks}
+
+
 def map_means(y):
     """float32 per-map means over every other axis of y [..., C]: `numpy.mean(y, axis=(0, 1, 2))` of lossless/stats.py:306 bit
     for bit (float32 accumulator per map, rows ascending, then / float32(rows))."""

@@ -57,6 +57,9 @@ def parse_args(argv=None):
                              'events around a launch time that kernel alone (the roofline figures). 2-3: consecutive batches '
                              'alternate between private streams and their kernels overlap (fills the tails: +6-8 %% whole-job '
                              'throughput with --coder-streams 3), but a launch then shares the GPU and its duration says little')
+    parser.add_argument('--fuse-latent', action='store_true',
+                        help='the latent stage as the epilogue of the conv_3 launch (codec.BatchCodec(fuse_latent=True)); the roofline '
+                             'figure then counts gdn_3 and inverse_gdn_4 in that launch')
     parser.add_argument('--graphs', action='store_true',
                         help='replay one captured hipGraph per step instead of launching kernel by kernel (small batches: the '
                              'launch thread is the bottleneck there). No per-launch events, so no roofline figures')
@@ -229,7 +232,7 @@ def run_pipeline(ctx, batch, steps, warmup, variables, coder='device', coder_str
     with codec.BatchCodec(variables, False, bin_widths, map_mean_host, probabilities, IDX_MAP_EXCEPTION, batch, H_IN, W_IN,
                           device=device, nb_in_flight=coder_streams, launch_hook=timed_launch if record_gemm else None,
                           coder=coder_mode, host_coder_threads=coder_threads, nb_transform_streams=transform_streams,
-                          use_graphs=use_graphs, time_coder=coder_events) as the_codec:
+                          use_graphs=use_graphs, time_coder=coder_events, fuse_latent=args.fuse_latent) as the_codec:
         for _ in range(warmup):
             the_codec.submit(images)
         the_codec.drain()
@@ -364,7 +367,9 @@ def main(args):
     value = pixels_per_step*args.steps*world/elapsed/1e6
     nb_images_total = stats[3].item()
     (bpp, mean_psnr) = rate_and_psnr(stats)
-    flops = {'conv2_gdn2': pipeline.FLOP_PER_PIXEL['conv2_gdn2'], 'conv3': 2*1600,      # gdn_3 runs in the latent-stage kernel
+    flops = {'conv2_gdn2': pipeline.FLOP_PER_PIXEL['conv2_gdn2'],
+             # gdn_3 (and inverse_gdn_4) run in the latent-stage kernel unless that stage is the conv_3 launch's epilogue
+             'conv3': 2*1600 + (pipeline.FLOP_PER_PIXEL['conv3_gdn3'] - 2*1600 + pipeline.FLOP_PER_PIXEL['igdn4'] if args.fuse_latent else 0),
              'tconv1_igdn5': pipeline.FLOP_PER_PIXEL['tconv1_igdn5'], 'tconv2_igdn6': pipeline.FLOP_PER_PIXEL['tconv2_igdn6']}
     per_launch_ms = {}
     for (a, b, name) in gemm_events:

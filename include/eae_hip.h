@@ -191,6 +191,19 @@ int eae_hip_latent_stage(const float* x, const float* gamma_in_packed, const flo
                          float* shifted_out, float* t_out, int16_t* symbols_planar, uint32_t* nonzero_flags, uint32_t* checks,
                          int n, int hw, void* stream);
 
+/* conv_3 + bias_add with the latent stage behind it in one launch: the convolution's register tile goes straight through
+ * gdn_3 -> quantiser -> inverse_gdn_4 (eae_hip_latent_stage's arithmetic, same bits) instead of through HBM and a second
+ * kernel -- what `codec.BatchCodec` launches between conv_2 and transpose_conv_1. x: gdn_2 output [N][h][w][128]; w_packed /
+ * bias: conv_3; gamma_in/beta_in (gdn_3) and gamma_out/beta_out (inverse_gdn_4): both pairs (fixed-bin-width model) or
+ * neither (learned: the quantiser only); outputs as eae_hip_latent_stage ([N][h/2 * w/2][128] f32, planar int16 symbols,
+ * flags and checks zeroed by the caller); t_out (fixed) / shifted_out (learned) is required: it is the synthesis transform's
+ * input. workspace: as eae_hip_conv5x5s2_ws (nullable: then the launch is never cut). Layers too small for the fused kernel
+ * run as the convolution followed by eae_hip_latent_stage in place. */
+int eae_hip_conv5x5s2_latent(const float* x, const float* w_packed, const float* bias, const float* gamma_in_packed,
+                             const float* beta_in, const float* map_mean, const float* bin_widths, const float* gamma_out_packed,
+                             const float* beta_out, float* y_out, float* shifted_out, float* t_out, int16_t* symbols_planar,
+                             uint32_t* nonzero_flags, uint32_t* checks, int n, int h, int w_in, void* workspace, void* stream);
+
 /* The map means of lossless/stats.py:306, `numpy.mean(y_float32, axis=(0, 1, 2))`, bit for bit: means[c] = (the float32
  * sum of y[row][c] accumulated row by row, rows ascending) / float32(rows) -- the order numpy reduces the leading axes of a
  * C-contiguous float32 array in (tests/test_host_logic.py pins that order against numpy itself). y: [rows][c] f32. */

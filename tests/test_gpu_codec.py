@@ -154,3 +154,29 @@ def test_batch_codec_graph_replay_equals_the_launch_by_launch_path(learned):
     graphed.close()
     with pytest.raises(ValueError):
         codec.BatchCodec(v, learned, bin_widths, map_mean, probabilities, 67, 2, 64, 96, coder='host', use_graphs=True)
+
+
+@pytest.mark.parametrize('learned', [False, True])
+@pytest.mark.parametrize('shape', [(3, 64, 96), (24, 128, 192)])
+def test_fused_latent_stage_gives_the_same_results(learned, shape):
+    """`fuse_latent`: the latent stage as the epilogue of the conv_3 launch (small batch: two launches inside the entry point;
+    24 x 128x192: the fused conv_3 entry point on a mid-size batch) against the default codec."""
+    from autoencoder_based_image_compression_amd import codec
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    with numpy.load(GOLD) as g:
+        probabilities = g['real_probabilities_1']
+    rng = numpy.random.RandomState(29)
+    v = var.random_variables(1., learned, seed=8, bias_std=0.01)
+    v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
+    images = torch.from_numpy(rng.randint(16, 236, size=shape).astype(numpy.uint8)).cuda()
+    bin_widths = rng.uniform(0.6, 1.4, size=128).astype(numpy.float32)
+    map_mean = rng.normal(scale=0.05, size=128).astype(numpy.float32)
+    results = []
+    for fuse in (False, True):
+        with codec.BatchCodec(v, learned, bin_widths, map_mean, probabilities, 67, shape[0], shape[1], shape[2], keep_reconstruction=True,
+                              fuse_latent=fuse) as c:
+            t = c.submit(images)
+            results.append((t.result(), t.reconstruction_uint8.cpu().numpy()))
+    for key in ('nb_bits', 'coder_bits', 'exception_bits', 'sse', 'nb_deads'):
+        assert numpy.array_equal(results[0][0][key], results[1][0][key]), key
+    assert numpy.array_equal(results[0][1], results[1][1])

@@ -58,3 +58,42 @@ def test_latent_stage_argument_checks():
     # gamma without beta
     assert lib.eae_hip_latent_stage(x.data_ptr(), bw.data_ptr(), None, None, bw.data_ptr(), None, None, None, None, None, None, None, None,
                                     1, 4, None) == -1
+
+
+@pytest.mark.parametrize('learned', [False, True])
+@pytest.mark.parametrize('shape,form', [((2, 16, 24), ''), ((1, 6, 10), ''), ((2, 16, 24), 'u'), ((2, 16, 24), 's'), ((1, 6, 10), 's'),
+                                        ((6, 128, 192), ''), ((6, 128, 192), 'u'), ((24, 64, 96), '')])
+def test_conv3_with_the_latent_stage_as_its_epilogue(shape, form, learned, monkeypatch):
+    """eae_hip_conv5x5s2_latent == eae_hip_conv5x5s2 (no normalisation) followed by eae_hip_latent_stage, every output, bit for
+    bit: small layers (two launches inside the entry point), the fused kernel with whole tiles ('u'), with every tile cut
+    ('s') and as the launch decides ('' : 6 x 128x192 = 1152 tiles is cut, 24 x 64x96 = Kodak batch)."""
+    from autoencoder_based_image_compression_amd import device as dev
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    for name in ('EAE_HIP_GEMM', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_FORCE_TILE', 'EAE_HIP_FORCE_NT', 'EAE_HIP_LATENT_LDS'):
+        monkeypatch.delenv(name, raising=False)
+    v = var.random_variables(1., learned, seed=61, bias_std=0.01)
+    rng = numpy.random.RandomState(62 + shape[1])
+    x = torch.from_numpy(rng.standard_normal(size=shape + (128,)).astype(numpy.float32)).cuda()
+    w3 = dev.pack_conv_weights(torch.from_numpy(v['encoder/weights_3']).cuda())
+    b3 = torch.from_numpy(v['encoder/biases_3']).cuda()
+    bw = torch.from_numpy(rng.uniform(0.05, 0.5, size=128).astype(numpy.float32)).cuda()
+    mean = torch.from_numpy(rng.normal(scale=0.05, size=128).astype(numpy.float32)).cuda()
+    gdn_in = igdn_out = None
+    if not learned:
+        gdn_in = (dev.pack_gamma(torch.from_numpy(v['encoder/gamma_3']).cuda()), torch.from_numpy(v['encoder/beta_3']).cuda())
+        igdn_out = (dev.pack_gamma(torch.from_numpy(v['decoder/gamma_4']).cuda()), torch.from_numpy(v['decoder/beta_4']).cuda())
+    # the two separate launches (the convolution in its one-tile-per-wave form)
+    monkeypatch.setenv('EAE_HIP_GEMM', 'w')
+    raw = dev.conv5x5s2(x, w3, b3, dev.NORM_NONE, workspace=False)
+    monkeypatch.delenv('EAE_HIP_GEMM')
+    ref = dev.latent_stage(raw, bw, mean, gdn_in=gdn_in, igdn_out=igdn_out, want_y=True, want_shifted=True, want_flags=True)
+    if form:
+        monkeypatch.setenv('EAE_HIP_GEMM', form)
+    ws = dev.conv_workspace('cuda')
+    for _ in range(2):
+        got = dev.conv5x5s2_latent(x, w3, b3, bw, mean, gdn_in=gdn_in, igdn_out=igdn_out, want_y=True, want_shifted=True, want_flags=True,
+                                   workspace=ws)
+        for key in ('y', 'shifted', 'symbols', 'nonzero_flags', 'checks') + (() if learned else ('t',)):
+            assert torch.equal(got[key].reshape(ref[key].shape), ref[key]), key
+        assert int(torch.count_nonzero(ws).item()) == 0
+    assert int(ref['symbols'].abs().max().item()) > 2            # the quantiser is exercised, not a field of zeros

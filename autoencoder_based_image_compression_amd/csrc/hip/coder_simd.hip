@@ -72,6 +72,7 @@ struct SimdParams {
     int32_t* stage;
     uint8_t* decisions;                   // [group][j / 8][lane][8]
     uint32_t* ndec;                       // [n_maps]
+    int32_t* perm;                        // decode, sorted form: [0..3] header (short blocks, long blocks), then 64 maps per block
 };
 
 __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t& total) {
@@ -282,11 +283,14 @@ __global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // (3) 64 maps per wavefront: decode, streams staged in LDS
 // ---------------------------------------------------------------------------------------------------------------------
-template <uint32_t WB, uint32_t WY, bool SECOND>
-__global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
-    __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
+// MODE 0 / 1: first / second pass over the maps in their own order (maps 64 b .. 64 b + 63 in block b). MODE 2: ONE launch
+// over the maps sorted by sort_maps_kernel into blocks of short maps (streams fit the windows) and blocks of long ones: a block
+// is either all first-pass or all second-pass work, so no map is walked twice and no wavefront runs both loops. At the rates
+// of trained models (~1 bit per pixel) most maps are long and nearly every group of 64 held both kinds: the two passes then
+// cost two full serial decodes (1.94 ms per Kodak batch at 0.9 bpp against 0.57 ms at 0.19 bpp).
+template <uint32_t WB, uint32_t WY, int MODE, bool SECOND>
+__device__ __forceinline__ void bac_decode_body(const SimdParams& p, const uint32_t m) {
     const uint32_t lane = threadIdx.x;
-    const uint32_t m = blockIdx.x * 64u + lane;
     const bool in_range = m < p.n_maps;
     const int32_t row = in_range ? (p.prob_row ? p.prob_row[m] : (int32_t)m) : -1;
     const uint32_t L = p.L;
@@ -301,8 +305,8 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
     // CU's LDS waits for a CU to drain, 0.2 ms next to the transforms even when it has nothing to do): only the RETRY maps,
     // and a lane whose stream is longer than the window fetches the words beyond it from memory itself, one load per word
     // (the wave waits for that load: slower, but exact and unbounded).
-    bool live = in_range && row >= 0 && p.status[m] == (SECOND ? RETRY : 0);
-    if (SECOND && !__any(live)) return;                  // nothing was handed on to this pass in this group of 64 maps
+    bool live = in_range && row >= 0 && p.status[m] == (MODE == 1 ? RETRY : 0);
+    if (MODE == 1 && !__any(live)) return;                  // nothing was handed on to this pass in this group of 64 maps
     const uint32_t nbac = live ? p.bac_bits[m] : 0u;
     const uint32_t nbyp = live ? p.bypass_bits[m] : 0u;
     const uint32_t* gbac = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)(in_range ? m : 0u) * p.stride);
@@ -320,8 +324,8 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
     }
     // stage the streams of the 64 maps: the wave copies one map per iteration, coalesced
     for (uint32_t l = 0; l < 64u; l++) {
-        const uint32_t ml = blockIdx.x * 64u + l;
-        if (ml >= p.n_maps) break;
+        const uint32_t ml = __shfl(m, l, 64);
+        if (ml >= p.n_maps) { if (MODE == 2) continue; else break; }
         const uint32_t bits_b = __shfl(nbac, l, 64), bits_y = __shfl(nbyp, l, 64);
         const uint32_t* src = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)ml * p.stride);
         for (uint32_t w = lane; w < WB && w * 32u < bits_b; w += 64u) wbac[w * 64u + l] = src[w];
@@ -377,14 +381,21 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
     // bit): none of their latencies sits in the decision -> decision dependency chain.
     const double p0 = active ? probs[lane] : 0.5;
     double pk = p0;
-    uint32_t gw = 0, gw_row = 0xFFFFFFFFu, gy = 0, gy_row = 0xFFFFFFFFu;        // the words held from beyond the windows
+    uint32_t gw = 0, gw_ahead = 0, gw_row = 0xFFFFFFF0u, gy = 0, gy_row = 0xFFFFFFFFu;   // the words held from beyond the windows
     // (macros, not lambdas: with the held words captured by reference the compiler kept them in scratch memory and turned
     // the LDS read into a flat load selecting between LDS and scratch, waited for in every step)
 #define EAE_WINDOW_WORD(dst_)                                                                                         \
     {                                                                                                                 \
         dst_ = wbac[(!SECOND || rword < WB + 2u ? rword : WB + 2u) * 64u + lane];                                     \
         if (SECOND && rword >= WB) {                                                                                  \
-            if (rword != gw_row) { gw = rword * 32u < nbac ? gbac[rword] : 0u; gw_row = rword; }                      \
+            /* beyond the window: the word comes from memory. The word after it is requested at the same time and has */  \
+            /* the ~30 steps it takes to use up 32 bits to arrive (a load per word on demand stalled the wave for a   */  \
+            /* memory round trip every time any of its 64 lanes crossed a word boundary)                              */  \
+            if (rword != gw_row) {                                                                                    \
+                gw = rword == gw_row + 1u ? gw_ahead : (rword * 32u < nbac ? gbac[rword] : 0u);                       \
+                gw_row = rword;                                                                                       \
+                gw_ahead = (rword + 1u) * 32u < nbac ? gbac[rword + 1u] : 0u;                                         \
+            }                                                                                                         \
             dst_ = gw;                                                                                                \
         }                                                                                                             \
     }
@@ -498,6 +509,93 @@ __global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
 #undef EAE_BYPASS_WORD
 }
 
+template <uint32_t WB, uint32_t WY, int MODE>
+__global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
+    __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
+    const uint32_t lane = threadIdx.x;
+    if (MODE == 2) {
+        const uint32_t short_blocks = (uint32_t)p.perm[0], long_blocks = (uint32_t)p.perm[1];
+        if (blockIdx.x >= short_blocks + long_blocks) return;
+        const uint32_t m = (uint32_t)p.perm[4u + blockIdx.x * 64u + lane];          // 0xFFFFFFFF pads the last block of a kind
+        // two copies of the loop, each with its windows' bounds known at compile time (a block-uniform flag inside ONE copy
+        // cost the short maps 18 %: three more compares and branches in a step of ~105 instructions)
+        if (blockIdx.x >= short_blocks) bac_decode_body<WB, WY, MODE, true>(p, m);
+        else bac_decode_body<WB, WY, MODE, false>(p, m);
+    } else {
+        bac_decode_body<WB, WY, MODE, MODE == 1>(p, blockIdx.x * 64u + lane);
+    }
+}
+
+// Sorts the maps of a launch into blocks of 64 for bac_decode_kernel<.., 2>: first the maps whose streams fit the windows of
+// WB / WY words (and the ones there is nothing to decode for: skipped, failed), in their own order, padded to a multiple of 64
+// with 0xFFFFFFFF; then the long ones, padded likewise. perm[0] / perm[1] = number of blocks of each kind. One block of 1024
+// threads walks the maps in chunks (a few thousand maps: microseconds).
+__global__ __launch_bounds__(1024) void sort_maps_kernel(const SimdParams p, uint32_t wb_bits, uint32_t wy_bits) {
+    __shared__ uint32_t wave_sums[2][16];
+    __shared__ uint32_t base[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    int32_t* slots = p.perm + 4;
+    // pass A: how many long maps there are, i.e. where the long blocks start
+    uint32_t n_long = 0;
+    for (uint32_t m = tid; m < p.n_maps; m += 1024u) {
+        const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
+        if (row >= 0 && p.status[m] == 0 && (p.bac_bits[m] > wb_bits || p.bypass_bits[m] > wy_bits)) n_long++;
+    }
+    for (int off = 32; off > 0; off >>= 1) n_long += __shfl_down(n_long, off, 64);
+    if (lane == 0) wave_sums[0][wave] = n_long;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t total_long = 0;
+        for (int w = 0; w < 16; w++) total_long += wave_sums[0][w];
+        const uint32_t total_short = p.n_maps - total_long;
+        const uint32_t short_blocks = (total_short + 63u) / 64u, long_blocks = (total_long + 63u) / 64u;
+        p.perm[0] = (int32_t)short_blocks; p.perm[1] = (int32_t)long_blocks; p.perm[2] = (int32_t)total_short; p.perm[3] = (int32_t)total_long;
+        base[0] = 0u;
+        base[1] = short_blocks * 64u;
+    }
+    __syncthreads();
+    const uint32_t total_short = (uint32_t)p.perm[2], total_long = (uint32_t)p.perm[3];
+    const uint32_t short_end = ((total_short + 63u) / 64u) * 64u, long_start = short_end, long_end = long_start + ((total_long + 63u) / 64u) * 64u;
+    // padding slots
+    for (uint32_t i = total_short + tid; i < short_end; i += 1024u) slots[i] = -1;
+    for (uint32_t i = long_start + total_long + tid; i < long_end; i += 1024u) slots[i] = -1;
+    // pass B: stable placement, chunk by chunk (exclusive scans over the 1024 threads of a chunk)
+    for (uint32_t m0 = 0; m0 < p.n_maps; m0 += 1024u) {
+        const uint32_t m = m0 + tid;
+        uint32_t is_long = 0, is_short = 0;
+        if (m < p.n_maps) {
+            const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
+            is_long = (row >= 0 && p.status[m] == 0 && (p.bac_bits[m] > wb_bits || p.bypass_bits[m] > wy_bits)) ? 1u : 0u;
+            is_short = 1u - is_long;
+        }
+        // exclusive scans inside the wavefront (wave_exclusive_scan indexes by threadIdx.x: written for 64-thread blocks)
+        uint32_t inc_s = is_short, inc_l = is_long;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t us = __shfl_up(inc_s, d, 64), ul = __shfl_up(inc_l, d, 64);
+            if ((int)lane >= d) { inc_s += us; inc_l += ul; }
+        }
+        const uint32_t tot_s = __shfl(inc_s, 63, 64), tot_l = __shfl(inc_l, 63, 64);
+        const uint32_t off_s = inc_s - is_short, off_l = inc_l - is_long;
+        if (lane == 0) { wave_sums[0][wave] = tot_s; wave_sums[1][wave] = tot_l; }
+        __syncthreads();
+        uint32_t before_s = 0, before_l = 0;
+        for (uint32_t w = 0; w < wave; w++) { before_s += wave_sums[0][w]; before_l += wave_sums[1][w]; }
+        if (m < p.n_maps) {
+            if (is_long) slots[base[1] + before_l + off_l] = (int32_t)m;
+            else slots[base[0] + before_s + off_s] = (int32_t)m;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t cs = 0, cl = 0;
+            for (int w = 0; w < 16; w++) { cs += wave_sums[0][w]; cl += wave_sums[1][w]; }
+            base[0] += cs;
+            base[1] += cl;
+        }
+        __syncthreads();
+    }
+}
+
 // (4) decoded == encoded, one wavefront per map
 __global__ __launch_bounds__(64) void compare_kernel(const SimdParams p) {
     const uint32_t m = blockIdx.x, lane = threadIdx.x;
@@ -531,7 +629,8 @@ uint64_t eae_hip_coder_workspace_bytes(uint32_t n_maps, uint32_t map_size, uint8
     const uint64_t groups = ((uint64_t)n_maps + 63u) / 64u;
     const uint64_t decisions = fast_applies(L) ? groups * 64u * decision_capacity(map_size, L) : 0u;
     const uint64_t decoded = (uint64_t)n_maps * map_size * sizeof(int16_t);
-    return 256u + round256((uint64_t)n_maps * sizeof(uint32_t)) + round256(decisions > decoded ? decisions : decoded);
+    return 256u + round256((uint64_t)n_maps * sizeof(uint32_t)) + round256(decisions > decoded ? decisions : decoded) +
+           round256(((uint64_t)n_maps + 128u + 4u) * sizeof(int32_t));        // + the decoder's sorted map order
 }
 
 static SimdParams make_params(uint32_t n_maps, uint32_t map_size, uint8_t L, const int16_t* symbols, const double* probs,
@@ -546,6 +645,10 @@ static SimdParams make_params(uint32_t n_maps, uint32_t map_size, uint8_t L, con
         p.ndec = reinterpret_cast<uint32_t*>(ws);
         p.decisions = ws + round256((uint64_t)n_maps * sizeof(uint32_t));
         p.decoded = reinterpret_cast<int16_t*>(p.decisions);
+        const uint64_t groups = ((uint64_t)n_maps + 63u) / 64u;
+        const uint64_t decisions = fast_applies(L) ? groups * 64u * decision_capacity(map_size, L) : 0u;
+        const uint64_t decoded = (uint64_t)n_maps * map_size * sizeof(int16_t);
+        p.perm = reinterpret_cast<int32_t*>(p.decisions + round256(decisions > decoded ? decisions : decoded));
     }
     return p;
 }
@@ -594,24 +697,41 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
     if (!expected) (void)hipMemsetAsync(status, 0, (size_t)n_maps * sizeof(int32_t), s);   // a pure decode starts from a clean slate
     if (fast_applies(L) && map_size) {
         const dim3 grid((n_maps + 63u) / 64u);
+        // with a workspace (large enough for the sorted map order): ONE launch over blocks of short maps and blocks of long
+        // maps; without: first pass over every group of 64, second pass over the maps the first one found too long
+        const bool sorted = workspace && workspace_bytes >= eae_hip_coder_workspace_bytes(n_maps, map_size, L);
+        const dim3 sorted_grid((n_maps + 63u) / 64u + 1u);
         if (map_size > kMediumMapSize) {
             const size_t lds = decode_lds_bytes(L, kBacWindowWordsMedium, kBypassWindowWordsMedium);
             static const hipError_t medium_ok = [] {
-                hipError_t e = hipFuncSetAttribute(
-                    reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, false>),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-                if (e != hipSuccess) return e;
-                return hipFuncSetAttribute(
-                    reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, true>),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                hipError_t e = hipSuccess;
+                const void* kernels[3] = {
+                    reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, 0>),
+                    reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, 1>),
+                    reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, 2>)};
+                for (const void* k : kernels) {
+                    e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                    if (e != hipSuccess) return e;
+                }
+                return e;
             }();
             if (medium_ok != hipSuccess) return (int)medium_ok;
-            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, false>), grid, dim3(64), lds, s, p);
-            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, true>), grid, dim3(64), lds, s, p);
+            if (sorted) {
+                hipLaunchKernelGGL(sort_maps_kernel, dim3(1), dim3(1024), 0, s, p, kBacWindowWordsMedium * 32u, kBypassWindowWordsMedium * 32u);
+                hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, 2>), sorted_grid, dim3(64), lds, s, p);
+            } else {
+                hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, 0>), grid, dim3(64), lds, s, p);
+                hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, 1>), grid, dim3(64), lds, s, p);
+            }
         } else {
             const size_t lds = decode_lds_bytes(L, kBacWindowWords, kBypassWindowWords);
-            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, false>), grid, dim3(64), lds, s, p);
-            hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, true>), grid, dim3(64), lds, s, p);
+            if (sorted) {
+                hipLaunchKernelGGL(sort_maps_kernel, dim3(1), dim3(1024), 0, s, p, kBacWindowWords * 32u, kBypassWindowWords * 32u);
+                hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, 2>), sorted_grid, dim3(64), lds, s, p);
+            } else {
+                hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, 0>), grid, dim3(64), lds, s, p);
+                hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, 1>), grid, dim3(64), lds, s, p);
+            }
         }
         // whatever a map reported that only the general kernel can name (errors of any kind)
         const int rc = eae_coder_generic_decode(n_maps, map_size, p.decoded, L, probs, prob_row, streams, stride, bac_bits,

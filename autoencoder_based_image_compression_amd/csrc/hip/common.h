@@ -101,10 +101,10 @@ __device__ __forceinline__ void swap_halves(float& a, float& b) {
     b = __uint_as_float(r[1]);
 }
 
-template <int NORM>
+// RING: gamma k-pairs (16 bytes per lane each) in flight ahead of the MFMAs that use them
+template <int NORM, int RING = 8>
 __device__ __forceinline__ void wave_epilogue(f32x16 (&acc)[4], const float* vec_lds, bool has_bias,
                                               const float* __restrict__ gamma_packed, float* o, bool valid, int lane) {
-    constexpr int RING = 8;
     const int hi = lane >> 5, lj = lane & 31;
     const int cbase = 4 * hi;                 // channel of (t, g, q) = 32 t + 8 g + cbase + q
     o += cbase;

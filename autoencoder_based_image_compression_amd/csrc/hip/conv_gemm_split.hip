@@ -39,10 +39,17 @@ using namespace eae_conv_gemm;
 namespace {
 
 constexpr int RING = 8;
+#ifndef EAE_EPI_RING
+#define EAE_EPI_RING 4
+#endif
+constexpr int EPI_RING = EAE_EPI_RING;   // gamma ring of the epilogue (see the register budget at the kernel)
 constexpr int ABUF = 32 * AS_STRIDE;                 // one activation buffer of one wave
-// per wave: two activation buffers + the per-channel vectors of the epilogue: bias | beta, or, with the latent stage behind
-// conv_3, bias | beta_in | beta_out | map_mean | bin_widths
-constexpr int wave_lds(int norm) { return 2 * ABUF + (norm >= NORM_LATENT ? 5 : 2) * EAE_C; }
+// LDS of a block: two activation buffers per wave + ONE copy of the per-channel vectors of the epilogue (bias | beta, or, with
+// the latent stage behind conv_3, bias | beta_in | beta_out | map_mean | bin_widths). Every wave writes the whole copy itself
+// (identical values: a benign race, no barrier), so three blocks take 3 x 37.9 KB and leave room for two of the coder's
+// decoder blocks (20 KB each) on the same CU: with a copy per wave (3 x 41 KB) a CU that drew two of them ran one GEMM block
+// short for the length of a decode.
+constexpr int vec_floats(int norm) { return (norm >= NORM_LATENT ? 5 : 2) * EAE_C; }
 constexpr int QT_H = 4, QT_W = 8;                    // a wave's tile: 4 x 8 positions
 constexpr int MIN_PIECE = 4;                         // K-steps: no head or tail shorter than this
 constexpr int SPIN_LIMIT = 1 << 22;                  // ~1 s of polling: a bug, not a wait; sets the error word
@@ -55,14 +62,15 @@ __device__ __forceinline__ int head_steps(int d, int D, int T) {
 // Three waves per SIMD (<= 168 registers) for the plain epilogues; the latent-stage epilogue (two normalisations and the
 // quantiser on the register tile) needs ~190 and gets two: conv_3 has a quarter of conv_2's tiles, at Kodak batch sizes its
 // SIMDs hold one or two waves anyway.
+// Blocks of four waves, each wave on its own (the block is only the unit of dispatch; one-wave blocks measured 1-10 % slower
+// alone and no better next to the coder).
 template <int NORM>
 __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_split_kernel(const ConvGemmParams p) {
-    constexpr int WAVE_LDS = wave_lds(NORM);
-    __shared__ __attribute__((aligned(16))) float lds[4 * WAVE_LDS];
+    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * ABUF + vec_floats(NORM)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* wlds = lds + wave * WAVE_LDS;
-    float* vec_lds = wlds + 2 * ABUF;
+    float* wlds = lds + wave * 2 * ABUF;
+    float* vec_lds = lds + 4 * 2 * ABUF;
     {
         const float2 z = make_float2(0.f, 0.f);
         *reinterpret_cast<float2*>(vec_lds + 2 * lane) = p.bias ? *reinterpret_cast<const float2*>(p.bias + 2 * lane) : z;
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
                 wave_latent_body<NORM == NORM_LATENT, NORM == NORM_LATENT>(acc, vec_lds + EAE_C, p.gamma, p.gamma_out, p.latent, valid,
                                                                            (long)img, pr * p.wp + pc, p.hp * p.wp, lane);
             } else {
-                wave_epilogue<NORM>(acc, vec_lds, p.bias != nullptr, p.gamma, o, valid, lane);
+                wave_epilogue<NORM, EPI_RING>(acc, vec_lds, p.bias != nullptr, p.gamma, o, valid, lane);
             }
         } else {
             // a head: park the accumulators in the tile's own output pixels, write-through, and publish them
@@ -332,11 +340,13 @@ int eae_conv_gemm::launch_split(ConvGemmParams& p, hipStream_t stream, int cut) 
     const long cnt_max = (nsp + 7) / 8 * p.n_phases;
     const long d_max = split ? (cnt_max < p.split_resident_waves_per_xcd ? cnt_max : p.split_resident_waves_per_xcd) : 0;
     const int grid = (int)((cnt_max + d_max + 3) / 4) * 8;
-    if (p.norm == NORM_LATENT) hipLaunchKernelGGL((conv_gemm_split_kernel<NORM_LATENT>), dim3(grid), dim3(256), 0, stream, p);
-    else if (p.norm == NORM_LATENT_PLAIN) hipLaunchKernelGGL((conv_gemm_split_kernel<NORM_LATENT_PLAIN>), dim3(grid), dim3(256), 0, stream, p);
-    else if (p.norm == EAE_NORM_GDN) hipLaunchKernelGGL((conv_gemm_split_kernel<EAE_NORM_GDN>), dim3(grid), dim3(256), 0, stream, p);
-    else if (p.norm == EAE_NORM_IGDN) hipLaunchKernelGGL((conv_gemm_split_kernel<EAE_NORM_IGDN>), dim3(grid), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((conv_gemm_split_kernel<EAE_NORM_NONE>), dim3(grid), dim3(256), 0, stream, p);
+#define EAE_LAUNCH_S(N_) hipLaunchKernelGGL((conv_gemm_split_kernel<N_>), dim3(grid), dim3(256), 0, stream, p)
+    if (p.norm == NORM_LATENT) EAE_LAUNCH_S(NORM_LATENT);
+    else if (p.norm == NORM_LATENT_PLAIN) EAE_LAUNCH_S(NORM_LATENT_PLAIN);
+    else if (p.norm == EAE_NORM_GDN) EAE_LAUNCH_S(EAE_NORM_GDN);
+    else if (p.norm == EAE_NORM_IGDN) EAE_LAUNCH_S(EAE_NORM_IGDN);
+    else EAE_LAUNCH_S(EAE_NORM_NONE);
+#undef EAE_LAUNCH_S
     EAE_HIP_CHECK_LAUNCH();
     return EAE_HIP_OK;
 }

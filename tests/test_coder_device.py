@@ -242,6 +242,11 @@ def test_batch_encoder_and_decoder_equal_the_host_coder(gold, dev, scale):
     keep = prob_row >= 0
     assert not streams.status.cpu().numpy().any()
     assert numpy.array_equal(out[keep], planar[keep]) and not out[~keep].any()
+    # the same decode with a workspace: maps sorted into short and long, one launch instead of two passes
+    ws = dev.coder_workspace(n, 96, probs.shape[1], 'cuda')
+    out = dev.coder_decode_batch(streams, p, rows, workspace=ws).cpu().numpy()
+    assert not streams.status.cpu().numpy().any()
+    assert numpy.array_equal(out[keep], planar[keep]) and not out[~keep].any()
     dev.coder_decode_batch(streams, p, rows, expected=sym)
     assert not streams.status.cpu().numpy().any()
     # a flipped bit in one arithmetic-coded stream is found by the comparison, and only there
@@ -279,6 +284,9 @@ def test_batch_large_maps_long_pending_runs_and_every_window_tier(gold, dev):
     assert (bits < 64*32).any() and ((bits > 64*32) & (bits <= 192*32)).any() and ((bits > 192*32) & (bits <= 448*32)).any() \
         and (bits > 448*32).any(), bits
     out = dev.coder_decode_batch(streams, p, r).cpu().numpy()
+    assert not streams.status.cpu().numpy().any()
+    assert numpy.array_equal(out, planar)
+    out = dev.coder_decode_batch(streams, p, r, workspace=dev.coder_workspace(n, size, L, 'cuda')).cpu().numpy()     # sorted form
     assert not streams.status.cpu().numpy().any()
     assert numpy.array_equal(out, planar)
     dev.coder_decode_batch(streams, p, r, expected=sym)
@@ -335,6 +343,10 @@ def test_batch_fuzz_against_host_coder_including_errors(gold, dev):
         out = dev.coder_decode_batch(streams, p, r).cpu().numpy()     # pure decode rewrites every status
         good = ok & (rows >= 0)
         assert numpy.array_equal(out[good], planar[good]), t
+        two_pass_status = streams.status.clone()
+        out = dev.coder_decode_batch(streams, p, r, workspace=dev.coder_workspace(n_maps, size, L, 'cuda')).cpu().numpy()   # sorted form
+        assert numpy.array_equal(out[good], planar[good]), t
+        assert torch.equal(streams.status, two_pass_status) and torch.equal(streams.stage[streams.status != 0], streams.stage[two_pass_status != 0]), t
     assert {0, 1, 4} <= seen
 
 

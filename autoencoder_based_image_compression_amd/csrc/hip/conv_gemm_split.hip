@@ -322,8 +322,14 @@ int eae_conv_gemm::launch_split(ConvGemmParams& p, hipStream_t stream, int cut) 
         // the hand-offs. Only the convolutions: the tiles of the transposed ones are short (16-36 K-steps against 100), their
         // last round costs little and cutting them was measured to lose (Kodak batch 24, bursts: transpose_conv_1 0.286 ms
         // uncut, 0.295-0.310 cut; _2 1.009 / 1.014-1.031; conv_2 0.995 / 0.917; conv_3 0.382 / 0.249).
+        // Also when the tile count is a whole number of rounds, from three tiles per SIMD on: alone on the GPU a launch of
+        // exactly 9 tiles per SIMD runs 0.6 % faster uncut (conv_2 of 48 images: 1.778 against 1.788 ms), but next to the coder's
+        // long-lived waves some SIMDs fall behind and an uncut launch then waits for a whole tile on them (0.77 of peak in the
+        // pipeline against 0.90 alone; cut: 0.83); the short items at the end of a cut launch absorb that. With exactly two
+        // tiles per SIMD (conv_2 of 64 images of 256x256) every tile would be cut and the tails would be dispatched while
+        // their heads still run: measured slower there (0.50 against 0.44 ms in the pipeline), so such launches stay whole.
         const long rounds = (tiles + simds - 1) / simds;
-        split = (double)rounds * simds > 1.03 * (double)tiles;
+        split = (double)rounds * simds > 1.03 * (double)tiles || tiles >= 3 * simds;
     }
     if (split && !p.split_ws) return EAE_HIP_BAD_ARGUMENT;
     if (p.norm >= NORM_LATENT && k > 2) k = 2;       // that instance holds two waves per SIMD

@@ -30,6 +30,8 @@ def _load(name):
     path = os.path.join(LIB_DIR, name)
     if name == 'libeae_coder.so' and os.environ.get('EAE_CODER_LIB'):
         path = os.environ['EAE_CODER_LIB']      # e.g. the sanitizer build (`make -C csrc sanitize-test`); same ABI, same checks
+    if name == 'libeae_hip.so' and os.environ.get('EAE_HIP_LIB'):
+        path = os.environ['EAE_HIP_LIB']        # an instrumented build of the same ABI (scratch/t3_trace.sh)
     if not os.path.isfile(path):
         raise NativeLibraryMissing(
             '{0} not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` '

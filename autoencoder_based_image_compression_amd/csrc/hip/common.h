@@ -30,6 +30,19 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 __device__ __forceinline__ int acc_row32(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// Compute units of the current device (cached per device; 0 when the runtime cannot tell).
+inline int eae_compute_units() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (cached[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cached[dev] = prop.multiProcessorCount;
+    }
+    return cached[dev];
+}
+
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous chunk of the logical grid so that
 // neighbouring tiles (shared input halos, same image) hit the same L2. Bijective for any grid size. Speed only.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {

@@ -289,22 +289,10 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
     }
 }
 
-int compute_units() {
-    static int cached[16] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
-    if (cached[dev] == 0) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        cached[dev] = prop.multiProcessorCount;
-    }
-    return cached[dev];
-}
-
 }  // namespace
 
 int eae_conv_gemm::launch_split(ConvGemmParams& p, hipStream_t stream, int cut) {
-    const int cus = compute_units();
+    const int cus = eae_compute_units();
     if (cus < 8 || (cus & 7)) return 1;
     p.tiles_r = (p.hp + QT_H - 1) / QT_H;
     p.tiles_c = (p.wp + QT_W - 1) / QT_W;

@@ -22,7 +22,7 @@
 namespace {
 constexpr int TH = 4, TW = 16;
 #ifndef EAE_T3_PASSES
-#define EAE_T3_PASSES 2
+#define EAE_T3_PASSES 4
 #endif
 constexpr int PASSES = EAE_T3_PASSES;         // the input patch is staged PASSES times, 128 / PASSES channels at a time
 constexpr int HALF_C = EAE_C / PASSES;

@@ -157,6 +157,188 @@ __global__ __launch_bounds__(64) void latent_wave_kernel(const float* __restrict
     const LatentOut o{y_out, shifted_out, t_out, symbols, nonzero, checks};
     wave_latent_body<GDN_IN, IGDN_OUT>(v, vec, gamma_in, gamma_out, o, valid, img, pix, hw, lane);
 }
+
+// ---- four wavefronts per 32 positions, one 32-channel tile each (the default) ------------------------------------------------
+// The register-resident form above puts 1,152 wavefronts on 1,024 SIMDs at Kodak batch 24: most SIMDs hold ONE wave whose
+// ~60,000 cycles are a quarter MFMA and the rest vector work (64 sqrt, 192 divisions, 64 double-precision checks per lane)
+// with nothing to overlap it, and an eighth of them hold two. Here a block of four waves shares the tile: every wave keeps
+// all 128 channels of the 32 positions in registers as the B operand (exchanged once through LDS, lane-private slots) but
+// accumulates, normalises, quantises and stores only its own 32 channels. 4.5 waves per SIMD, each a quarter as long: the
+// MFMAs of one overlap the vector work of the others. Same FMA chain per element, same statements: same bits.
+template <int RING>
+__device__ __forceinline__ f32x16 quarter_denominator(const f32x16 (&x)[4], const float* __restrict__ gamma_packed, int w, int lane) {
+    const int hi = lane >> 5, lj = lane & 31;
+    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(gamma_packed), 0, (int)(EAE_C * EAE_C * sizeof(float)), 0x00020000);
+    const int g_lane = (hi * EAE_C + lj * 4 + w) * 4;      // packed row k = 2 kk + hi, column 4 lj + w = channel 32 w + lj
+    f32x16 d;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] = 0.f;
+    float ring[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) ring[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(g_rsrc, g_lane + i * 2 * EAE_C * 4, 0, 0));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float s0 = x[t][4 * g + 0], s1 = x[t][4 * g + 1], s2 = x[t][4 * g + 2], s3 = x[t][4 * g + 3];
+            swap_halves(s0, s1);     // as wave_gdn_inplace: k pairs in ascending order
+            swap_halves(s2, s3);
+            const float xs[4] = {s0, s2, s1, s3};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = 16 * t + 4 * g + e;            // k = 2 kk + hi
+                d = mfma32(ring[kk % RING], xs[e] * xs[e], d);
+                if (kk + RING < EAE_C / 2)
+                    ring[kk % RING] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(g_rsrc, g_lane + (kk + RING) * 2 * EAE_C * 4, 0, 0));
+            }
+        }
+    }
+    return d;
+}
+
+template <bool GDN_IN, bool IGDN_OUT>
+__global__ __launch_bounds__(256) void latent_quarter_kernel(const float* __restrict__ x, const float* __restrict__ gamma_in,
+                                                             const float* __restrict__ beta_in, const float* __restrict__ map_mean,
+                                                             const float* __restrict__ bin_widths, const float* __restrict__ gamma_out,
+                                                             const float* __restrict__ beta_out, float* __restrict__ y_out,
+                                                             float* __restrict__ shifted_out, float* __restrict__ t_out,
+                                                             int16_t* __restrict__ symbols, unsigned int* __restrict__ nonzero,
+                                                             unsigned int* __restrict__ checks, long rows, int hw) {
+    __shared__ __attribute__((aligned(16))) float vec[4 * EAE_C];          // beta_in | beta_out | map_mean | bin_widths
+    __shared__ __attribute__((aligned(16))) float xch[4 * 4 * 64 * 4];     // [channel tile][g][lane][4]: the exchange, 16 KB
+    __shared__ unsigned int tally[4][3];
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, lj = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < EAE_C) {
+        vec[tid] = GDN_IN ? beta_in[tid] : 0.f;
+        vec[EAE_C + tid] = IGDN_OUT ? beta_out[tid] : 0.f;
+        vec[2 * EAE_C + tid] = map_mean ? map_mean[tid] : 0.f;
+        vec[3 * EAE_C + tid] = bin_widths[tid];
+    }
+    const long row = (long)blockIdx.x * 32 + lj;
+    const bool valid = row < rows;
+    const long img = row / hw;
+    const int pix = (int)(row - img * hw);
+    const int cw = 32 * w + 4 * hi;                          // this lane's channels: cw + 8 g + q
+    const size_t obase = (size_t)(valid ? row : 0) * EAE_C + cw;
+    f32x16 own;                                              // [4 g + q]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 q = valid ? *reinterpret_cast<const float4*>(x + obase + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        own[4 * g + 0] = q.x; own[4 * g + 1] = q.y; own[4 * g + 2] = q.z; own[4 * g + 3] = q.w;
+    }
+    float4* slot = reinterpret_cast<float4*>(xch) + lane;    // + (16 t + 4 g... ) * 64: [t][g][lane]
+    f32x16 full[4];
+#define EAE_Q_EXCHANGE()                                                                                                 \
+    {                                                                                                                    \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                                    \
+            slot[(4 * w + g) * 64] = make_float4(own[4 * g], own[4 * g + 1], own[4 * g + 2], own[4 * g + 3]);            \
+        __syncthreads();                                                                                                 \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                    \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                              \
+                const float4 q = slot[(4 * t + g) * 64];                                                                 \
+                full[t][4 * g + 0] = q.x; full[t][4 * g + 1] = q.y; full[t][4 * g + 2] = q.z; full[t][4 * g + 3] = q.w;  \
+            }                                                                                                            \
+    }
+    if (GDN_IN) {
+        EAE_Q_EXCHANGE()
+        const f32x16 d = quarter_denominator<8>(full, gamma_in, w, lane);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bt = *reinterpret_cast<const float4*>(vec + cw + 8 * g);
+            own[4 * g + 0] = gdn_apply(own[4 * g + 0], d[4 * g + 0], bt.x, false);
+            own[4 * g + 1] = gdn_apply(own[4 * g + 1], d[4 * g + 1], bt.y, false);
+            own[4 * g + 2] = gdn_apply(own[4 * g + 2], d[4 * g + 2], bt.z, false);
+            own[4 * g + 3] = gdn_apply(own[4 * g + 3], d[4 * g + 3], bt.w, false);
+        }
+    } else {
+        __syncthreads();                                     // vec
+    }
+    // the quantiser on this wave's 32 channels (quantize.hip, statement for statement). Planar symbols: the lanes of a
+    // half-wave write neighbouring pixels of one map; offsets are relative to the tile's first image so that 32 bits do
+    const long img0 = ((long)blockIdx.x * 32) / hw;
+    const bool one_image = __all(!valid || img == img0) != 0;
+    const __amdgpu_buffer_rsrc_t sym_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        symbols ? symbols + (size_t)img0 * EAE_C * hw : nullptr, 0, symbols ? 0x7FFFFFFF : 0, 0x00020000);
+    const int sym_lane = valid ? (int)((((img - img0) * EAE_C + 4 * hi) * hw + pix) * 2) : -1;     // bytes; -1: no store
+    unsigned int bad = 0, not_quantized = 0, altered = 0, flag_bits = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 m4 = *reinterpret_cast<const float4*>(vec + 2 * EAE_C + cw + 8 * g);
+        const float4 b4 = *reinterpret_cast<const float4*>(vec + 3 * EAE_C + cw + 8 * g);
+        const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, bw[4] = {b4.x, b4.y, b4.z, b4.w};
+        float sh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float yv = own[4 * g + q];
+            const float centered = yv - mm[q];
+            const float rr = round_half_even(centered / bw[q]);
+            const float cq = bw[q] * rr;
+            const float rs = round_half_even(cq / bw[q]);
+            sh[q] = cq + mm[q];
+            if (valid) {
+                if (!(fabsf(rs) < 32768.f)) bad++;
+                if (!(fabs((double)cq - (double)centered) < 1.5e-10)) not_quantized++;
+                if (!((float)(int16_t)(int)rs * bw[q] == centered)) altered++;
+            }
+            const bool nz = valid && cq != 0.f;
+            if (nonzero) {
+                if (one_image) {
+                    // one bit per channel of this tile: a half-wave's 32 positions share the channel
+                    const unsigned long long any = __ballot(nz);
+                    if ((unsigned int)any) flag_bits |= 1u << (8 * g + q);
+                    if ((unsigned int)(any >> 32)) flag_bits |= 1u << (8 * g + 4 + q);
+                } else if (nz) {
+                    nonzero[img * EAE_C + cw + 8 * g + q] = 1u;                      // benign race: every writer stores 1
+                }
+            }
+            if (symbols)
+                __builtin_amdgcn_raw_buffer_store_b16((short)(int16_t)(int)rs, sym_rsrc, sym_lane, (32 * w + 8 * g + q) * hw * 2, 0);
+        }
+        if (valid && y_out)
+            *reinterpret_cast<float4*>(y_out + obase + 8 * g) = make_float4(own[4 * g], own[4 * g + 1], own[4 * g + 2], own[4 * g + 3]);
+        if (valid && shifted_out) *reinterpret_cast<float4*>(shifted_out + obase + 8 * g) = make_float4(sh[0], sh[1], sh[2], sh[3]);
+        own[4 * g + 0] = sh[0]; own[4 * g + 1] = sh[1]; own[4 * g + 2] = sh[2]; own[4 * g + 3] = sh[3];
+    }
+    if (nonzero && one_image && lane < 32 && ((flag_bits >> lane) & 1u)) nonzero[img0 * EAE_C + 32 * w + lane] = 1u;
+#ifndef EAE_LATENT_NOCHECKS
+    if (checks) {
+        // one atomic per block and counter: all 4,608 waves adding to the same three words would queue behind each other in L2
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            bad += __shfl_down(bad, off, 64);
+            not_quantized += __shfl_down(not_quantized, off, 64);
+            altered += __shfl_down(altered, off, 64);
+        }
+        if (lane == 0) { tally[w][0] = bad; tally[w][1] = not_quantized; tally[w][2] = altered; }
+    }
+#endif
+    if (IGDN_OUT) {
+        if (GDN_IN) __syncthreads();                         // every wave has read the first exchange
+        EAE_Q_EXCHANGE()
+        const f32x16 d = quarter_denominator<8>(full, gamma_out, w, lane);
+        if (valid) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 bt = *reinterpret_cast<const float4*>(vec + EAE_C + cw + 8 * g);
+                *reinterpret_cast<float4*>(t_out + obase + 8 * g) =
+                    make_float4(gdn_apply(own[4 * g + 0], d[4 * g + 0], bt.x, true), gdn_apply(own[4 * g + 1], d[4 * g + 1], bt.y, true),
+                                gdn_apply(own[4 * g + 2], d[4 * g + 2], bt.z, true), gdn_apply(own[4 * g + 3], d[4 * g + 3], bt.w, true));
+            }
+        }
+    }
+#ifndef EAE_LATENT_NOCHECKS
+    if (checks) {
+        if (!IGDN_OUT) __syncthreads();                      // (with IGDN_OUT the second exchange's barrier came after the tally)
+        if (tid < 3) {
+            const unsigned int sum = tally[0][tid] + tally[1][tid] + tally[2][tid] + tally[3][tid];
+            if (sum) atomicAdd(&checks[tid], sum);
+        }
+    }
+#endif
+#undef EAE_Q_EXCHANGE
+}
 }  // namespace
 
 extern "C" int eae_hip_latent_stage(const float* x, const float* gamma_in_packed, const float* beta_in, const float* map_mean,
@@ -168,16 +350,27 @@ extern "C" int eae_hip_latent_stage(const float* x, const float* gamma_in_packed
     if ((gamma_out_packed == nullptr) != (beta_out == nullptr) || (gamma_out_packed && !t_out)) return EAE_HIP_BAD_ARGUMENT;
     const long rows = (long)n * hw;
     hipStream_t s = (hipStream_t)stream;
-    const bool lds_form = std::getenv("EAE_HIP_LATENT_LDS") != nullptr;   // the block-cooperative form (read per launch: the parity tests run both)
-    if (!lds_form) {
+    // EAE_HIP_LATENT = q (four waves per tile, the default) | w (one wave per tile) | l (block-cooperative LDS form); read per
+    // launch: the parity tests run all three. EAE_HIP_LATENT_LDS (round 1) still selects the LDS form.
+    const char* form_env = std::getenv("EAE_HIP_LATENT");
+    char form = form_env && (form_env[0] == 'w' || form_env[0] == 'l' || form_env[0] == 'q') ? form_env[0] : 'q';
+    if (std::getenv("EAE_HIP_LATENT_LDS") != nullptr) form = 'l';
+    if (form == 'q' && hw > (1 << 21)) form = 'w';          // 32-bit symbol offsets inside two images
+    if (form != 'l') {
         const unsigned wgrid = (unsigned)((rows + 31) / 32);
 #define EAE_LATENT_W(A_, B_)                                                                                              \
-        hipLaunchKernelGGL((latent_wave_kernel<A_, B_>), dim3(wgrid), dim3(64), 0, s, x, gamma_in_packed, beta_in, map_mean,  \
-                           bin_widths, gamma_out_packed, beta_out, y_out, shifted_out, t_out, symbols_planar, nonzero_flags, checks, rows, hw)
-        if (gamma_in_packed && gamma_out_packed) EAE_LATENT_W(true, true);
-        else if (gamma_in_packed) EAE_LATENT_W(true, false);
-        else if (gamma_out_packed) EAE_LATENT_W(false, true);
-        else EAE_LATENT_W(false, false);
+        {                                                                                                                \
+            if (form == 'q')                                                                                             \
+                hipLaunchKernelGGL((latent_quarter_kernel<A_, B_>), dim3(wgrid), dim3(256), 0, s, x, gamma_in_packed, beta_in, map_mean,  \
+                                   bin_widths, gamma_out_packed, beta_out, y_out, shifted_out, t_out, symbols_planar, nonzero_flags, checks, rows, hw); \
+            else                                                                                                         \
+                hipLaunchKernelGGL((latent_wave_kernel<A_, B_>), dim3(wgrid), dim3(64), 0, s, x, gamma_in_packed, beta_in, map_mean,  \
+                                   bin_widths, gamma_out_packed, beta_out, y_out, shifted_out, t_out, symbols_planar, nonzero_flags, checks, rows, hw); \
+        }
+        if (gamma_in_packed && gamma_out_packed) EAE_LATENT_W(true, true)
+        else if (gamma_in_packed) EAE_LATENT_W(true, false)
+        else if (gamma_out_packed) EAE_LATENT_W(false, true)
+        else EAE_LATENT_W(false, false)
 #undef EAE_LATENT_W
         EAE_HIP_CHECK_LAUNCH();
         return EAE_HIP_OK;

@@ -8,6 +8,11 @@
 #ifndef EAE_LATENT_RING
 #define EAE_LATENT_RING 8
 #endif
+#ifdef EAE_LATENT_TRACE               // scratch/variant.sh: clock ticks per phase, summed behind the three data checks
+#define LAT_MARK(i_) { const long long t_ = clock64(); if (o.checks && lane == 0) atomicAdd(&o.checks[16 + (i_)], (unsigned int)((t_ - lat_last) >> 4)); lat_last = t_; }
+#else
+#define LAT_MARK(i_)
+#endif
 
 // The layout is the one the conv GEMM epilogue uses (common.h wave_epilogue): lane (hi = lane >> 5, lj = lane & 31) holds, for
 // position lj, the 64 channels 32 t + 8 g + 4 hi + q in x[t][4 g + q]. x^2 goes from those registers straight into the MFMA
@@ -87,7 +92,11 @@ __device__ __forceinline__ void wave_latent_body(f32x16 (&v)[4], const float* ve
                                                  const float* __restrict__ gamma_out, const LatentOut& o, bool valid, long img,
                                                  int pix, int hw, int lane) {
     const int hi = lane >> 5;
+#ifdef EAE_LATENT_TRACE
+    long long lat_last = clock64();
+#endif
     if (GDN_IN) wave_gdn_inplace<false>(v, vec, gamma_in, lane);
+    LAT_MARK(0)
     unsigned int bad = 0, not_quantized = 0, altered = 0;
     const size_t obase = ((size_t)(valid ? img : 0) * hw + (valid ? pix : 0)) * EAE_C + 4 * hi;
 #pragma unroll
@@ -123,6 +132,7 @@ __device__ __forceinline__ void wave_latent_body(f32x16 (&v)[4], const float* ve
             if (valid && o.shifted_out) *reinterpret_cast<float4*>(o.shifted_out + obase + 32 * t + 8 * g) = make_float4(sh[0], sh[1], sh[2], sh[3]);
             v[t][4 * g + 0] = sh[0]; v[t][4 * g + 1] = sh[1]; v[t][4 * g + 2] = sh[2]; v[t][4 * g + 3] = sh[3];
         }
+    LAT_MARK(1)
     if (o.checks) {
         if (bad) atomicAdd(&o.checks[0], bad);
         if (not_quantized) atomicAdd(&o.checks[1], not_quantized);
@@ -130,6 +140,7 @@ __device__ __forceinline__ void wave_latent_body(f32x16 (&v)[4], const float* ve
     }
     if (IGDN_OUT) {
         wave_gdn_inplace<true>(v, vec + EAE_C, gamma_out, lane);
+        LAT_MARK(2)
         if (valid) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -138,5 +149,6 @@ __device__ __forceinline__ void wave_latent_body(f32x16 (&v)[4], const float* ve
                     *reinterpret_cast<float4*>(o.t_out + obase + 32 * t + 8 * g) =
                         make_float4(v[t][4 * g], v[t][4 * g + 1], v[t][4 * g + 2], v[t][4 * g + 3]);
         }
+        LAT_MARK(3)
     }
 }

@@ -7,16 +7,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('shape', [(2, 32, 48), (3, 5, 7), (1, 1, 1), (5, 16, 16)])
+@pytest.mark.parametrize('shape', [(2, 32, 48), (3, 5, 7), (1, 1, 1), (5, 16, 16), (40, 1, 2)])
 @pytest.mark.parametrize('learned', [False, True])
-@pytest.mark.parametrize('form', ['wave', 'lds'])
+@pytest.mark.parametrize('form', ['quarter', 'wave', 'lds'])
 def test_latent_stage_equals_the_separate_kernels(shape, learned, form, monkeypatch):
-    """form: the register-resident wave kernel (default) and the block-cooperative LDS kernel (EAE_HIP_LATENT_LDS)."""
+    """form (EAE_HIP_LATENT, csrc/hip/latent.hip): four waves per 32-position tile, one 32-channel tile each (the default);
+    one register-resident wave per tile; the block-cooperative LDS kernel. (3, 5, 7): tiles that straddle images."""
     from autoencoder_based_image_compression_amd import device as dev
-    if form == 'lds':
-        monkeypatch.setenv('EAE_HIP_LATENT_LDS', '1')
-    else:
-        monkeypatch.delenv('EAE_HIP_LATENT_LDS', raising=False)
+    monkeypatch.delenv('EAE_HIP_LATENT_LDS', raising=False)
+    monkeypatch.setenv('EAE_HIP_LATENT', form[0])
     rng = numpy.random.RandomState(shape[1]*7 + int(learned))
     (n, h, w) = shape
     x = torch.from_numpy((rng.laplace(size=(n, h, w, 128))*rng.uniform(0.1, 6., size=128)).astype(numpy.float32)).cuda()
@@ -69,7 +68,7 @@ def test_conv3_with_the_latent_stage_as_its_epilogue(shape, form, learned, monke
     ('s') and as the launch decides ('' : 6 x 128x192 = 1152 tiles is cut, 24 x 64x96 = Kodak batch)."""
     from autoencoder_based_image_compression_amd import device as dev
     from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
-    for name in ('EAE_HIP_GEMM', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_FORCE_TILE', 'EAE_HIP_FORCE_NT', 'EAE_HIP_LATENT_LDS'):
+    for name in ('EAE_HIP_GEMM', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_FORCE_TILE', 'EAE_HIP_FORCE_NT', 'EAE_HIP_LATENT_LDS', 'EAE_HIP_LATENT'):
         monkeypatch.delenv(name, raising=False)
     v = var.random_variables(1., learned, seed=61, bias_std=0.01)
     rng = numpy.random.RandomState(62 + shape[1])

@@ -162,11 +162,14 @@ __global__ __launch_bounds__(64) void latent_wave_kernel(const float* __restrict
 // The register-resident form above puts 1,152 wavefronts on 1,024 SIMDs at Kodak batch 24: most SIMDs hold ONE wave whose
 // ~60,000 cycles are a quarter MFMA and the rest vector work (64 sqrt, 192 divisions, 64 double-precision checks per lane)
 // with nothing to overlap it, and an eighth of them hold two. Here a block of four waves shares the tile: every wave keeps
-// all 128 channels of the 32 positions in registers as the B operand (exchanged once through LDS, lane-private slots) but
+// the squares of all 128 channels of the 32 positions in registers as the B operand (each wave squares and orders its own 32
+// channels, then they exchange through LDS, lane-private slots) but
 // accumulates, normalises, quantises and stores only its own 32 channels. 4.5 waves per SIMD, each a quarter as long: the
 // MFMAs of one overlap the vector work of the others. Same FMA chain per element, same statements: same bits.
+// x2[t][4 g + e]: the B operand of K-step kk = 16 t + 4 g + e, i.e. the squares of the tile in the order and lane placement the
+// MFMA wants them (squares_for_mfma below), all 128 channels; the wave accumulates its own channel tile w.
 template <int RING>
-__device__ __forceinline__ f32x16 quarter_denominator(const f32x16 (&x)[4], const float* __restrict__ gamma_packed, int w, int lane) {
+__device__ __forceinline__ f32x16 quarter_denominator(const f32x16 (&x2)[4], const float* __restrict__ gamma_packed, int w, int lane) {
     const int hi = lane >> 5, lj = lane & 31;
     const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(gamma_packed), 0, (int)(EAE_C * EAE_C * sizeof(float)), 0x00020000);
@@ -176,25 +179,28 @@ __device__ __forceinline__ f32x16 quarter_denominator(const f32x16 (&x)[4], cons
     for (int r = 0; r < 16; ++r) d[r] = 0.f;
     float ring[RING];
 #pragma unroll
-    for (int i = 0; i < RING; ++i) ring[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(g_rsrc, g_lane + i * 2 * EAE_C * 4, 0, 0));
+    for (int i = 0; i < RING; ++i) ring[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(g_rsrc, g_lane, i * 2 * EAE_C * 4, 0));
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float s0 = x[t][4 * g + 0], s1 = x[t][4 * g + 1], s2 = x[t][4 * g + 2], s3 = x[t][4 * g + 3];
-            swap_halves(s0, s1);     // as wave_gdn_inplace: k pairs in ascending order
-            swap_halves(s2, s3);
-            const float xs[4] = {s0, s2, s1, s3};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int kk = 16 * t + 4 * g + e;            // k = 2 kk + hi
-                d = mfma32(ring[kk % RING], xs[e] * xs[e], d);
-                if (kk + RING < EAE_C / 2)
-                    ring[kk % RING] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(g_rsrc, g_lane + (kk + RING) * 2 * EAE_C * 4, 0, 0));
-            }
-        }
+    for (int kk = 0; kk < EAE_C / 2; ++kk) {                // k = 2 kk + hi
+        d = mfma32(ring[kk % RING], x2[kk >> 4][kk & 15], d);
+        if (kk + RING < EAE_C / 2)
+            ring[kk % RING] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(g_rsrc, g_lane, (kk + RING) * 2 * EAE_C * 4, 0));
     }
     return d;
+}
+
+// One channel tile (16 registers: channel 8 g + 4 hi + q in [4 g + q]) -> its squares as MFMA B operands: [4 g + e] feeds K-step
+// 4 g + e of the tile, k pairs ascending (the swaps of wave_gdn_inplace, done once by the tile's owner instead of by every reader)
+__device__ __forceinline__ f32x16 squares_for_mfma(const f32x16& v) {
+    f32x16 r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float s0 = v[4 * g + 0], s1 = v[4 * g + 1], s2 = v[4 * g + 2], s3 = v[4 * g + 3];
+        swap_halves(s0, s1);     // s0 = channels (8g+0 | 8g+1), s1 = (8g+4 | 8g+5) in the (low | high) half-waves
+        swap_halves(s2, s3);     // s2 = (8g+2 | 8g+3), s3 = (8g+6 | 8g+7)
+        r[4 * g + 0] = s0 * s0; r[4 * g + 1] = s2 * s2; r[4 * g + 2] = s1 * s1; r[4 * g + 3] = s3 * s3;
+    }
+    return r;
 }
 
 template <bool GDN_IN, bool IGDN_OUT>
@@ -232,8 +238,9 @@ __global__ __launch_bounds__(256) void latent_quarter_kernel(const float* __rest
     f32x16 full[4];
 #define EAE_Q_EXCHANGE()                                                                                                 \
     {                                                                                                                    \
+        const f32x16 sq = squares_for_mfma(own);                                                                         \
         _Pragma("unroll") for (int g = 0; g < 4; ++g)                                                                    \
-            slot[(4 * w + g) * 64] = make_float4(own[4 * g], own[4 * g + 1], own[4 * g + 2], own[4 * g + 3]);            \
+            slot[(4 * w + g) * 64] = make_float4(sq[4 * g], sq[4 * g + 1], sq[4 * g + 2], sq[4 * g + 3]);                \
         __syncthreads();                                                                                                 \
         _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                    \
             _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                              \

@@ -30,6 +30,22 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 __device__ __forceinline__ int acc_row32(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// Phase timestamps for experiments (scratch/variant.sh builds ONE kernel file with -DEAE_TRACE and reads them back through
+// eae_hip_trace_read): mark i of wave w = clock64() at that point, in eae_trace_buf[8 w + i]. Not part of the product build.
+#ifdef EAE_TRACE
+static __device__ long long eae_trace_buf[65536 * 8];
+#define EAE_TRACE_MARK(i_)                                                                                           \
+    {                                                                                                                \
+        const unsigned int wid_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                               \
+        if ((threadIdx.x & 63) == 0 && wid_ < 65536u) eae_trace_buf[(size_t)wid_ * 8 + (i_)] = clock64();            \
+    }
+extern "C" int eae_hip_trace_read(long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(eae_trace_buf), (size_t)n * sizeof(long long));
+}
+#else
+#define EAE_TRACE_MARK(i_)
+#endif
+
 // Compute units of the current device (cached per device; 0 when the runtime cannot tell).
 inline int eae_compute_units() {
     static int cached[16] = {0};
@@ -184,6 +200,7 @@ __device__ __forceinline__ void wave_epilogue(f32x16 (&acc)[4], const float* vec
             }
         }
 #undef EAE_G_LOAD
+        EAE_TRACE_MARK(3)
         constexpr bool inverse = NORM == EAE_NORM_IGDN;
 #pragma unroll
         for (int t = 0; t < 4; ++t)

@@ -4,8 +4,8 @@
 //
 // One block = 8 x 16 output positions; each of its 4 waves owns 2 tile rows = 32 positions x 128 channels and, after one
 // barrier for the shared input patch, runs on its own (same structure as the conv GEMM wave kernel):
-//   * the uint8 patch (37 x 69 pixels) is converted to f32 and staged in LDS split by column phase (col mod 4), so the
-//     32 positions of a wave read consecutive words (conflict-free);
+//   * the uint8 patch (37 rows x 69 columns, read as 18 aligned 32-bit words per row) is converted to f32 and staged in LDS
+//     split by column phase (col mod 4), so the 32 positions of a wave read consecutive words (conflict-free);
 //   * the product is transposed (weights = MFMA A operand): w1 rows (packed channel order, 82 rows, the last one zero)
 //     stream from L1/L2 through a register ring of 16-byte loads, K = 81 taps in (kernel row, kernel column) order;
 //   * bias, GDN (x^2 from accumulator registers, gamma through the ring) and 16-byte stores: common.h wave_epilogue.
@@ -16,7 +16,6 @@ namespace {
 constexpr int TH = 8, TW = 16;
 constexpr int K9 = 9, S4 = 4, KTAPS = 81, KPAD = 82;
 constexpr int PR = TH * S4 + K9 - S4;    // 37 patch rows
-constexpr int PCOLS = TW * S4 + K9 - S4; // 69 patch columns
 constexpr int PW = 20;                   // words per (phase, row): 18 used; 4*PW = 80 = 16 (mod 32) -> two rows, 32 banks
 constexpr int PATCH_FLOATS = 4 * PR * PW;                 // 2960
 constexpr int RING = 8;
@@ -31,24 +30,56 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const uint8_t* __restrict
     float* vec_lds = lds + PATCH_FLOATS; // bias[128], beta[128]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    EAE_TRACE_MARK(0)
+#ifdef EAE_C1_STAGGER
+    {   // experiment: the three blocks a CU holds at first start a third of a tile apart
+        const int cls = ((int)blockIdx.x / EAE_C1_STAGGER_CUS) % 3;
+        if ((int)blockIdx.x < 3 * EAE_C1_STAGGER_CUS)
+            for (int i = 0; i < cls * EAE_C1_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     int b = xcd_remap(blockIdx.x, gridDim.x);
     const int tc = b % tiles_c; b /= tiles_c;
     const int tr = b % tiles_r;
     const int img = b / tiles_r;
     const uint8_t* x_img = x + (size_t)img * h * win;
     const int r0 = tr * TH * S4 - 2, c0 = tc * TW * S4 - 2;   // SAME: pad_before = 2 (appendix A.2)
-    for (int i = tid; i < PR * PCOLS; i += 256) {
-        const int pr = i / PCOLS, pc = i % PCOLS;
-        const int r = r0 + pr, c = c0 + pc;
-        float v = 0.f;
-        if (r >= 0 && r < h && c >= 0 && c < win) v = (float)x_img[(size_t)r * win + c];
-        patch[((pc & 3) * PR + pr) * PW + (pc >> 2)] = v;
+    // The patch as aligned 32-bit words: columns c0 - 2 + 4 D ... + 3 for D = 0..17 (c0 = 64 tc - 2, so the words are aligned
+    // and -- the width being a multiple of 4 -- each lies entirely inside or outside the image). 37 x 18 words, at most three per
+    // thread, all in flight together (one byte per load in a loop with its bounds check cost ten memory latencies per tile:
+    // 33,000 of a wave's 107,000 cycles). Byte b of word D is patch column 4 D + b - 2: phase (b + 2) & 3, word D - 1 or D.
+    constexpr int DW = 18, NDW = (PR * DW + 255) / 256;
+    unsigned int pw[NDW];
+#pragma unroll
+    for (int j = 0; j < NDW; ++j) {
+        const int i = tid + 256 * j;
+        const int pr = i / DW, dq = i % DW;
+        const int r = r0 + pr, c = c0 - 2 + 4 * dq;
+        const bool ok = i < PR * DW && r >= 0 && r < h && c >= 0 && c < win;
+        const unsigned int* src = reinterpret_cast<const unsigned int*>(x_img + (size_t)(ok ? r : 0) * win + (ok ? c : 0));
+        const unsigned int t = *src;
+        pw[j] = ok ? t : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < NDW; ++j) {
+        const int i = tid + 256 * j;
+        const int pr = i / DW, dq = i % DW;
+        if (i < PR * DW) {
+            float* row = patch + pr * PW + dq;
+            if (dq > 0) {
+                row[2 * PR * PW - 1] = (float)(pw[j] & 0xFFu);             // phase 2, word D - 1
+                row[3 * PR * PW - 1] = (float)((pw[j] >> 8) & 0xFFu);      // phase 3, word D - 1
+            }
+            row[0] = (float)((pw[j] >> 16) & 0xFFu);                       // phase 0, word D
+            row[PR * PW] = (float)(pw[j] >> 24);                           // phase 1, word D
+        }
     }
     if (tid < EAE_C) {
         vec_lds[tid] = bias ? bias[tid] : 0.f;
         vec_lds[EAE_C + tid] = NORM != EAE_NORM_NONE ? beta[tid] : 0.f;
     }
     __syncthreads();
+    EAE_TRACE_MARK(1)
 
     const int hi = lane >> 5, lj = lane & 31;
     const int lr = 2 * wave + (lj >> 4), lc = lj & 15;        // this lane's position inside the tile
@@ -86,10 +117,12 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const uint8_t* __restrict
         acc[3] = mfma32(wq.w, a, acc[3]);
         if (kk + RING < KPAD / 2) { EAE_C1_LOAD(ring[kk % RING], kk + RING) }
     }
+    EAE_TRACE_MARK(2)
     const int pr = tr * TH + lr, pc = tc * TW + lc;
     const bool valid = pr < ho && pc < wo;
     float* o = out + (((size_t)img * ho + pr) * wo + pc) * EAE_C;
     wave_epilogue<NORM>(acc, vec_lds, bias != nullptr, gamma, o, valid, lane);
+    EAE_TRACE_MARK(4)
 }
 
 // TF filter [9][9][1][128] -> [82][128 packed co], row 81 = 0
@@ -113,6 +146,7 @@ extern "C" int eae_hip_conv9x9s4_u8(const uint8_t* x, const float* w_packed, con
     if (!x || !w_packed || !out || n <= 0 || h <= 0 || w_in <= 0) return EAE_HIP_BAD_ARGUMENT;
     if (gamma_packed && !beta) return EAE_HIP_BAD_ARGUMENT;
     if ((h & 3) || (w_in & 3)) return EAE_HIP_BAD_SHAPE;
+    if (reinterpret_cast<uintptr_t>(x) & 3u) return EAE_HIP_BAD_ARGUMENT;      // the kernel reads the image as aligned 32-bit words
     const int ho = h / 4, wo = w_in / 4;
     const int tiles_r = (ho + TH - 1) / TH, tiles_c = (wo + TW - 1) / TW;
     const dim3 grid(n * tiles_r * tiles_c);

@@ -93,7 +93,8 @@ int eae_hip_decode(const eae_hip_model* model, const float* quantized_latents, i
 /* conv_1 + bias_add + gdn_1  (components.py:119-125; tf.nn.conv2d 9x9, 1->128, stride 4, 'SAME' = pad 2/3;
  * tfutils.py:393-397). x: uint8 [N][H][W] (the uint8->float32 cast of batching.py:95 is done in-kernel, no offset,
  * no scale); w_packed: [82][128] from eae_hip_pack_conv9x9s4_weights; out: f32 [N][H/4][W/4][128]. H, W multiples
- * of 4. gamma_packed: from eae_hip_pack_gamma; NULL skips the normalisation (plain conv + bias). */
+ * of 4, x aligned to 4 bytes (the kernel reads whole 32-bit words; EAE_HIP_BAD_ARGUMENT otherwise). gamma_packed: from
+ * eae_hip_pack_gamma; NULL skips the normalisation (plain conv + bias). */
 int eae_hip_conv9x9s4_u8(const uint8_t* x, const float* w_packed, const float* bias, const float* gamma_packed,
                          const float* beta, float* out, int n, int h, int w_in, void* stream);
 

@@ -196,6 +196,9 @@ __device__ __forceinline__ void wave_epilogue(f32x16 (&acc)[4], const float* vec
                     d[2] = mfma32(gq.z, x2, d[2]);
                     d[3] = mfma32(gq.w, x2, d[3]);
                     if (kk + RING < EAE_C / 2) { EAE_G_LOAD(ring[kk % RING], kk + RING) }
+                    // keep this load HERE: left alone, the scheduler sinks every load to one step before its use (a two-deep
+                    // ring whatever RING says), and each K-step then waits for an L2 round trip
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }

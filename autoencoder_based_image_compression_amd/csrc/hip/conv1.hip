@@ -18,7 +18,7 @@ constexpr int K9 = 9, S4 = 4, KTAPS = 81, KPAD = 82;
 constexpr int PR = TH * S4 + K9 - S4;    // 37 patch rows
 constexpr int PW = 20;                   // words per (phase, row): 18 used; 4*PW = 80 = 16 (mod 32) -> two rows, 32 banks
 constexpr int PATCH_FLOATS = 4 * PR * PW;                 // 2960
-constexpr int RING = 8;
+constexpr int RING = 6;                  // weight rows in flight (with 8 the kernel needs 172 registers: two waves per SIMD)
 
 template <int NORM>
 __global__ __launch_bounds__(256, 2) void conv1_kernel(const uint8_t* __restrict__ x, const float* __restrict__ w_packed,
@@ -101,27 +101,37 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const uint8_t* __restrict
 #pragma unroll
     for (int i = 0; i < RING; ++i) EAE_C1_LOAD(ring[i], i)
     const float* prow = patch + (4 * lr) * PW + lc;
+    // the patch value of K-step kk: taps k = 2 kk (low half-wave) and 2 kk + 1 (high); k = 81 does not exist (zero weight row too)
+#define EAE_C1_A(dst_, kk_)                                                                                          \
+    {                                                                                                                \
+        const int k0_ = 2 * (kk_), k1_ = 2 * (kk_) + 1;                                                              \
+        const int u0_ = k0_ / K9, v0_ = k0_ % K9;                                                                    \
+        const int u1_ = k1_ < KTAPS ? k1_ / K9 : 0, v1_ = k1_ < KTAPS ? k1_ % K9 : 0;                                \
+        const int off0_ = ((v0_ & 3) * PR + u0_) * PW + (v0_ >> 2);                                                  \
+        const int off1_ = ((v1_ & 3) * PR + u1_) * PW + (v1_ >> 2);                                                  \
+        dst_ = prow[hi ? off1_ : off0_];                                                                             \
+        if (k1_ >= KTAPS && hi) dst_ = 0.f;                                                                          \
+    }
+    float a_pipe[2];
+    EAE_C1_A(a_pipe[0], 0)
 #pragma unroll
     for (int kk = 0; kk < KPAD / 2; ++kk) {
-        const int k0 = 2 * kk, k1 = 2 * kk + 1;
-        const int u0 = k0 / K9, v0 = k0 % K9;
-        const int u1 = k1 < KTAPS ? k1 / K9 : 0, v1 = k1 < KTAPS ? k1 % K9 : 0;
-        const int off0 = ((v0 & 3) * PR + u0) * PW + (v0 >> 2);
-        const int off1 = ((v1 & 3) * PR + u1) * PW + (v1 >> 2);
-        float a = prow[hi ? off1 : off0];
-        if (k1 >= KTAPS && hi) a = 0.f;                        // k = 81 does not exist (its weight row is zero too)
+        if (kk + 1 < KPAD / 2) EAE_C1_A(a_pipe[(kk + 1) & 1], kk + 1)      // read from LDS a step before its MFMAs
+        const float a = a_pipe[kk & 1];
         const float4 wq = ring[kk % RING];
         acc[0] = mfma32(wq.x, a, acc[0]);                      // A = w1^T[co][k], B = patch^T[k][pos]
         acc[1] = mfma32(wq.y, a, acc[1]);
         acc[2] = mfma32(wq.z, a, acc[2]);
         acc[3] = mfma32(wq.w, a, acc[3]);
         if (kk + RING < KPAD / 2) { EAE_C1_LOAD(ring[kk % RING], kk + RING) }
+        __builtin_amdgcn_sched_barrier(0);                     // the load stays RING steps ahead of its use (see wave_epilogue)
     }
+#undef EAE_C1_A
     EAE_TRACE_MARK(2)
     const int pr = tr * TH + lr, pc = tc * TW + lc;
     const bool valid = pr < ho && pc < wo;
     float* o = out + (((size_t)img * ho + pr) * wo + pc) * EAE_C;
-    wave_epilogue<NORM>(acc, vec_lds, bias != nullptr, gamma, o, valid, lane);
+    wave_epilogue<NORM, RING>(acc, vec_lds, bias != nullptr, gamma, o, valid, lane);
     EAE_TRACE_MARK(4)
 }
 

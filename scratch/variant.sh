@@ -10,7 +10,12 @@ SRC=${SRC:-tconv3}
 D=/tmp/eae_variant
 mkdir -p $D
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Iinclude -I$C/hip"
-/opt/rocm/bin/hipcc $FLAGS $EXTRA -c -o $D/$SRC.o $C/hip/$SRC.hip
-OBJS=$(ls build/hip/*.o | grep -v "/$SRC.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libeae_hip.so $OBJS $D/$SRC.o
+OBJS=$(ls build/hip/*.o)
+NEW=""
+for f in $SRC; do                      # SRC may name several files: the same EXTRA flags go to each
+  /opt/rocm/bin/hipcc $FLAGS $EXTRA -c -o $D/$f.o $C/hip/$f.hip
+  OBJS=$(echo "$OBJS" | grep -v "/$f.o")
+  NEW="$NEW $D/$f.o"
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libeae_hip.so $OBJS $NEW
 EAE_HIP_LIB=$D/libeae_hip.so python scratch/${SCRIPT:-t3_trace.py} "$@"

@@ -60,7 +60,8 @@ int eae_hip_publish_to_host(const void* src_device, void* dst_host_mapped, uint6
  * eae_hip_encode, a decoder-only one (the reference's IsolatedDecoder, IsolatedDecoder.py:21-129) for eae_hip_decode; a side
  * that is given must be complete, else EAE_HIP_BAD_ARGUMENT.
  * eae_hip_model_create uploads and re-lays them out on the current device (7 MB resident) and returns when that is done.
- * eae_hip_encode:  images uint8 [n][h][w] (device) -> latents f32 [n][h/16][w/16][128] (device). h, w multiples of 16.
+ * eae_hip_encode:  images uint8 [n][h][w] (device, 4-byte aligned) -> latents f32 [n][h/16][w/16][128] (device). h, w
+ *                  multiples of 16.
  * eae_hip_decode:  quantised latents f32 [n][h_latent][w_latent][128] (after the de-centring of
  *   reconstructing_eae_kodak.py:192) -> out_f32 [n][16 h_latent][16 w_latent] (nullable: the float reconstruction),
  *   out_u8 (nullable: its BT.601 cast), and with ref_u8 + sse the squared error per image as in eae_hip_tconv9x9s4_luma.

@@ -83,6 +83,24 @@ FORMS = [('wave', '32'), ('wave', '64'), ('wave', '128'), ('lds', '64'), ('lds',
          ('whole', ''), ('cut1', ''), ('cut2', ''), ('cut3', '')]
 
 
+def test_conv1_reads_words(T, dev, orc):
+    """conv_1 reads the luminance as aligned 32-bit words: an image at an odd byte offset is refused (include/eae_hip.h), one
+    at a multiple of 4 inside a larger buffer gives the oracle's bits, and so does a width that leaves the last tile ragged."""
+    from autoencoder_based_image_compression_amd import device
+    v = _vars(1)
+    (wp, b) = (dev.pack_conv9x9s4_weights(_cuda(T, v['encoder/weights_1'])), _cuda(T, v['encoder/biases_1']))
+    x = _image(numpy.random.RandomState(5), 1, 36, 100)
+    ref = orc.conv2d_same(x.astype(numpy.float32)[..., None], v['encoder/weights_1'], 4, v['encoder/biases_1'])
+    raw = T.zeros(x.size + 16, dtype=T.uint8, device='cuda')
+    for offset in (4, 12):
+        view = raw[offset:offset + x.size].view(1, 36, 100)
+        view.copy_(_cuda(T, x))
+        assert numpy.array_equal(dev.conv9x9s4_u8(view, wp, b).cpu().numpy(), ref)
+    odd = raw[1:1 + x.size].view(1, 36, 100)
+    with pytest.raises(device.HipError):
+        dev.conv9x9s4_u8(odd, wp, b)
+
+
 @pytest.mark.parametrize('form,tile', FORMS)
 @pytest.mark.parametrize('shape', [(2, 16, 24), (1, 32, 64), (1, 6, 10), (2, 2, 2), (1, 20, 36)])
 @pytest.mark.parametrize('norm', [0, 1])

@@ -267,23 +267,59 @@ class BatchCodec(object):
     def _submit_graph(self, luminances_uint8):
         """One step = three hipGraph launches: the analysis side (conv1 .. symbols) and the synthesis side on a transform
         stream, the coder on a coder stream between two events, exactly the stream structure of the launch-by-launch path.
-        Slot s owns its buffers (symbols, streams, result blocks), so it owns its three graphs too: captured the first time the
-        slot comes up (after one ordinary step that gets every lazy initialisation out of the way), replayed afterwards."""
+        Slot s owns its buffers (symbols, streams, result blocks), so it owns its three graphs too: all captured at the first
+        call (after one ordinary step that gets every lazy initialisation out of the way: `_capture_all`), replayed afterwards."""
         if not self._warm:
             self._warm = True
             self._submit(luminances_uint8).result()          # first launches: function attributes, lazy module loads
+            self._capture_all(luminances_uint8)
         slot = self._index % self.nb_slots
         stream = self._transform_streams[self._index % len(self._transform_streams)]
         coder_stream = self._streams[self._index % len(self._streams)]
         self._index += 1
         self._slot_free[slot].wait()
         self._slot_free[slot].clear()
-        caller = torch.cuda.current_stream()
-        if self._graphs[slot] is None:
-            static_input = torch.empty_like(luminances_uint8)
-            caller.synchronize()
+        try:
+            caller = torch.cuda.current_stream()
+            (graphs, static_input, _, reconstruction) = self._graphs[slot]
+            stream.wait_stream(caller)
+            with torch.cuda.stream(stream):
+                static_input.copy_(luminances_uint8, non_blocking=True)
+                graphs[0].replay()
+                quantized = torch.cuda.Event()
+                quantized.record()
+            with torch.cuda.stream(coder_stream):
+                coder_stream.wait_event(quantized)
+                graphs[1].replay()
+                coded = torch.cuda.Event()
+                coded.record()
+            with torch.cuda.stream(stream):
+                graphs[2].replay()
+                decoded = torch.cuda.Event()
+                decoded.record()
+            luminances_uint8.record_stream(stream)
+            ticket = Ticket(self.batch_size)
+            if self.keep_reconstruction:
+                ticket.reconstruction_uint8 = reconstruction       # valid until this slot is replayed again
+            self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],), None,
+                                   self._slot_free[slot]))
+            return ticket
+        except BaseException:
+            self._slot_free[slot].set()       # nobody will report on this slot: without this, drain() / close() wait for ever
+            raise
+
+    def _capture_all(self, like):
+        """Captures the three graphs of EVERY slot now, while nothing is in flight and the result worker is idle: a capture that
+        starts later shares its stream with replays whose events the worker is polling, and on this runtime a query of an
+        event recorded on a capturing stream invalidates the capture (seen with one transform stream and 24 Kodak images:
+        hipErrorStreamCaptureInvalidated at the first launch of the second slot's capture)."""
+        torch.cuda.synchronize(self.device)
+        for slot in range(self.nb_slots):
+            # the streams this slot will be replayed on: submissions go round the slots and the streams in step
+            stream = self._transform_streams[slot % len(self._transform_streams)]
+            coder_stream = self._streams[slot % len(self._streams)]
+            static_input = torch.empty_like(like)
             graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
-            # thread_local: the result worker keeps querying its events while this thread captures
             with torch.cuda.graph(graphs[0], stream=stream, capture_error_mode='thread_local'):
                 latents = self._launch_analysis(static_input, slot, None)
             with torch.cuda.graph(graphs[1], stream=coder_stream, capture_error_mode='thread_local'):
@@ -291,29 +327,6 @@ class BatchCodec(object):
             with torch.cuda.graph(graphs[2], stream=stream, capture_error_mode='thread_local'):
                 reconstruction = self._launch_synthesis(latents, static_input, slot, None)
             self._graphs[slot] = (graphs, static_input, latents, reconstruction)
-        (graphs, static_input, _, reconstruction) = self._graphs[slot]
-        stream.wait_stream(caller)
-        with torch.cuda.stream(stream):
-            static_input.copy_(luminances_uint8, non_blocking=True)
-            graphs[0].replay()
-            quantized = torch.cuda.Event()
-            quantized.record()
-        with torch.cuda.stream(coder_stream):
-            coder_stream.wait_event(quantized)
-            graphs[1].replay()
-            coded = torch.cuda.Event()
-            coded.record()
-        with torch.cuda.stream(stream):
-            graphs[2].replay()
-            decoded = torch.cuda.Event()
-            decoded.record()
-        luminances_uint8.record_stream(stream)
-        ticket = Ticket(self.batch_size)
-        if self.keep_reconstruction:
-            ticket.reconstruction_uint8 = reconstruction       # valid until this slot is replayed again
-        self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],), None,
-                               self._slot_free[slot]))
-        return ticket
 
     def _submit(self, luminances_uint8):
         slot = self._index % self.nb_slots
@@ -321,29 +334,33 @@ class BatchCodec(object):
         self._index += 1
         self._slot_free[slot].wait()
         self._slot_free[slot].clear()
-        hook = self.launch_hook
-        latents = self._launch_analysis(luminances_uint8, slot, hook)
-        quantized = torch.cuda.Event()
-        quantized.record()
-        ticket = Ticket(self.batch_size)
-        with torch.cuda.stream(stream):
-            stream.wait_event(quantized)
-            if self.time_coder:
-                started = torch.cuda.Event(enable_timing=True)
-                started.record()
-            self._launch_coder(slot)
-            coded = torch.cuda.Event(enable_timing=self.time_coder)
-            coded.record()
-            if self.time_coder:
-                ticket._coder_span = (started, coded)
-        reconstruction = self._launch_synthesis(latents, luminances_uint8, slot, hook)
-        decoded = torch.cuda.Event()
-        decoded.record()
-        if self.keep_reconstruction:
-            ticket.reconstruction_uint8 = reconstruction
-        self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],),
-                               self._pinned_symbols[slot], self._slot_free[slot]))
-        return ticket
+        try:
+            hook = self.launch_hook
+            latents = self._launch_analysis(luminances_uint8, slot, hook)
+            quantized = torch.cuda.Event()
+            quantized.record()
+            ticket = Ticket(self.batch_size)
+            with torch.cuda.stream(stream):
+                stream.wait_event(quantized)
+                if self.time_coder:
+                    started = torch.cuda.Event(enable_timing=True)
+                    started.record()
+                self._launch_coder(slot)
+                coded = torch.cuda.Event(enable_timing=self.time_coder)
+                coded.record()
+                if self.time_coder:
+                    ticket._coder_span = (started, coded)
+            reconstruction = self._launch_synthesis(latents, luminances_uint8, slot, hook)
+            decoded = torch.cuda.Event()
+            decoded.record()
+            if self.keep_reconstruction:
+                ticket.reconstruction_uint8 = reconstruction
+            self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],),
+                                   self._pinned_symbols[slot], self._slot_free[slot]))
+            return ticket
+        except BaseException:
+            self._slot_free[slot].set()       # as in _submit_graph
+            raise
 
     @staticmethod
     def _no_hook(name, fn):

@@ -115,8 +115,9 @@ def test_batch_codec_on_tiny_images(tmp_path, shape):
     c.close()
 
 
+@pytest.mark.parametrize('streams', [1, 2])
 @pytest.mark.parametrize('learned', [False, True])
-def test_batch_codec_graph_replay_equals_the_launch_by_launch_path(learned):
+def test_batch_codec_graph_replay_equals_the_launch_by_launch_path(learned, streams):
     """use_graphs: a step captured into one hipGraph per slot and replayed (with the coder as a forked branch) gives the same
     bits, squared errors, dead maps and reconstructions as the same codec launching kernel by kernel; replays of a slot with
     different images do not leak into each other."""
@@ -137,7 +138,7 @@ def test_batch_codec_graph_replay_equals_the_launch_by_launch_path(learned):
         expected.append((t.result(), t.reconstruction_uint8.cpu().numpy()))
     plain.close()
     graphed = codec.BatchCodec(v, learned, bin_widths, map_mean, probabilities, 67, 2, 64, 96, keep_reconstruction=True,
-                               use_graphs=True, nb_transform_streams=2)
+                               use_graphs=True, nb_transform_streams=streams)
     order = list(range(10)) + [3, 9, 0, 5, 5, 1]                  # 16 steps over 4 slots: every graph is replayed several times
     for start in range(0, len(order), 3):
         chunk = order[start:start + 3]
@@ -154,6 +155,49 @@ def test_batch_codec_graph_replay_equals_the_launch_by_launch_path(learned):
     graphed.close()
     with pytest.raises(ValueError):
         codec.BatchCodec(v, learned, bin_widths, map_mean, probabilities, 67, 2, 64, 96, coder='host', use_graphs=True)
+
+
+@pytest.mark.parametrize('graphs', [False, True])
+def test_a_failed_submit_does_not_hang_the_codec(graphs, monkeypatch):
+    """A launch that raises in the middle of `submit` must surface as that exception: the slot it had taken is given back, so
+    leaving the `with` block (close -> drain) returns instead of waiting for a result nobody will post, and the codec goes on
+    working (round 2: a failed graph capture showed up as a bench run that sat in drain() for its whole time limit)."""
+    from autoencoder_based_image_compression_amd import codec
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    with numpy.load(GOLD) as g:
+        probabilities = g['real_probabilities_1']
+    rng = numpy.random.RandomState(29)
+    v = var.random_variables(1., False, seed=8, bias_std=0.01)
+    images = torch.from_numpy(rng.randint(16, 236, size=(2, 64, 96)).astype(numpy.uint8)).cuda()
+    bin_widths = numpy.ones(128, dtype=numpy.float32)
+    map_mean = numpy.zeros(128, dtype=numpy.float32)
+    with codec.BatchCodec(v, False, bin_widths, map_mean, probabilities, 67, 2, 64, 96, use_graphs=graphs) as c:
+        good = c.submit(images).result()
+        real = c._launch_coder
+
+        def broken(slot):
+            raise RuntimeError('injected')
+
+        c._launch_coder = broken
+        if graphs:
+            replay = torch.cuda.CUDAGraph.replay
+            calls = [0]
+
+            def failing_replay(self):
+                calls[0] += 1
+                if calls[0] == 2:                       # the coder graph of the step
+                    raise RuntimeError('injected')
+                return replay(self)
+
+            monkeypatch.setattr(torch.cuda.CUDAGraph, 'replay', failing_replay)
+        with pytest.raises(RuntimeError, match='injected'):
+            c.submit(images)
+        if graphs:
+            monkeypatch.undo()
+        c._launch_coder = real
+        torch.cuda.synchronize()
+        again = c.submit(images).result()
+        assert numpy.array_equal(again['nb_bits'], good['nb_bits'])
 
 
 @pytest.mark.parametrize('learned', [False, True])

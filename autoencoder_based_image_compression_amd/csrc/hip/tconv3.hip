@@ -9,18 +9,25 @@
 // K order = the oracle's: 32-channel block (outer), then (dr, dc) descending == (u, v) ascending, then the channel inside
 // the block. v_mfma_f32_16x16x4_f32 (A = sites x k, B = k x phases).
 //
-// One block = 2 waves = 4 x 16 sites -> 16 x 64 output pixels; wave w owns tile rows 2w, 2w+1 (two independent
-// accumulator chains, enough to keep the 32-cycle MFMA issue rate alone on its SIMD). The input patch (6 x 18 sites x 128
-// channels) is staged ONCE in LDS with each site's channels permuted to [ci mod 4][ci / 4] (region stride 36, site
-// stride 152 floats): the 8 k-values a lane needs per (channel block, neighbour) are then two conflict-free
-// ds_read_b128 per tile row. Weights are pre-packed per lane ([block][neighbour][lane][8]) and stream from L1/L2 through
-// a register ring four steps (1024 MFMA cycles) ahead: no barrier inside the K loop. Epilogue: the 16 x 64 pixel tile goes
-// through LDS, 8 pixels per thread, BT.601 cast, exact integer squared error (wave shuffle -> one u64 atomic per block).
+// One block = WAVES waves (4) = a tile of 8 x 16 sites -> 32 x 64 output pixels; wave w owns tile rows 2w, 2w+1 (two
+// independent accumulator chains, enough to keep the 32-cycle MFMA issue rate alone on its SIMD). The input patch (10 x 18
+// sites) is staged in LDS PASSES (4) times, 32 channels at a time, with each site's channels permuted to [ci mod 4][ci / 4]:
+// the 8 k-values a lane needs per (channel block, neighbour) are then two conflict-free ds_read_b128 per tile row.
+// 40 KB per block: three blocks = three waves per SIMD. (Two waves on 4 x 16 sites, the first persistent form, re-read
+// 1.69 x the input for its halo against 1.41 x here: 0.196 against 0.192 ms per Kodak batch, 23 against 17 us for one image.)
+// Weights are pre-packed per lane ([block][neighbour][lane][8]) and stream from L1/L2 through a register ring RING steps
+// ahead: no barrier inside the K loop. Epilogue: the pixel tile goes through LDS, 8 pixels per thread, BT.601 cast, exact
+// integer squared error (wave shuffle -> one u64 atomic per tile).
 // Bound: MFMA for the contraction (2,304 issued / 1,296 algorithmic FLOP per pixel); 32 B/px read is the HBM term.
 #include "common.h"
 
 namespace {
-constexpr int TH = 4, TW = 16;
+#ifndef EAE_T3_WAVES
+#define EAE_T3_WAVES 4
+#endif
+constexpr int WAVES = EAE_T3_WAVES;           // waves per block, two tile rows each
+constexpr int NT = 64 * WAVES;                // threads per block
+constexpr int TH = 2 * WAVES, TW = 16;
 #ifndef EAE_T3_PASSES
 #define EAE_T3_PASSES 4
 #endif
@@ -31,14 +38,14 @@ constexpr int PS = PASSES == 2 ? 88 : 56;     // floats per site: 4 regions, rou
 constexpr int PATCH_R = TH + 2, PATCH_C = TW + 2;     //   16-byte bank groups (PS/4 = 22 or 14) -> conflict-free b128 reads
 constexpr int PATCH_FLOATS = PATCH_R * PATCH_C * PS;   // 38,016 B (4 blocks = 8 waves per CU) or 24,192 B (6 blocks)
 constexpr int Q = HALF_C / 4;                 // float4 per site per pass
-constexpr int LOADS = (PATCH_R * PATCH_C * Q + 127) / 128;   // per thread per pass (14 or 7)
+constexpr int LOADS = (PATCH_R * PATCH_C * Q + NT - 1) / NT;   // per thread per pass
 constexpr int STEPS = 4 * 9;                  // (channel block, neighbour)
 #ifndef EAE_T3_RING
-#define EAE_T3_RING 4
+#define EAE_T3_RING 6
 #endif
 constexpr int RING = EAE_T3_RING;             // steps of weights in flight (2 float4 each); divides STEPS: the ring runs on
 static_assert(STEPS % RING == 0, "ring");     //   from one tile into the next
-constexpr int BLOCKS_PER_CU = PASSES == 2 ? 4 : 6;    // by LDS (38 or 24 KB each)
+constexpr int BLOCKS_PER_CU = (PASSES == 2 ? 4 : 6) * 2 / WAVES;    // by LDS (38 or 24 KB each with two waves)
 constexpr int WAVES_PER_SIMD = PASSES == 2 ? 2 : 3;
 
 #ifdef EAE_T3_TRACE                   // scratch/t3_trace.sh: cycles per phase, summed behind the per-image squared errors
@@ -66,12 +73,12 @@ __device__ __forceinline__ Tile tile_of(int t, int tiles_r, int tiles_c) {
 // MFMAs of one pass run, the input sites of the next pass -- the next channels of this tile, or the first ones of the block's
 // next tile -- are already on their way into registers, and so are the tile's reference pixels for the epilogue: the only
 // staging time left on the critical path is the LDS write between two barriers.
-__global__ __launch_bounds__(128, WAVES_PER_SIMD) void tconv3_kernel(const float* __restrict__ x, const float* __restrict__ wq,
+__global__ __launch_bounds__(NT, WAVES_PER_SIMD) void tconv3_kernel(const float* __restrict__ x, const float* __restrict__ wq,
                                                                      float* __restrict__ out_f32, uint8_t* __restrict__ out_u8,
                                                                      const uint8_t* __restrict__ ref, unsigned long long* sse,
                                                                      int n_tiles, int h, int win, int tiles_r, int tiles_c) {
     __shared__ __attribute__((aligned(16))) float patch[PATCH_FLOATS];
-    __shared__ unsigned int red[2];
+    __shared__ unsigned int red[WAVES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, S = (int)gridDim.x >> 3;
@@ -92,16 +99,16 @@ __global__ __launch_bounds__(128, WAVES_PER_SIMD) void tconv3_kernel(const float
         ring[slot_][1] = make_float4(__uint_as_float(v1_.x), __uint_as_float(v1_.y), __uint_as_float(v1_.z),         \
                                      __uint_as_float(v1_.w));                                                        \
     }
-    // A pass = HALF_C channels of the 6 x 18 patch (the K order is channel-block outer anyway): 38 or 24 KB of LDS per block,
-    // so four or six blocks share a CU. 108 sites x Q float4, LOADS per thread; sites outside the image read zero (offset
+    // A pass = HALF_C channels of the patch (the K order is channel-block outer anyway). PATCH_R x PATCH_C sites x Q float4,
+    // LOADS per thread; sites outside the image read zero (offset
     // beyond the buffer: zero-fill at THIS layer, appendix C.3); channel ci of the pass lands at (ci & 3) * REGION + (ci >> 2).
     const int img_bytes = h * win * EAE_C * (int)sizeof(float);
-    // what never changes from tile to tile, per load j of this thread (patch element tid + 128 j): the site's place inside the
+    // what never changes from tile to tile, per load j of this thread (patch element tid + NT j): the site's place inside the
     // patch (row, column), its byte offset from the patch's first site, and where its four values go in LDS
     int rel_rc[LOADS], rel_off[LOADS], lds_at[LOADS];
 #pragma unroll
     for (int j = 0; j < LOADS; ++j) {
-        const int i = tid + 128 * j;
+        const int i = tid + NT * j;
         const int site = i / Q, q = i % Q;
         const int rr = site / PATCH_C, cc = site % PATCH_C;
         rel_rc[j] = i < PATCH_R * PATCH_C * Q ? (rr << 16 | cc) : 0x40000000;     // beyond the patch: a row no image has
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(128, WAVES_PER_SIMD) void tconv3_kernel(const float
             T3_MARK(0)
 #pragma unroll
             for (int j = 0; j < LOADS; ++j) {
-                if (tid + 128 * j < PATCH_R * PATCH_C * Q) {
+                if (tid + NT * j < PATCH_R * PATCH_C * Q) {
                     float* dst = patch + lds_at[j];
                     dst[0] = v[j].x; dst[REGION] = v[j].y; dst[2 * REGION] = v[j].z; dst[3 * REGION] = v[j].w;
                 }
@@ -246,7 +253,12 @@ __global__ __launch_bounds__(128, WAVES_PER_SIMD) void tconv3_kernel(const float
             for (int off = 32; off > 0; off >>= 1) se += __shfl_down(se, off, 64);
             if (lane == 0) red[wave] = se;
             __syncthreads();
-            if (tid == 0) atomicAdd(&sse[cur.img], (unsigned long long)red[0] + red[1]);
+            if (tid == 0) {
+                unsigned long long total = 0;
+#pragma unroll
+                for (int i = 0; i < WAVES; ++i) total += red[i];
+                atomicAdd(&sse[cur.img], total);
+            }
         }
         cur = nxt;
         T3_MARK(6)
@@ -297,7 +309,7 @@ extern "C" int eae_hip_tconv9x9s4_luma(const float* x, const float* w_phase, flo
     long grid = (long)cus * BLOCKS_PER_CU;
     if (grid > n_tiles) grid = n_tiles;
     grid = (grid + 7) / 8 * 8;
-    hipLaunchKernelGGL(tconv3_kernel, dim3((unsigned)grid), dim3(128), 0, (hipStream_t)stream, x, w_phase, out_f32,
+    hipLaunchKernelGGL(tconv3_kernel, dim3((unsigned)grid), dim3(NT), 0, (hipStream_t)stream, x, w_phase, out_f32,
                        out_u8, ref_u8, reinterpret_cast<unsigned long long*>(sse), (int)n_tiles, h, w_in, tiles_r, tiles_c);
     EAE_HIP_CHECK_LAUNCH();
     return EAE_HIP_OK;

@@ -31,13 +31,6 @@ __global__ __launch_bounds__(256, 2) void conv1_kernel(const uint8_t* __restrict
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     EAE_TRACE_MARK(0)
-#ifdef EAE_C1_STAGGER
-    {   // experiment: the three blocks a CU holds at first start a third of a tile apart
-        const int cls = ((int)blockIdx.x / EAE_C1_STAGGER_CUS) % 3;
-        if ((int)blockIdx.x < 3 * EAE_C1_STAGGER_CUS)
-            for (int i = 0; i < cls * EAE_C1_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     int b = xcd_remap(blockIdx.x, gridDim.x);
     const int tc = b % tiles_c; b /= tiles_c;
     const int tr = b % tiles_r;

@@ -53,11 +53,6 @@ constexpr int WAVES_PER_SIMD = PASSES == 2 ? 2 : 3;
 #else
 #define T3_MARK(i_)
 #endif
-#ifdef EAE_T3_NOFETCH
-#define T3_FETCH_ON (h < 0)           // experiment: no input traffic (every site reads as outside the image)
-#else
-#define T3_FETCH_ON true
-#endif
 
 struct Tile { int img, tr, tc; };
 __device__ __forceinline__ Tile tile_of(int t, int tiles_r, int tiles_c) {
@@ -124,7 +119,7 @@ __global__ __launch_bounds__(NT, WAVES_PER_SIMD) void tconv3_kernel(const float*
         const int base_ = ((r0_ * win + c0_) * EAE_C + HALF_C * (pass_)) * 4;                                        \
         _Pragma("unroll") for (int j = 0; j < LOADS; ++j) {                                                          \
             const int r = r0_ + (rel_rc[j] >> 16), c = c0_ + (rel_rc[j] & 0xFFFF);                                   \
-            const bool ok = (unsigned)r < (unsigned)h && (unsigned)c < (unsigned)win && T3_FETCH_ON;                 \
+            const bool ok = (unsigned)r < (unsigned)h && (unsigned)c < (unsigned)win;                                \
             const u32x4 t_ = __builtin_amdgcn_raw_buffer_load_b128(rs_, ok ? base_ + rel_off[j] : -1, 0, 0);         \
             v[j] = make_float4(__uint_as_float(t_.x), __uint_as_float(t_.y), __uint_as_float(t_.z),                  \
                                __uint_as_float(t_.w));                                                               \

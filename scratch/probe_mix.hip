@@ -39,7 +39,10 @@ __global__ __launch_bounds__(256, 3) void mix(const float* __restrict__ table, f
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(kk + 5 * j) & 15], bv[kk], acc[j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        if (MODE & 16) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(av[(kk + 5 * j) & 15]), "v"(bv[kk]));
+        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(kk + 5 * j) & 15], bv[kk], acc[j], 0, 0, 0);
+      }
       if (MODE & 2) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, ((lane * 16 + kk * 1024 + st * 4096) & 65535), 0, 0);
         av[kk] += __uint_as_float(v.x) * 1e-30f;
@@ -116,14 +119,16 @@ int main() {
   float *sink, *table; hipMalloc(&sink, 1 << 22); hipMalloc(&table, 65536); hipMemset(table, 0, 65536);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int steps = 6000;                       // 6000 x 64 MFMAs x 64 cycles x 3 waves = 74 M cycles = ~31 ms at 2.4 GHz
-  const char* names[16] = {"MFMA only", "+LDS", "+global", "+LDS+global", "+int", "+LDS+int", "+global+int", "+LDS+global+int",
-                           "+fp", "+LDS+fp", "+global+fp", "+LDS+global+fp", "+int+fp", "+LDS+int+fp", "+global+int+fp", "+all"};
+  const char* names[32] = {"MFMA only", "+LDS", "+global", "+LDS+global", "+int", "+LDS+int", "+global+int", "+LDS+global+int",
+                           "+fp", "+LDS+fp", "+global+fp", "+LDS+global+fp", "+int+fp", "+LDS+int+fp", "+global+int+fp", "+all",
+                           "AGPR MFMA only", "AGPR +LDS", "AGPR +global", "AGPR +LDS+global", "AGPR +int", "", "", "AGPR +LDS+global+int", "AGPR +fp", "", "", "", "", "", "", "AGPR +all"};
 #define RUN(M)                                                                                                       \
   { for (int rep = 0; rep < 2; ++rep) { hipEventRecord(e0); hipLaunchKernelGGL((mix<M>), dim3(768), dim3(256), 0, 0, table, sink, steps);   \
       hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);                       \
       if (rep) printf("%-18s %8.2f ms  %.1f TFLOP/s (%.3f of 157.3)\n", names[M], ms, 768. * 4 * steps * 64 * 4096. / (ms * 1e-3) / 1e12,   \
                       768. * 4 * steps * 64 * 4096. / (ms * 1e-3) / 157.3e12); } }
   RUN(0) RUN(1) RUN(2) RUN(4) RUN(8) RUN(3) RUN(7) RUN(15)
+  RUN(16) RUN(17) RUN(18) RUN(20) RUN(24) RUN(19) RUN(23) RUN(31)
 #define RUN64(M)                                                                                                     \
   { for (int rep = 0; rep < 2; ++rep) { hipEventRecord(e0); hipLaunchKernelGGL((mix64<M>), dim3(512), dim3(256), 0, 0, table, sink, steps / 2);   \
       hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);                       \

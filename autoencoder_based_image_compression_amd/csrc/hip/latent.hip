@@ -5,8 +5,9 @@
 //   count_nb_deads flags, the three data checks     tools.py:294-320, 130-132, 372-375, compression.py:149-153
 //   + map_mean, inverse_gdn_4                       reconstructing_eae_kodak.py:192, components.py:53-58, tfutils.py:505-509
 // The separate kernels (conv epilogue / gdn_kernel, quantize_kernel, gdn_kernel) each stream the 128-channel latents
-// through HBM; here a wave keeps 32 positions x 128 channels in registers (latent_wave_kernel, the default; latent_kernel
-// keeps 64 positions per block in LDS) and runs both 128 x 128 contractions on the MFMA.
+// through HBM; here the 32 positions x 128 channels of a tile stay in registers -- of four waves, 32 channels each
+// (latent_quarter_kernel, the default), or of one wave (latent_wave_kernel); latent_kernel keeps 64 positions per block in
+// LDS -- and both 128 x 128 contractions run on the MFMA.
 // Arithmetic, operation by operation, is that of gdn.hip and quantize.hip (same helpers), so the results are the same bits.
 #include "latent_body.h"
 
@@ -16,7 +17,7 @@ namespace {
 // Block-cooperative form (EAE_HIP_LATENT_LDS=1, kept for comparison): 64 positions per block (2 waves x 32 positions x 128
 // channels) in 50 KB of LDS. Measured at Kodak batch 24 (36,864 positions): 127-131 us in the bench, against 188 us for
 // 128-position blocks and 162 us for 32 positions with one channel tile per wave; the register-resident wave form below
-// (the default) takes 121 us; the three separate kernels 25 + 75 + 45 us plus two launch gaps. With about one wave per SIMD
+// (round 1's default) takes 121 us; the three separate kernels 25 + 75 + 45 us plus two launch gaps. With about one wave per SIMD
 // every form is bound by exposed latencies (the gamma rows come from L2 behind an 8-deep ring), not by MFMA or HBM rates.
 constexpr int WAVES = 2;
 constexpr int TM = WAVES * 32;

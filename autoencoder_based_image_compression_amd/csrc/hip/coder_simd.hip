@@ -75,15 +75,20 @@ struct SimdParams {
     int32_t* perm;                        // decode, sorted form: [0..3] header (short blocks, long blocks), then 64 maps per block
 };
 
+// Exclusive prefix sum over the 64 lanes, and the total. Data-parallel primitives, not cross-lane loads: four row_shr steps scan
+// the rows of 16 lanes, row_bcast:15 / :31 carry the row totals on (the sequence LLVM's atomic optimiser emits for gfx9): 6 DPP
+// additions where six __shfl_up rounds were 6 x (ds_bpermute + compare + add) -- this runs once per 64 symbols of every map,
+// next to the transforms.
 __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t& total) {
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(inc, d, 64);
-        if ((int)threadIdx.x >= d) inc += up;
-    }
-    total = __shfl(inc, 63, 64);
-    return inc - v;
+    int inc = (int)v;
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, false);     // row_shr:1
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, false);     // row_shr:2
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, false);     // row_shr:4
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, false);     // row_shr:8
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
+    total = (uint32_t)__builtin_amdgcn_readlane(inc, 63);
+    return (uint32_t)inc - v;
 }
 __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 #pragma unroll
@@ -133,9 +138,10 @@ __global__ __launch_bounds__(64) void binarise_kernel(const SimdParams p) {
             bb |= (unsigned long long)(s > 0 ? 1u : 0u) << nb;   // LosslessCoder.cpp:22-37: 0 = negative
             nb++;
         }
-        uint32_t jtot, btot;
-        const uint32_t jo = wave_exclusive_scan(nd, jtot);
-        const uint32_t bo = wave_exclusive_scan(nb, btot);
+        // both prefix sums in one scan: decisions (<= 33 per symbol) in the low half, bypass bits (<= 34) in the high half
+        uint32_t both_tot;
+        const uint32_t both = wave_exclusive_scan(nd | (nb << 16), both_tot);
+        const uint32_t jo = both & 0xFFFFu, bo = both >> 16, jtot = both_tot & 0xFFFFu, btot = both_tot >> 16;
         // decisions: `ones` ones in contexts 0..ones-1, then a zero in context a when a < L (LosslessCoder.cpp:167-191)
         for (uint32_t q = 0; q < nd; q++) {
             const uint32_t j = jbase + jo + q;
@@ -568,15 +574,10 @@ __global__ __launch_bounds__(1024) void sort_maps_kernel(const SimdParams p, uin
             is_long = (row >= 0 && p.status[m] == 0 && (p.bac_bits[m] > wb_bits || p.bypass_bits[m] > wy_bits)) ? 1u : 0u;
             is_short = 1u - is_long;
         }
-        // exclusive scans inside the wavefront (wave_exclusive_scan indexes by threadIdx.x: written for 64-thread blocks)
-        uint32_t inc_s = is_short, inc_l = is_long;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t us = __shfl_up(inc_s, d, 64), ul = __shfl_up(inc_l, d, 64);
-            if ((int)lane >= d) { inc_s += us; inc_l += ul; }
-        }
-        const uint32_t tot_s = __shfl(inc_s, 63, 64), tot_l = __shfl(inc_l, 63, 64);
-        const uint32_t off_s = inc_s - is_short, off_l = inc_l - is_long;
+        // both exclusive scans inside the wavefront at once: short maps in the low half, long ones in the high half
+        uint32_t both_tot;
+        const uint32_t both = wave_exclusive_scan(is_short | (is_long << 16), both_tot);
+        const uint32_t off_s = both & 0xFFFFu, off_l = both >> 16, tot_s = both_tot & 0xFFFFu, tot_l = both_tot >> 16;
         if (lane == 0) { wave_sums[0][wave] = tot_s; wave_sums[1][wave] = tot_l; }
         __syncthreads();
         uint32_t before_s = 0, before_l = 0;

@@ -38,7 +38,10 @@ using namespace eae_conv_gemm;
 
 namespace {
 
-constexpr int RING = 8;
+#ifndef EAE_SPLIT_RING
+#define EAE_SPLIT_RING 8
+#endif
+constexpr int RING = EAE_SPLIT_RING;      // weight k-pairs in flight ahead of their MFMAs
 #ifndef EAE_EPI_RING
 #define EAE_EPI_RING 3
 #endif

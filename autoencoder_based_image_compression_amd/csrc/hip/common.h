@@ -131,25 +131,12 @@ __device__ __forceinline__ void swap_halves(float& a, float& b) {
 }
 
 // RING: gamma k-pairs (16 bytes per lane each) in flight ahead of the MFMAs that use them
-// Stores: through a pointer (`o`, guarded by `valid`), or -- BUFFER -- through a buffer descriptor with a 32-bit byte offset per
-// lane (`voff`, -1 for a lane outside the image: beyond the buffer, the store is dropped): two registers less over the whole
-// epilogue, which is what lets three of these waves and a coder wave of 48 registers share a SIMD.
-template <int NORM, int RING = 8, bool BUFFER = false>
+template <int NORM, int RING = 8>
 __device__ __forceinline__ void wave_epilogue(f32x16 (&acc)[4], const float* vec_lds, bool has_bias,
-                                              const float* __restrict__ gamma_packed, float* o, bool valid, int lane,
-                                              __amdgpu_buffer_rsrc_t rsrc = __amdgpu_buffer_rsrc_t(), int voff = 0) {
+                                              const float* __restrict__ gamma_packed, float* o, bool valid, int lane) {
     const int hi = lane >> 5, lj = lane & 31;
     const int cbase = 4 * hi;                 // channel of (t, g, q) = 32 t + 8 g + cbase + q
-    if (!BUFFER) o += cbase;
-#define EAE_EPI_STORE(t_, g_, y_)                                                                                    \
-    {                                                                                                                \
-        if (BUFFER) {                                                                                                \
-            const u32x4 w_ = {__float_as_uint((y_).x), __float_as_uint((y_).y), __float_as_uint((y_).z), __float_as_uint((y_).w)};  \
-            __builtin_amdgcn_raw_buffer_store_b128(w_, rsrc, voff, (32 * (t_) + 8 * (g_)) * 4, 0);                    \
-        } else if (valid) {                                                                                          \
-            *reinterpret_cast<float4*>(o + 32 * (t_) + 8 * (g_)) = (y_);                                             \
-        }                                                                                                            \
-    }
+    o += cbase;
     if (has_bias) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -163,13 +150,14 @@ __device__ __forceinline__ void wave_epilogue(f32x16 (&acc)[4], const float* vec
             }
     }
     if constexpr (NORM == EAE_NORM_NONE) {
+        if (valid) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 y = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
-                EAE_EPI_STORE(t, g, y)
-            }
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(o + 32 * t + 8 * g) =
+                        make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+        }
         return;
     } else {
         const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -183,7 +171,7 @@ __device__ __forceinline__ void wave_epilogue(f32x16 (&acc)[4], const float* vec
         float4 ring[RING];
 #define EAE_G_LOAD(dst_, kk_)                                                                                        \
         {                                                                                                            \
-            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_lane, (kk_) * 2 * EAE_C * 4, 0);       \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_lane + (kk_) * 2 * EAE_C * 4, 0, 0);    \
             dst_ = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z),                  \
                                __uint_as_float(v_.w));                                                               \
         }
@@ -226,8 +214,7 @@ __device__ __forceinline__ void wave_epilogue(f32x16 (&acc)[4], const float* vec
                                              gdn_apply(acc[t][4 * g + 1], d[t][4 * g + 1], bt.y, inverse),
                                              gdn_apply(acc[t][4 * g + 2], d[t][4 * g + 2], bt.z, inverse),
                                              gdn_apply(acc[t][4 * g + 3], d[t][4 * g + 3], bt.w, inverse));
-                EAE_EPI_STORE(t, g, y)
+                if (valid) *reinterpret_cast<float4*>(o + 32 * t + 8 * g) = y;
             }
     }
-#undef EAE_EPI_STORE
 }

@@ -38,15 +38,11 @@ using namespace eae_conv_gemm;
 
 namespace {
 
-#ifndef EAE_SPLIT_RING
-#define EAE_SPLIT_RING 8
-#endif
-constexpr int RING = EAE_SPLIT_RING;      // weight k-pairs in flight ahead of their MFMAs
+constexpr int RING = 8;
 #ifndef EAE_EPI_RING
-#define EAE_EPI_RING 3
+#define EAE_EPI_RING 4
 #endif
-constexpr int EPI_RING = EAE_EPI_RING;   // gamma ring of the epilogue: with 3 the GDN / IGDN instances need 150 registers, i.e. three
-                                         // of their waves (3 x 152) leave a SIMD room for a coder wave of up to 56
+constexpr int EPI_RING = EAE_EPI_RING;   // gamma ring of the epilogue (see the register budget at the kernel)
 constexpr int ABUF = 32 * AS_STRIDE;                 // one activation buffer of one wave
 // LDS of a block: two activation buffers per wave + ONE copy of the per-channel vectors of the epilogue (bias | beta, or, with
 // the latent stage behind conv_3, bias | beta_in | beta_out | map_mean | bin_widths). Every wave writes the whole copy itself
@@ -149,6 +145,7 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
         const bool valid = pr < p.hp && pc < p.wp;
         float* out_img = p.out + (size_t)img * p.hout * p.wout * EAE_C;
         const int o_off = ((pr * p.out_stride + pd.out_a) * p.wout + (pc * p.out_stride + pd.out_b)) * EAE_C;   // floats, inside the image
+        float* o = out_img + o_off;
         const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             out_img, 0, (int)((size_t)p.hout * p.wout * EAE_C * sizeof(float)), 0x00020000);
         const int park = valid ? (o_off + cbase) * 4 : -1;      // byte offset of this lane's parked accumulators (-1: beyond the buffer)
@@ -179,7 +176,7 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
 #define EAE_Q_SLAB(ti_, ch_) ((((pd.tap[ti_] >> 16) * EAE_C + (ch_) * KC) * EAE_C) * 4)
 #define EAE_Q_W_LOAD(dst_, slab_, kk_)                                                                               \
         {                                                                                                            \
-            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, (slab_) + (kk_) * 2 * EAE_C * 4, 0); \
+            const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane + (kk_) * 2 * EAE_C * 4, (slab_), 0); \
             dst_ = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z),                  \
                                __uint_as_float(v_.w));                                                               \
         }
@@ -270,7 +267,7 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
                 wave_latent_body<NORM == NORM_LATENT, NORM == NORM_LATENT>(acc, vec_lds + EAE_C, p.gamma, p.gamma_out, p.latent, valid,
                                                                            (long)img, pr * p.wp + pc, p.hp * p.wp, lane);
             } else {
-                wave_epilogue<NORM, EPI_RING, true>(acc, vec_lds, p.bias != nullptr, p.gamma, nullptr, valid, lane, out_rsrc, park);
+                wave_epilogue<NORM, EPI_RING>(acc, vec_lds, p.bias != nullptr, p.gamma, o, valid, lane);
             }
         } else {
             // a head: park the accumulators in the tile's own output pixels, write-through, and publish them

@@ -157,6 +157,31 @@ def test_batch_codec_graph_replay_equals_the_launch_by_launch_path(learned, stre
         codec.BatchCodec(v, learned, bin_widths, map_mean, probabilities, 67, 2, 64, 96, coder='host', use_graphs=True)
 
 
+def test_graph_capture_with_one_transform_stream_at_kodak_size():
+    """use_graphs with ONE transform stream on a batch whose step takes milliseconds: while slot 0's replay was still running, the
+    capture of slot 1 (same stream) used to be invalidated by the result worker's event polls (hipErrorStreamCaptureInvalidated;
+    the bench then sat in close() for its whole time limit). All slots are captured up front now: the steps below must all
+    return, with the bits of the launch-by-launch path."""
+    import bench
+    from autoencoder_based_image_compression_amd import codec, device as dev, pipeline
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    from autoencoder_based_image_compression_amd.kodak.lossless import stats as lossless_stats
+    variables = bench.synthetic_model(1.)
+    images = torch.from_numpy(bench.synthetic_images(3, 24, 512, 768)).cuda()
+    y0 = pipeline.DeviceEncoder(variables, False)(images)
+    map_mean = dev.map_means(y0).cpu().numpy()
+    probabilities = lossless_stats.compute_binary_probabilities(y0.cpu().numpy(), variables[var.BIN_WIDTHS_NAME], map_mean, 10)
+    del y0
+    with codec.BatchCodec(variables, False, variables[var.BIN_WIDTHS_NAME], map_mean, probabilities, 67, 24, 512, 768) as plain:
+        expected = plain.submit(images).result()
+    with codec.BatchCodec(variables, False, variables[var.BIN_WIDTHS_NAME], map_mean, probabilities, 67, 24, 512, 768, use_graphs=True,
+                          nb_transform_streams=1) as graphed:
+        tickets = [graphed.submit(images) for _ in range(8)]
+        for t in tickets:
+            r = t.result()
+            assert numpy.array_equal(r['nb_bits'], expected['nb_bits']) and numpy.array_equal(r['sse'], expected['sse'])
+
+
 @pytest.mark.parametrize('graphs', [False, True])
 def test_a_failed_submit_does_not_hang_the_codec(graphs, monkeypatch):
     """A launch that raises in the middle of `submit` must surface as that exception: the slot it had taken is given back, so

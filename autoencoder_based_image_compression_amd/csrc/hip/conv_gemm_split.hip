@@ -270,7 +270,10 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
                 wave_epilogue<NORM, EPI_RING>(acc, vec_lds, p.bias != nullptr, p.gamma, o, valid, lane);
             }
         } else {
-            // a head: park the accumulators in the tile's own output pixels, write-through, and publish them
+            // a head: park the accumulators in the tile's own output pixels, write-through, and publish them. (These 16-byte
+            // buffer stores carry MFMA results, which the compiler keeps apart from their readers whatever the store looks like.
+            // The same store right behind VECTOR instructions that write its data registers is NOT kept apart when its soffset
+            // is a register, and then stores stale lanes: DESIGN.md section 10, "a trap met on the way".)
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll

@@ -57,6 +57,8 @@ class Ticket(object):
         self._error = None
         self._values = None
         self.reconstruction_uint8 = None      # device tensor when the codec keeps reconstructions
+        self.decoded_event = None             # recorded behind the synthesis transform: wait for it on another stream before
+        #                                       reading `reconstruction_uint8` there (valid until the slot comes round again)
         self._coder_span = None               # (start, stop) timing events on the coder stream (BatchCodec(time_coder=True))
 
     def coder_ms(self):
@@ -91,7 +93,7 @@ class _Worker(threading.Thread):
             job = self.jobs.get()
             if job is None:
                 return
-            (ticket, events, views, symbols_host, slot_free) = job
+            (ticket, events, views, symbols_host, slot_free, recount) = job
             try:
                 for event in events:
                     if _POLL_SECONDS > 0.:
@@ -100,6 +102,12 @@ class _Worker(threading.Thread):
                     else:
                         event.synchronize()
                 (results, hist, overflow, flags, checks, sse) = [v.numpy() for v in views]
+                # the last word of the squared-error block: tiles that a cut conv launch of this batch left unfinished
+                # (device.conv_workspace_collect); nothing of this batch can be trusted then
+                (sse, unfinished) = (sse[:-1], int(sse[-1]))
+                if unfinished != 0:
+                    raise dev.SplitHandOffTimeout('{} tiles of a cut conv launch were not handed over: the results of this batch '
+                                                  'are invalid (the workspace has been reset; later batches are unaffected)'.format(unfinished))
                 if symbols_host is not None:
                     # encode + decode + compare per map on the host cores, like compress_lossless + the caller's assert
                     (_, nb_bits) = lossless_compression.code_planar_symbols(symbols_host.numpy(), self.host_probabilities,
@@ -120,7 +128,9 @@ class _Worker(threading.Thread):
                 exception_bits = numpy.zeros(n, dtype=numpy.int64)
                 if hist.size:
                     if int(overflow.sum()) != 0:
-                        raise RuntimeError('exception-map symbols outside the histogram radius')
+                        # a symbol beyond +-hist_radius: the reference's histogram runs from the smallest to the largest symbol
+                        # whatever they are (lossless/compression.py:68-75, tools.py:376-388), so count again over all of int16
+                        hist = recount()
                     exception_bits = numpy.array([int(lossless_compression.exception_map_nb_bits(row, self.map_size))
                                                   for row in hist.astype(numpy.int64)], dtype=numpy.int64)
                 ticket._values = {'nb_bits': coder_bits + exception_bits, 'coder_bits': coder_bits,
@@ -153,8 +163,9 @@ class BatchCodec(object):
         SIMD and nothing to hide that epilogue behind: 3.41 against 3.44 ms per 24 images, with the conv_3 launch at 0.36 ms
         instead of 0.27 + 0.12. Pays for batches that give conv_3 several tiles per SIMD.
         hist_radius: the exception map's entropy is formed from an exact histogram of its symbols over [-hist_radius,
-        hist_radius]; a symbol outside it makes `Ticket.result()` raise (the image-by-image functions of `kodak/` widen the
-        histogram instead)."""
+        hist_radius]; when a symbol falls outside, the result worker counts that batch's exception maps again over the whole
+        int16 range (like the image-by-image functions of `kodak/`; the reference's histogram has no bound,
+        lossless/compression.py:68-75)."""
         if coder not in ('device', 'host', 'none'):
             raise ValueError('`coder` is neither "device" nor "host" nor "none".')
         if use_graphs and coder == 'host':
@@ -193,6 +204,9 @@ class BatchCodec(object):
         self.coder = coder
         self.time_coder = bool(time_coder)      # Ticket.coder_ms(): the launch-by-launch path only
         self.fuse_latent = bool(fuse_latent)
+        # launch_hook(name, fn): called for every timed launch of the launch-by-launch path with name in ('conv1_gdn1',
+        # 'conv2_gdn2', 'conv3', 'latent', 'tconv1_igdn5', 'tconv2_igdn6', 'tconv3', 'coder_encode', 'coder_decode') on the
+        # stream the launch goes to (bench.py brackets them with HIP events); it must return fn()
         self.launch_hook = launch_hook if launch_hook is not None else (lambda name, fn: fn())
         n_maps = batch_size*self.nb_maps
         nb_hist = batch_size if self.idx_map_exception >= 0 else 0
@@ -205,11 +219,13 @@ class BatchCodec(object):
         self.nb_slots = nb_in_flight + 2
         self._streams = _side_streams(nb_in_flight, self.device)
         self._transform_streams = _side_streams(nb_in_flight + nb_transform_streams, self.device)[nb_in_flight:] if nb_transform_streams > 1 else []
-        self._slot_all = [torch.zeros(nb_words + 2*batch_size, dtype=torch.int32, device=self.device) for _ in range(self.nb_slots)]
+        # ... and behind the squared errors one more 64-bit word whose low half is the conv workspace's error word of the step
+        self._slot_all = [torch.zeros(nb_words + 2*batch_size + 2, dtype=torch.int32, device=self.device) for _ in range(self.nb_slots)]
         self._slot_out = [t[:nb_words] for t in self._slot_all]
         self._pinned_out = [torch.zeros(nb_words, dtype=torch.int32).pin_memory() for _ in range(self.nb_slots)]
-        self._slot_sse = [t[nb_words:].view(torch.int64) for t in self._slot_all]
-        self._pinned_sse = [torch.zeros(batch_size, dtype=torch.int64).pin_memory() for _ in range(self.nb_slots)]
+        self._slot_sse = [t[nb_words:].view(torch.int64) for t in self._slot_all]           # [batch_size] errors + [1] status
+        self._slot_unfinished = [t[nb_words + 2*batch_size:nb_words + 2*batch_size + 1] for t in self._slot_all]
+        self._pinned_sse = [torch.zeros(batch_size + 1, dtype=torch.int64).pin_memory() for _ in range(self.nb_slots)]
         self._symbols = [torch.empty((batch_size, self.nb_maps, self.map_size), dtype=torch.int16, device=self.device)
                          for _ in range(self.nb_slots)]
         self._coder_streams = [dev.CoderStreams(n_maps, self.map_size, self.truncated_unary_length, self.device,
@@ -230,6 +246,7 @@ class BatchCodec(object):
         self.use_graphs = bool(use_graphs)
         self._graphs = [None]*self.nb_slots          # per slot: (three graphs, static input, latents, reconstruction)
         self._warm = False
+        self._recount_stream = None
         if self.use_graphs and not self._transform_streams:
             self._transform_streams = _side_streams(nb_in_flight + 1, self.device)[nb_in_flight:]     # replays never go to the caller's stream
 
@@ -270,9 +287,13 @@ class BatchCodec(object):
         Slot s owns its buffers (symbols, streams, result blocks), so it owns its three graphs too: all captured at the first
         call (after one ordinary step that gets every lazy initialisation out of the way: `_capture_all`), replayed afterwards."""
         if not self._warm:
-            self._warm = True
             self._submit(luminances_uint8).result()          # first launches: function attributes, lazy module loads
-            self._capture_all(luminances_uint8)
+            try:
+                self._capture_all(luminances_uint8)
+            except BaseException:
+                self._graphs = [None]*self.nb_slots          # a half-captured set is of no use: the next submit starts over
+                raise
+            self._warm = True
         slot = self._index % self.nb_slots
         stream = self._transform_streams[self._index % len(self._transform_streams)]
         coder_stream = self._streams[self._index % len(self._streams)]
@@ -281,6 +302,8 @@ class BatchCodec(object):
         self._slot_free[slot].clear()
         try:
             caller = torch.cuda.current_stream()
+            if self._graphs[slot] is None:
+                raise RuntimeError('slot {} has no captured graphs (a capture failed earlier)'.format(slot))
             (graphs, static_input, _, reconstruction) = self._graphs[slot]
             stream.wait_stream(caller)
             with torch.cuda.stream(stream):
@@ -299,23 +322,26 @@ class BatchCodec(object):
                 decoded.record()
             luminances_uint8.record_stream(stream)
             ticket = Ticket(self.batch_size)
+            ticket.decoded_event = decoded
             if self.keep_reconstruction:
                 ticket.reconstruction_uint8 = reconstruction       # valid until this slot is replayed again
             self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],), None,
-                                   self._slot_free[slot]))
+                                   self._slot_free[slot], lambda: self._recount_exception_maps(slot)))
             return ticket
         except BaseException:
             self._slot_free[slot].set()       # nobody will report on this slot: without this, drain() / close() wait for ever
             raise
 
     def _capture_all(self, like):
-        """Captures the three graphs of EVERY slot now, while nothing is in flight and the result worker is idle: a capture that
+        """Captures the three graphs of EVERY slot now, while nothing of THIS codec is in flight and its result worker is idle
+        (other codecs of the process share the side streams: capture before they are busy, or give them other streams): a capture that
         starts later shares its stream with replays whose events the worker is polling, and on this runtime a query of an
         event recorded on a capturing stream invalidates the capture (seen with one transform stream and 24 Kodak images:
         hipErrorStreamCaptureInvalidated at the first launch of the second slot's capture)."""
         torch.cuda.synchronize(self.device)
         for slot in range(self.nb_slots):
-            # the streams this slot will be replayed on: submissions go round the slots and the streams in step
+            # any of the codec's streams will do for the capture: a replay runs on the stream it is launched into, which
+            # `_submit_graph` picks from the submission index (slots and streams go round at different periods)
             stream = self._transform_streams[slot % len(self._transform_streams)]
             coder_stream = self._streams[slot % len(self._streams)]
             static_input = torch.empty_like(like)
@@ -345,7 +371,7 @@ class BatchCodec(object):
                 if self.time_coder:
                     started = torch.cuda.Event(enable_timing=True)
                     started.record()
-                self._launch_coder(slot)
+                self._launch_coder(slot, hook)
                 coded = torch.cuda.Event(enable_timing=self.time_coder)
                 coded.record()
                 if self.time_coder:
@@ -353,14 +379,29 @@ class BatchCodec(object):
             reconstruction = self._launch_synthesis(latents, luminances_uint8, slot, hook)
             decoded = torch.cuda.Event()
             decoded.record()
+            ticket.decoded_event = decoded
             if self.keep_reconstruction:
                 ticket.reconstruction_uint8 = reconstruction
             self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],),
-                                   self._pinned_symbols[slot], self._slot_free[slot]))
+                                   self._pinned_symbols[slot], self._slot_free[slot], lambda: self._recount_exception_maps(slot)))
             return ticket
         except BaseException:
             self._slot_free[slot].set()       # as in _submit_graph
             raise
+
+    def _recount_exception_maps(self, slot):
+        """Histograms of the slot's exception maps over all of int16, as a host array [batch, 65535] (called by the result
+        worker while it still owns the slot, on its own stream, when a symbol fell outside `hist_radius`)."""
+        with torch.cuda.device(self.device):
+            if self._recount_stream is None:
+                self._recount_stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._recount_stream):
+                (hist, overflow) = dev.symbol_histograms(self._symbols[slot].view(self._n_maps, self.map_size), 32767,
+                                                         first_map=self.idx_map_exception, map_step=self.nb_maps)
+                host = hist.cpu().numpy()
+                if int(overflow.sum().item()) != 0:          # -32768: cast_float_to_int16 never produces it (tools.py:95-133)
+                    raise RuntimeError('exception-map symbol outside [-32767, 32767]')
+        return host
 
     @staticmethod
     def _no_hook(name, fn):
@@ -373,7 +414,7 @@ class BatchCodec(object):
         enc = self.encoder
         v = enc.v
         d = self.decoder.v
-        gdn_1 = dev.conv9x9s4_u8(luminances_uint8, enc.w1, v['encoder/biases_1'], enc.g[1], v['encoder/beta_1'])
+        gdn_1 = hook('conv1_gdn1', lambda: dev.conv9x9s4_u8(luminances_uint8, enc.w1, v['encoder/biases_1'], enc.g[1], v['encoder/beta_1']))
         ws = self._conv_ws[slot]
         gdn_2 = hook('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, enc.w2, v['encoder/biases_2'], dev.NORM_GDN, enc.g[2], v['encoder/beta_2'], workspace=ws))
         (_, hist, overflow, flags, checks) = self._views(self._slot_out[slot])
@@ -388,23 +429,24 @@ class BatchCodec(object):
         else:
             y_raw = hook('conv3', lambda: dev.conv5x5s2(gdn_2, enc.w3, v['encoder/biases_3'], dev.NORM_NONE, workspace=ws))
             # gdn_3 -> centre / quantise / symbols / dead-map flags -> de-centre -> inverse_gdn_4: one pass over the latents
-            q = dev.latent_stage(y_raw, self.bin_widths, self.map_mean, gdn_in=gdn_in, igdn_out=igdn_out, want_shifted=self.learned,
-                                 want_symbols=True, want_flags=True, out_symbols=self._symbols[slot], out_flags=flags,
-                                 out_checks=checks[:3])
+            q = hook('latent', lambda: dev.latent_stage(y_raw, self.bin_widths, self.map_mean, gdn_in=gdn_in, igdn_out=igdn_out,
+                                                        want_shifted=self.learned, want_symbols=True, want_flags=True,
+                                                        out_symbols=self._symbols[slot], out_flags=flags, out_checks=checks[:3]))
         if self.idx_map_exception >= 0:
             dev.symbol_histograms(self._symbols[slot].view(self._n_maps, self.map_size), self.hist_radius, out=(hist, overflow),
                                   first_map=self.idx_map_exception, map_step=self.nb_maps, zero=False)
         return q['shifted'] if self.learned else q['t']
 
-    def _launch_coder(self, slot):
+    def _launch_coder(self, slot, hook=None):
         """The lossless coder over the slot's symbols (encode every map, decode it back, compare) and the publication of the
         slot's result block, on the current stream."""
+        hook = hook or self._no_hook
         symbols = self._symbols[slot].view(self._n_maps, self.map_size)
         if self.coder == 'device':
-            dev.coder_encode_batch(symbols, self.probabilities, self.prob_row, self.truncated_unary_length,
-                                   out=self._coder_streams[slot], workspace=self._workspaces[slot])
-            dev.coder_decode_batch(self._coder_streams[slot], self.probabilities, self.prob_row, expected=symbols,
-                                   workspace=self._workspaces[slot])
+            hook('coder_encode', lambda: dev.coder_encode_batch(symbols, self.probabilities, self.prob_row, self.truncated_unary_length,
+                                                                out=self._coder_streams[slot], workspace=self._workspaces[slot]))
+            hook('coder_decode', lambda: dev.coder_decode_batch(self._coder_streams[slot], self.probabilities, self.prob_row,
+                                                                expected=symbols, workspace=self._workspaces[slot]))
         elif self.coder == 'host':
             self._pinned_symbols[slot].copy_(self._symbols[slot], non_blocking=True)
         else:
@@ -420,8 +462,11 @@ class BatchCodec(object):
         ws = self._conv_ws[slot]
         t = hook('tconv1_igdn5', lambda: dev.tconv5x5s2(latents, dec.w4, d['decoder/biases_4'], dev.NORM_IGDN, dec.g[5], d['decoder/beta_5'], workspace=ws))
         t = hook('tconv2_igdn6', lambda: dev.tconv5x5s2(t, dec.w5, d['decoder/biases_5'], dev.NORM_IGDN, dec.g[6], d['decoder/beta_6'], workspace=ws))
-        (_, reconstruction, _) = dev.tconv9x9s4_luma(t, dec.w6, want_f32=False, want_u8=True, ref_u8=luminances_uint8,
-                                                     sse=self._slot_sse[slot])
+        (_, reconstruction, _) = hook('tconv3', lambda: dev.tconv9x9s4_luma(t, dec.w6, want_f32=False, want_u8=True, ref_u8=luminances_uint8,
+                                                                            sse=self._slot_sse[slot][:self.batch_size]))
+        # every conv launch of this step (analysis side too: same stream, same workspace) is behind us: its error word, and a
+        # clean workspace for the slot's next step
+        dev.conv_workspace_collect(ws, self._slot_unfinished[slot])
         dev.publish_to_host(self._slot_sse[slot], self._pinned_sse[slot])
         return reconstruction
 

@@ -59,6 +59,21 @@ inline int eae_compute_units() {
     return cached[dev];
 }
 
+// True on the one architecture the hand-written hand-off protocols of this library were validated on (gfx950: in-order
+// workgroup dispatch, sc1 write-through stores / L1-bypassing loads inside an XCD's L2). Cached per device.
+inline bool eae_is_gfx950() {
+    static int cached[16] = {0};       // 0 unknown, 1 yes, 2 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    if (cached[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+        const char* a = prop.gcnArchName;
+        cached[dev] = (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 2;
+    }
+    return cached[dev] == 1;
+}
+
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous chunk of the logical grid so that
 // neighbouring tiles (shared input halos, same image) hit the same L2. Bijective for any grid size. Speed only.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {

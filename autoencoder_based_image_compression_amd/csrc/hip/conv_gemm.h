@@ -37,6 +37,8 @@ struct ConvGemmParams {
     unsigned int* split_ws;             // conv_gemm_split.hip: zeroed workspace of SPLIT_WORDS words (left zeroed), or nullptr
     int split;                          // conv_gemm_split.hip: 1 = the last tiles of each XCD's share are cut in two
     int split_resident_waves_per_xcd;   // conv_gemm_split.hip: how many tiles get cut (the waves an XCD holds at once)
+    int split_spin_limit;               // conv_gemm_split.hip: polls of a tail for its head before it gives up (error word)
+    int split_mute_heads;               // conv_gemm_split.hip: TEST HOOK (EAE_HIP_TEST_SPLIT_MUTE): heads never publish
     // conv_gemm_split.hip, norm == NORM_LATENT / NORM_LATENT_PLAIN: the latent stage behind conv_3 (latent_body.h)
     const float* map_mean;              // [128] or nullptr
     const float* bin_widths;            // [128]
@@ -49,7 +51,8 @@ struct ConvGemmParams {
 constexpr int NORM_LATENT = 3, NORM_LATENT_PLAIN = 4;
 
 // conv_gemm_split.hip
-constexpr int SPLIT_WORDS = 256 + 8 * 1024;     // [255] timeout word; 8 x 1024 "head published" flags
+constexpr int SPLIT_WORDS = 256 + 8 * 1024;     // [255] error word (tails that gave up); 8 x 1024 "head published" flags
+constexpr int SPLIT_ERROR_WORD = 255;
 // cut: -1 = decide from the shape, 0 = whole tiles only, 1..3 = cut (sized for that many resident waves per SIMD).
 // Returns EAE_HIP_OK, or 1 when the device does not suit the kernel (nothing launched).
 int launch_split(ConvGemmParams& p, hipStream_t stream, int cut);

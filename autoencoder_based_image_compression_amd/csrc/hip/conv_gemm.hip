@@ -598,6 +598,24 @@ extern "C" int eae_hip_conv5x5s2_latent(const float* x, const float* w_packed, c
 }
 
 extern "C" uint64_t eae_hip_conv_workspace_bytes(void) { return (uint64_t)SPLIT_WORDS * sizeof(unsigned int); }
+
+// The error word of a workspace, in stream order: nothing to do when it is zero (one block, one load); otherwise the count
+// of tails that gave up goes to *error_word (added) and the whole workspace -- flags that their consumers never reset, the
+// word itself -- is zeroed again, so that the launches behind this one start from the documented state.
+__global__ __launch_bounds__(1024) void conv_workspace_collect_kernel(unsigned int* ws, unsigned int* error_word) {
+    const unsigned int e = ws[SPLIT_ERROR_WORD];
+    if (e == 0u) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < SPLIT_WORDS; i += 1024) ws[i] = 0u;
+    if (threadIdx.x == 0) { atomicAdd(error_word, e); __threadfence_system(); }
+}
+extern "C" int eae_hip_conv_workspace_collect(void* workspace, uint32_t* error_word, void* stream) {
+    if (!workspace || !error_word) return EAE_HIP_BAD_ARGUMENT;
+    hipLaunchKernelGGL(conv_workspace_collect_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream,
+                       static_cast<unsigned int*>(workspace), error_word);
+    EAE_HIP_CHECK_LAUNCH();
+    return EAE_HIP_OK;
+}
 extern "C" int eae_hip_conv5x5s2_ws(const float* x, const float* w_packed, const float* bias, int norm,
                                     const float* gamma_packed, const float* beta, float* out, int n, int h, int w_in,
                                     void* workspace, void* stream) {

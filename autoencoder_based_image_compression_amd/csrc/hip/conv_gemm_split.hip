@@ -29,7 +29,10 @@
 // than the tile quantisation it was meant to remove (transpose_conv_2: 1.105 ms with fences against 1.041 uncut).
 //
 // Workspace (cut launches only): SPLIT_WORDS uint32, zero on entry, zero again on exit (a flag is reset by its consumer),
-// so a caller zeroes it once. Launches that may run concurrently need their own workspace.
+// so a caller zeroes it once. Launches that may run concurrently need their own workspace. The one exception is the error
+// word: a tail whose head has not published within SPIN_LIMIT polls writes NOTHING, counts itself in word SPLIT_ERROR_WORD
+// and leaves its flag alone; eae_hip_conv_workspace_collect (conv_gemm.hip) hands the word to the host in stream order and
+// zeroes the workspace again. In-order dispatch makes the wait finite in practice; the timeout makes a violation loud.
 #include "conv_gemm.h"
 
 #include <cstdlib>
@@ -52,7 +55,7 @@ constexpr int ABUF = 32 * AS_STRIDE;                 // one activation buffer of
 constexpr int vec_floats(int norm) { return (norm >= NORM_LATENT ? 5 : 2) * EAE_C; }
 constexpr int QT_H = 4, QT_W = 8;                    // a wave's tile: 4 x 8 positions
 constexpr int MIN_PIECE = 4;                         // K-steps: no head or tail shorter than this
-constexpr int SPIN_LIMIT = 1 << 22;                  // ~1 s of polling: a bug, not a wait; sets the error word
+constexpr int SPIN_LIMIT = 1 << 22;                  // ~1 s of polling: a bug, not a wait; counts in the error word, no result
 
 // K-steps of head d of D on a tile of T steps: [MIN_PIECE, T - MIN_PIECE); T itself (no split) for very short tiles
 __device__ __forceinline__ int head_steps(int d, int D, int T) {
@@ -189,12 +192,20 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
         } else {
             // the tail of an interrupted tile: wait for its head (published long ago, normally), then continue the chain
+            int gave_up = 0;
             if (lane == 0) {
                 int spins = 0;
                 while (__hip_atomic_load(flags + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (++spins > SPIN_LIMIT) { p.split_ws[255] = 1u; break; }
+                    if (++spins > p.split_spin_limit) { gave_up = 1; break; }
                 }
+            }
+            // No result on a timeout: the tile keeps whatever its head parked, the error word counts the tail, and the flag is
+            // left alone (a head that publishes late would otherwise leave a stale 1 behind a reset). The host reads the
+            // word in stream order (eae_hip_conv_workspace_collect), raises, and zeroes the workspace again.
+            if (__builtin_amdgcn_readfirstlane(gave_up)) {
+                if (lane == 0) atomicAdd(p.split_ws + SPLIT_ERROR_WORD, 1u);
+                return;
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
                     __builtin_amdgcn_raw_buffer_store_b128(v, out_rsrc, park, (32 * t + 8 * g) * 4, 16);
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store of this wave has reached memory
-            if (lane == 0) __hip_atomic_store(flags + d, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0 && !p.split_mute_heads) __hip_atomic_store(flags + d, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #undef EAE_Q_PREFETCH_A
 #undef EAE_Q_STAGE_A
@@ -306,9 +317,13 @@ int eae_conv_gemm::launch_split(ConvGemmParams& p, hipStream_t stream, int cut) 
     long k = tiles / simds;                     // whole tiles per SIMD
     if (k > 3) k = 3;
     if (k < 1) k = 1;
+    // The hand-off between the two halves of a cut tile rests on what was validated on gfx950 only: workgroups dispatched in
+    // grid order (a tail only waits for a wave dispatched before it), sc1 stores / loads meeting in the XCD's L2. On any
+    // other device the launch is never cut of its own accord (whole tiles: the same bits).
+    const bool validated = eae_is_gfx950();
     bool split = cut > 0;
     if (cut > 0) k = cut > 3 ? 3 : cut;
-    if (cut < 0 && p.split_ws && p.n_phases == 1 && tiles >= simds) {
+    if (cut < 0 && validated && p.split_ws && p.n_phases == 1 && tiles >= simds) {
         // Uncut, the launch takes as long as its busiest SIMD: ceil(tiles / SIMDs) tiles; cut, tiles / SIMDs plus ~2 % for
         // the hand-offs. Only the convolutions: the tiles of the transposed ones are short (16-36 K-steps against 100), their
         // last round costs little and cutting them was measured to lose (Kodak batch 24, bursts: transpose_conv_1 0.286 ms
@@ -332,6 +347,13 @@ int eae_conv_gemm::launch_split(ConvGemmParams& p, hipStream_t stream, int cut) 
             const PhaseDesc tmp = p.phase[j]; p.phase[j] = p.phase[j - 1]; p.phase[j - 1] = tmp;
         }
     p.split = split ? 1 : 0;
+    p.split_spin_limit = SPIN_LIMIT;
+    p.split_mute_heads = 0;
+    if (split) {
+        // test hook (tests/test_gpu_conv_split.py): heads that never publish, and tails that give up after ~1 ms
+        const char* mute = std::getenv("EAE_HIP_TEST_SPLIT_MUTE");
+        if (mute && mute[0] == '1') { p.split_mute_heads = 1; p.split_spin_limit = 1 << 12; }
+    }
     p.split_resident_waves_per_xcd = (cus / 8) * 4 * (int)k;
     // one wave per item, blocks of 4 items, the 8 shares interleaved: the largest share decides the grid
     const long cnt_max = (nsp + 7) / 8 * p.n_phases;

@@ -24,11 +24,13 @@ constexpr int TM = WAVES * 32;
 constexpr int SYM_STRIDE = TM + 2;
 
 template <bool GDN_IN, bool IGDN_OUT>
-__global__ __launch_bounds__(WAVES * 64) void latent_kernel(const float* __restrict__ x, const float* __restrict__ gamma_in,
+// x, y_out, shifted_out and t_out carry no __restrict__: eae_hip_conv5x5s2_latent runs the stage IN PLACE on the convolution's
+// output for small layers (x == t_out or shifted_out); every lane loads its elements before it stores them.
+__global__ __launch_bounds__(WAVES * 64) void latent_kernel(const float* x, const float* __restrict__ gamma_in,
                                                      const float* __restrict__ beta_in, const float* __restrict__ map_mean,
                                                      const float* __restrict__ bin_widths, const float* __restrict__ gamma_out,
-                                                     const float* __restrict__ beta_out, float* __restrict__ y_out,
-                                                     float* __restrict__ shifted_out, float* __restrict__ t_out,
+                                                     const float* __restrict__ beta_out, float* y_out,
+                                                     float* shifted_out, float* t_out,
                                                      int16_t* __restrict__ symbols, unsigned int* __restrict__ nonzero,
                                                      unsigned int* __restrict__ checks, long rows, int hw) {
     __shared__ __attribute__((aligned(16))) float Xs[TM * EAE_XS_STRIDE];   // [TM][129]: x, then y / shifted in place
@@ -125,11 +127,11 @@ __global__ __launch_bounds__(WAVES * 64) void latent_kernel(const float* __restr
 
 // ---- one wavefront per 32 positions, everything in registers: latent_body.h -------------------------------------------------
 template <bool GDN_IN, bool IGDN_OUT>
-__global__ __launch_bounds__(64) void latent_wave_kernel(const float* __restrict__ x, const float* __restrict__ gamma_in,
+__global__ __launch_bounds__(64) void latent_wave_kernel(const float* x, const float* __restrict__ gamma_in,
                                                          const float* __restrict__ beta_in, const float* __restrict__ map_mean,
                                                          const float* __restrict__ bin_widths, const float* __restrict__ gamma_out,
-                                                         const float* __restrict__ beta_out, float* __restrict__ y_out,
-                                                         float* __restrict__ shifted_out, float* __restrict__ t_out,
+                                                         const float* __restrict__ beta_out, float* y_out,
+                                                         float* shifted_out, float* t_out,
                                                          int16_t* __restrict__ symbols, unsigned int* __restrict__ nonzero,
                                                          unsigned int* __restrict__ checks, long rows, int hw) {
     __shared__ __attribute__((aligned(16))) float vec[4 * EAE_C];      // beta_in | beta_out | map_mean | bin_widths
@@ -205,11 +207,11 @@ __device__ __forceinline__ f32x16 squares_for_mfma(const f32x16& v) {
 }
 
 template <bool GDN_IN, bool IGDN_OUT>
-__global__ __launch_bounds__(256) void latent_quarter_kernel(const float* __restrict__ x, const float* __restrict__ gamma_in,
+__global__ __launch_bounds__(256) void latent_quarter_kernel(const float* x, const float* __restrict__ gamma_in,
                                                              const float* __restrict__ beta_in, const float* __restrict__ map_mean,
                                                              const float* __restrict__ bin_widths, const float* __restrict__ gamma_out,
-                                                             const float* __restrict__ beta_out, float* __restrict__ y_out,
-                                                             float* __restrict__ shifted_out, float* __restrict__ t_out,
+                                                             const float* __restrict__ beta_out, float* y_out,
+                                                             float* shifted_out, float* t_out,
                                                              int16_t* __restrict__ symbols, unsigned int* __restrict__ nonzero,
                                                              unsigned int* __restrict__ checks, long rows, int hw) {
     __shared__ __attribute__((aligned(16))) float vec[4 * EAE_C];          // beta_in | beta_out | map_mean | bin_widths

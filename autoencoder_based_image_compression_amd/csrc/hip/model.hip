@@ -28,13 +28,19 @@ constexpr size_t W1 = 82 * C, W5x5 = 25 * C * C, GAMMA = C * C, VEC = C, W6 = 9 
 inline size_t align_up(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 
 struct ScratchLayout {
-    size_t conv_ws, a, b, c, total;
+    size_t conv_ws, status, a, b, c, total;      // status: one word behind the conv workspace, same place in both layouts
 };
+// what the launches of one call leave in the conv workspace's error word goes to the block's status word (zeroed with the
+// workspace at the start of every call; read by eae_hip_transform_status); the workspace is all zero again afterwards
+int collect(char* base, const ScratchLayout& s, void* stream) {
+    return eae_hip_conv_workspace_collect(base + s.conv_ws, reinterpret_cast<uint32_t*>(base + s.status), stream);
+}
 // encode: a = conv_1 output [n][h/4][w/4][128], b = conv_2 output [n][h/8][w/8][128]
 ScratchLayout encode_layout(int n, int h, int w) {
     ScratchLayout s{};
     size_t off = align_up(eae_hip_conv_workspace_bytes());
     s.conv_ws = 0;
+    s.status = off; off += 256;
     s.a = off; off += align_up((size_t)n * (h / 4) * (w / 4) * C * sizeof(float));
     s.b = off; off += align_up((size_t)n * (h / 8) * (w / 8) * C * sizeof(float));
     s.total = off;
@@ -45,6 +51,7 @@ ScratchLayout decode_layout(int n, int h, int w) {
     ScratchLayout s{};
     size_t off = align_up(eae_hip_conv_workspace_bytes());
     s.conv_ws = 0;
+    s.status = off; off += 256;
     s.a = off; off += align_up((size_t)n * h * w * C * sizeof(float));
     s.b = off; off += align_up((size_t)n * 2 * h * 2 * w * C * sizeof(float));
     s.c = off; off += align_up((size_t)n * 4 * h * 4 * w * C * sizeof(float));
@@ -156,7 +163,7 @@ extern "C" int eae_hip_encode(const eae_hip_model* m, const uint8_t* images, int
     const ScratchLayout s = encode_layout(n, h, w);
     if (scratch_bytes < s.total) return EAE_HIP_BAD_ARGUMENT;
     char* base = static_cast<char*>(scratch);
-    hipError_t e = hipMemsetAsync(base + s.conv_ws, 0, eae_hip_conv_workspace_bytes(), (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(base + s.conv_ws, 0, s.status + 256, (hipStream_t)stream);   // workspace + status word
     if (e != hipSuccess) return (int)e;
     float* a = reinterpret_cast<float*>(base + s.a);
     float* b = reinterpret_cast<float*>(base + s.b);
@@ -164,8 +171,18 @@ extern "C" int eae_hip_encode(const eae_hip_model* m, const uint8_t* images, int
     if (rc) return rc;
     rc = eae_hip_conv5x5s2_ws(a, m->w2, m->b2, EAE_NORM_GDN, m->g2, m->be2, b, n, h / 4, w / 4, base + s.conv_ws, stream);
     if (rc) return rc;
-    if (m->learned) return eae_hip_conv5x5s2_ws(b, m->w3, m->b3, EAE_NORM_NONE, nullptr, nullptr, latents, n, h / 8, w / 8, base + s.conv_ws, stream);
-    return eae_hip_conv5x5s2_ws(b, m->w3, m->b3, EAE_NORM_GDN, m->g3, m->be3, latents, n, h / 8, w / 8, base + s.conv_ws, stream);
+    if (m->learned) rc = eae_hip_conv5x5s2_ws(b, m->w3, m->b3, EAE_NORM_NONE, nullptr, nullptr, latents, n, h / 8, w / 8, base + s.conv_ws, stream);
+    else rc = eae_hip_conv5x5s2_ws(b, m->w3, m->b3, EAE_NORM_GDN, m->g3, m->be3, latents, n, h / 8, w / 8, base + s.conv_ws, stream);
+    if (rc) return rc;
+    return collect(base, s, stream);
+}
+
+extern "C" int eae_hip_transform_status(void* scratch, uint32_t* host_count, void* stream) {
+    if (!scratch || !host_count) return EAE_HIP_BAD_ARGUMENT;
+    char* word = static_cast<char*>(scratch) + align_up(eae_hip_conv_workspace_bytes());
+    hipError_t e = hipMemcpyAsync(host_count, word, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    return (int)e;
 }
 
 extern "C" int eae_hip_decode(const eae_hip_model* m, const float* quantized_latents, int n, int h_latent, int w_latent,
@@ -176,7 +193,7 @@ extern "C" int eae_hip_decode(const eae_hip_model* m, const float* quantized_lat
     const ScratchLayout s = decode_layout(n, h_latent, w_latent);
     if (scratch_bytes < s.total) return EAE_HIP_BAD_ARGUMENT;
     char* base = static_cast<char*>(scratch);
-    hipError_t e = hipMemsetAsync(base + s.conv_ws, 0, eae_hip_conv_workspace_bytes(), (hipStream_t)stream);
+    hipError_t e = hipMemsetAsync(base + s.conv_ws, 0, s.status + 256, (hipStream_t)stream);   // workspace + status word
     if (e != hipSuccess) return (int)e;
     float* a = reinterpret_cast<float*>(base + s.a);
     float* b = reinterpret_cast<float*>(base + s.b);
@@ -191,6 +208,8 @@ extern "C" int eae_hip_decode(const eae_hip_model* m, const float* quantized_lat
     rc = eae_hip_tconv5x5s2_ws(t, m->w4, m->b4, EAE_NORM_IGDN, m->g5, m->be5, b, n, h_latent, w_latent, base + s.conv_ws, stream);
     if (rc) return rc;
     rc = eae_hip_tconv5x5s2_ws(b, m->w5, m->b5, EAE_NORM_IGDN, m->g6, m->be6, c, n, 2 * h_latent, 2 * w_latent, base + s.conv_ws, stream);
+    if (rc) return rc;
+    rc = collect(base, s, stream);
     if (rc) return rc;
     return eae_hip_tconv9x9s4_luma(c, m->w6, out_f32, out_u8, ref_u8, sse, n, 4 * h_latent, 4 * w_latent, stream);
 }

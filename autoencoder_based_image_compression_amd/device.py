@@ -82,6 +82,37 @@ class Model(object):
         _check(_native.hip().eae_hip_model_create(ctypes.cast(pointers, ctypes.c_void_p), 1 if self.are_bin_widths_learned else 0,
                                                   ctypes.byref(handle)), 'eae_hip_model_create')
         self._handle = handle
+        # the failure word of a call sits behind the conv workspace at the head of its scratch block (eae_hip_transform_status);
+        # calls are asynchronous, so the word is published to pinned memory behind each call and looked at later (`check`)
+        self._status_offset = (int(_native.hip().eae_hip_conv_workspace_bytes()) + 255)//256*256
+        self._pending = []          # (event, pinned word) of calls nobody has looked at yet
+        self._free_words = []
+
+    def _track(self, scratch):
+        word = scratch[self._status_offset:self._status_offset + 4].view(torch.int32)
+        pinned = self._free_words.pop() if self._free_words else torch.zeros(1, dtype=torch.int32).pin_memory()
+        publish_to_host(word, pinned)
+        event = torch.cuda.Event()
+        event.record()
+        self._pending.append((event, pinned))
+
+    def check(self, wait=False):
+        """Raises `SplitHandOffTimeout` if an encode / decode call that has completed (wait=True: any call issued so far) left
+        tiles unfinished (include/eae_hip.h: eae_hip_conv_workspace_collect) -- its outputs are then invalid. Every encode /
+        decode looks at the completed calls first; the reference-shaped `sess.run` nodes wait, right after their device -> host copy."""
+        (still, failed) = ([], 0)
+        for (event, pinned) in self._pending:
+            if wait:
+                event.synchronize()
+            if event.query():
+                failed += int(pinned[0])
+                self._free_words.append(pinned)
+            else:
+                still.append((event, pinned))
+        self._pending = still
+        if failed:
+            raise SplitHandOffTimeout('{} tiles of a cut conv launch were not handed over (eae_hip_transform_status): the outputs '
+                                      'of that call are invalid'.format(failed))
 
     def close(self):
         if getattr(self, '_handle', None):
@@ -102,10 +133,14 @@ class Model(object):
         nbytes = int(_native.hip().eae_hip_encode_scratch_bytes(n, h, wd))
         if nbytes == 0:
             raise ValueError('The image size is not divisible by the product of the three strides.')
+        if images_u8.device != self.device:
+            raise HipError('images on {0} but the model lives on {1}'.format(images_u8.device, self.device))
+        self.check()
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=images_u8.device)
         latents = torch.empty((n, h//16, wd//16, NB_MAPS), dtype=torch.float32, device=images_u8.device)
         _check(_native.hip().eae_hip_encode(self._handle, _p(images_u8), n, h, wd, _p(latents), _p(scratch), nbytes, _stream(images_u8)),
                'eae_hip_encode')
+        self._track(scratch)
         return latents
 
     def decode(self, quantized_latents, want_f32=False, want_u8=True, ref_u8=None, sse=None):
@@ -113,6 +148,9 @@ class Model(object):
         `tls.cast_bt601` of eae/batching.py:49-53 (+ the squared error of tls.psnr_2d) in one call."""
         (n, h, wd, c) = quantized_latents.shape
         d = quantized_latents.device
+        if d != self.device:
+            raise HipError('latents on {0} but the model lives on {1}'.format(d, self.device))
+        self.check()
         nbytes = int(_native.hip().eae_hip_decode_scratch_bytes(n, h, wd))
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=d)
         out_f32 = torch.empty((n, 16*h, 16*wd), dtype=torch.float32, device=d) if want_f32 else None
@@ -121,6 +159,7 @@ class Model(object):
             sse = torch.zeros(n, dtype=torch.int64, device=d)
         _check(_native.hip().eae_hip_decode(self._handle, _p(quantized_latents), n, h, wd, _p(out_f32), _p(out_u8), _p(ref_u8), _p(sse),
                                             _p(scratch), nbytes, _stream(quantized_latents)), 'eae_hip_decode')
+        self._track(scratch)
         return out_f32, out_u8, sse
 
 
@@ -139,22 +178,36 @@ def conv9x9s4_u8(x_u8, w_packed, bias, gamma_packed=None, beta=None, out=None):
 
 def conv_workspace(device):
     """Zeroed scratch that lets conv5x5s2 / tconv5x5s2 cut the last tiles of a launch (include/eae_hip.h): every launch leaves
-    it zeroed, so one allocation serves any number of launches that cannot overlap each other (one per stream / batch slot)."""
+    it zeroed, so one allocation serves any number of launches that cannot overlap each other (one per stream / batch slot).
+    Whoever passes one to a launch owns its error word: `conv_workspace_collect` behind the launches, and a look at the word
+    before their outputs are trusted (codec.BatchCodec does both per batch)."""
     return torch.zeros(int(_native.hip().eae_hip_conv_workspace_bytes())//4, dtype=torch.int32, device=device)
 
 
+class SplitHandOffTimeout(HipError):
+    """A cut conv launch left tiles unfinished (include/eae_hip.h: eae_hip_conv_workspace_collect): its outputs are invalid."""
+
+
+def conv_workspace_collect(workspace, error_word):
+    """Stream-ordered: adds the number of tiles the launches on `workspace` left unfinished since the last collect to
+    `error_word` (int32 device tensor of one element, or a pinned host one) and restores the all-zero workspace."""
+    if error_word.numel() != 1 or error_word.element_size() != 4:
+        raise HipError('`error_word` must be one 32-bit word')
+    word = error_word.data_ptr() if not error_word.is_cuda else _p(error_word)
+    _check(_native.hip().eae_hip_conv_workspace_collect(_p(workspace), word, _stream(workspace)), 'eae_hip_conv_workspace_collect')
+
+
 def conv5x5s2(x, w_packed, bias, norm=NORM_NONE, gamma_packed=None, beta=None, out=None, workspace=None):
-    """conv_2 / conv_3 + bias_add (+ gdn). workspace: `conv_workspace` (the launch may cut its last tiles: same bits, no
-    partly empty last round); None -> a fresh one per call; False -> the entry point without a workspace."""
+    """conv_2 / conv_3 + bias_add (+ gdn). workspace: a `conv_workspace` (the launch may cut its last tiles: same bits, no
+    partly empty last round; the caller collects its error word, see `conv_workspace_collect`); None / False -> the entry
+    point without a workspace (whole tiles only, nothing to collect)."""
     (n, h, wd, c) = x.shape
     if out is None:
         out = torch.empty((n, h//2, wd//2, NB_MAPS), dtype=torch.float32, device=x.device)
-    if workspace is False:
+    if workspace is None or workspace is False:
         _check(_native.hip().eae_hip_conv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream(x)),
                'eae_hip_conv5x5s2')
         return out
-    if workspace is None:
-        workspace = conv_workspace(x.device)
     _check(_native.hip().eae_hip_conv5x5s2_ws(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd,
                                                   _p(workspace), _stream(x)), 'eae_hip_conv5x5s2_ws')
     return out
@@ -173,12 +226,10 @@ def tconv5x5s2(x, w_packed, bias, norm=NORM_NONE, gamma_packed=None, beta=None, 
     (n, h, wd, c) = x.shape
     if out is None:
         out = torch.empty((n, 2*h, 2*wd, NB_MAPS), dtype=torch.float32, device=x.device)
-    if workspace is False:
+    if workspace is None or workspace is False:
         _check(_native.hip().eae_hip_tconv5x5s2(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd, _stream(x)),
                'eae_hip_tconv5x5s2')
         return out
-    if workspace is None:
-        workspace = conv_workspace(x.device)
     _check(_native.hip().eae_hip_tconv5x5s2_ws(_p(x), _p(w_packed), _p(bias), norm, _p(gamma_packed), _p(beta), _p(out), n, h, wd,
                                                    _p(workspace), _stream(x)), 'eae_hip_tconv5x5s2_ws')
     return out
@@ -309,7 +360,7 @@ def conv5x5s2_latent(x, w_packed, bias, bin_widths, map_mean=None, gdn_in=None, 
     (g_in, b_in) = gdn_in if fixed else (None, None)
     (g_out, b_out) = igdn_out if fixed else (None, None)
     if workspace is None:
-        workspace = conv_workspace(d)
+        workspace = False          # never cut without a workspace whose owner collects its error word
     _check(_native.hip().eae_hip_conv5x5s2_latent(_p(x), _p(w_packed), _p(bias), _p(g_in), _p(b_in), _p(map_mean), _p(bin_widths), _p(g_out),
                                                   _p(b_out), _p(y), _p(shifted), _p(t), _p(symbols), _p(flags), _p(checks), n, h, wd,
                                                   _p(workspace) if workspace is not False else None, _stream(x)),

@@ -55,8 +55,9 @@ class EntropyAutoencoder(object):
         as_uint8 = batch_float32.astype(numpy.uint8)
         if not numpy.array_equal(as_uint8.astype(batch_float32.dtype), batch_float32):
             raise ValueError('`node_visible_units` must be fed 8-bit luminance values cast to float (eae/batching.py:95).')
-        y = self._encoder(bk.to_device(as_uint8[..., 0]))
-        return bk.to_host(y)
+        y = bk.to_host(self._encoder(bk.to_device(as_uint8[..., 0])))
+        self._encoder.check()            # the copy above waited for the launches: a failed hand-off raises here, not later
+        return y
 
     def encode_uint8_device(self, luminances_uint8_device):
         """Device-resident entry (no host copies): uint8 [N,H,W] tensor -> float32 latents tensor."""

@@ -28,7 +28,9 @@ class IsolatedDecoder(object):
         if self._decoder is None:
             raise RuntimeError('Attempting to use uninitialized value decoder/weights_4: call `initialization` first.')
         (rec, _, _) = self._decoder(bk.to_device(quantized_y_float32, 'float32'), want_float=True, want_uint8=False)
-        return bk.to_host(rec)[..., None]   # (batch, h_in, w_in, 1) float32, as the TF node returns
+        rec = bk.to_host(rec)[..., None]   # (batch, h_in, w_in, 1) float32, as the TF node returns
+        self._decoder.check()
+        return rec
 
     def decode_device(self, quantized_y_device, reference_uint8_device=None, sse=None):
         """Device-resident entry: returns (uint8 reconstruction tensor, per-image squared error or None)."""

@@ -31,10 +31,24 @@ class DeviceEncoder(object):
         self.w2 = dev.pack_conv_weights(self.v['encoder/weights_2'])
         self.w3 = dev.pack_conv_weights(self.v['encoder/weights_3'])
         self.g = {i: dev.pack_gamma(self.v['encoder/gamma_{}'.format(i)]) for i in ((1, 2) if are_bin_widths_learned else (1, 2, 3))}
-        # the same variables behind the library's whole-path entry point (include/eae_hip.h: eae_hip_encode); the per-layer
-        # layouts above are what codec.BatchCodec chains itself (it fuses gdn_3 into the latent stage and times every launch)
-        with torch.cuda.device(self.device if self.device.index is not None else torch.cuda.current_device()):
-            self.model = dev.Model({name: variables[name] for name in names}, are_bin_widths_learned)
+        # the same variables behind the library's whole-path entry point (include/eae_hip.h: eae_hip_encode), built on first use:
+        # the per-layer layouts above are what codec.BatchCodec chains itself (it fuses gdn_3 into the latent stage and times
+        # every launch) and a codec that is never called image by image should not pay for a second copy of the weights
+        self._model = None
+        self._model_variables = {name: variables[name] for name in names}
+
+    @property
+    def model(self):
+        if self._model is None:
+            with torch.cuda.device(self.device if self.device.index is not None else torch.cuda.current_device()):
+                self._model = dev.Model(self._model_variables, self.are_bin_widths_learned)
+            self._model_variables = None
+        return self._model
+
+    def check(self):
+        """Waits for the calls issued so far and raises if one of them left tiles unfinished (device.Model.check)."""
+        if self._model is not None:
+            self._model.check(wait=True)
 
     def __call__(self, luminances_uint8):
         """uint8 [N,H,W] or [N,H,W,1] (device) -> float32 latents [N,H/16,W/16,128] (device)."""
@@ -64,8 +78,20 @@ class DeviceDecoder(object):
         self.w5 = dev.pack_tconv_weights(self.v['decoder/weights_5'])
         self.w6 = dev.pack_tconv9x9s4_weights(self.v['decoder/weights_6'])
         self.g = {i: dev.pack_gamma(self.v['decoder/gamma_{}'.format(i)]) for i in ((5, 6) if are_bin_widths_learned else (4, 5, 6))}
-        with torch.cuda.device(self.device if self.device.index is not None else torch.cuda.current_device()):
-            self.model = dev.Model({name: variables[name] for name in names}, are_bin_widths_learned)      # eae_hip_decode
+        self._model = None           # eae_hip_decode, built on first use (see DeviceEncoder)
+        self._model_variables = {name: variables[name] for name in names}
+
+    @property
+    def model(self):
+        if self._model is None:
+            with torch.cuda.device(self.device if self.device.index is not None else torch.cuda.current_device()):
+                self._model = dev.Model(self._model_variables, self.are_bin_widths_learned)
+            self._model_variables = None
+        return self._model
+
+    def check(self):
+        if self._model is not None:
+            self._model.check(wait=True)
 
     def __call__(self, quantized_y, want_float=False, want_uint8=True, reference_uint8=None, sse=None):
         """float32 [N,h,w,128] (device) -> (float32 [N,16h,16w] or None, uint8 [N,16h,16w] or None, sse or None)."""

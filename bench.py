@@ -29,7 +29,7 @@ def parse_args(argv=None):
     parser.add_argument('--gpus', type=int, default=1,
                         help='ranks = GPUs of this node. N > 1 without a launcher (no WORLD_SIZE in the environment): this '
                              'process starts N rank processes itself and waits for them; under torch.distributed.run it must '
-                             'equal WORLD_SIZE')
+                             'equal WORLD_SIZE. configs[3] of BASELINE.json is `--gpus 8 --height 256 --width 256 --batch 64`')
     parser.add_argument('--steps', type=int, default=100)
     parser.add_argument('--warmup', type=int, default=10)
     parser.add_argument('--min-seconds', type=float, default=1.0,
@@ -44,31 +44,35 @@ def parse_args(argv=None):
                              'give a low-entropy latent at 1.0; the `realistic_entropy` side figures repeat the run at smaller '
                              'widths (more bits per pixel for the coder)')
     parser.add_argument('--no-cpu-baseline', action='store_true')
-    parser.add_argument('--no-single-image', action='store_true', help='skip the side measurements (one image per step, overlapped mode, realistic entropy, host coder)')
+    parser.add_argument('--no-single-image', '--no-side', dest='no_single_image', action='store_true',
+                        help='skip the side measurements (one image per step, other shapes, PCIe-inclusive, realistic entropy, host coder)')
     parser.add_argument('--coder', choices=('device', 'host'), default='device',
                         help='device: the coder kernels on side streams (default). host: one device -> host copy of the symbols '
                              'per batch and the host C-ABI coder on a thread pool (the shape BASELINE.json sketches)')
     parser.add_argument('--coder-threads', type=int, default=0, help='host coder threads (0 = usable CPUs - 2)')
-    parser.add_argument('--coder-streams', type=int, default=int(os.environ.get('EAE_CODER_STREAMS', '3')),
-                        help='batches whose entropy coding may be in flight at once (each on its own HIP stream). 3: measured equal to 2 at '
-                             'the headline entropy and 9-14 %% faster at 0.9-1.4 bits per pixel; 4 costs the transforms 12 %%')
-    parser.add_argument('--transform-streams', type=int, default=int(os.environ.get('EAE_TRANSFORM_STREAMS', '1')),
-                        help='1 (default): the transforms of consecutive batches run back to back on one stream, so that the HIP '
-                             'events around a launch time that kernel alone (the roofline figures). 2-3: consecutive batches '
-                             'alternate between private streams and their kernels overlap (fills the tails: +6-8 %% whole-job '
-                             'throughput with --coder-streams 3), but a launch then shares the GPU and its duration says little')
+    parser.add_argument('--coder-streams', type=int, default=int(os.environ.get('EAE_CODER_STREAMS', '0')),
+                        help='batches whose entropy coding may be in flight at once (each on its own HIP stream). 0 (default): '
+                             'decided from the shape (`auto_coder_streams`: a map is one serial chain, so large maps need more '
+                             'batches in flight for the transforms to cover it)')
+    parser.add_argument('--transform-streams', type=int, default=int(os.environ.get('EAE_TRANSFORM_STREAMS', '2')),
+                        help='2 (default, the product mode): consecutive batches alternate between two private streams, so the '
+                             'tail of one batch\'s kernel is filled by the next batch\'s. 1: the transforms of consecutive batches '
+                             'back to back on one stream (what the `roofline` leg always uses, so that the HIP events around a '
+                             'launch time that kernel alone)')
     parser.add_argument('--fuse-latent', action='store_true',
                         help='the latent stage as the epilogue of the conv_3 launch (codec.BatchCodec(fuse_latent=True)); the roofline '
                              'figure then counts gdn_3 and inverse_gdn_4 in that launch')
-    parser.add_argument('--graphs', action='store_true',
-                        help='replay one captured hipGraph per step instead of launching kernel by kernel (small batches: the '
-                             'launch thread is the bottleneck there). No per-launch events, so no roofline figures')
+    parser.add_argument('--graphs', dest='graphs', action='store_true', default=True,
+                        help='(default) replay three captured hipGraphs per step instead of launching kernel by kernel')
+    parser.add_argument('--no-graphs', dest='graphs', action='store_false')
     parser.add_argument('--seed-offset', type=int, default=0, help='rank r codes the images of seed 1000 + r + this (tests)')
     parser.add_argument('--dry-launch', action='store_true',
                         help='rendezvous check only (no GPU): every rank joins a gloo group, one all-reduce, rank 0 prints n_gpus')
     args = parser.parse_args(argv)
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         parser.error('--gpus and --steps must be at least 1, --warmup at least 0')
+    if args.coder == 'host':
+        args.graphs = False          # the host coder's copy is not part of a captured step
     return args
 
 
@@ -84,6 +88,8 @@ def launch_ranks(args, argv):
         env = dict(os.environ)
         env.update({'RANK': str(rank), 'LOCAL_RANK': str(rank), 'WORLD_SIZE': str(args.gpus), 'LOCAL_WORLD_SIZE': str(args.gpus),
                     'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'EAE_BENCH_SPAWNED': '1'})
+        # The pool's host driver only supports dmabuf IPC: with the legacy mode RCCL's intra-node transport fails in
+        # hipIpcGetMemHandle ("invalid argument"). The image exports this already; a caller's own setting wins.
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
     code = 0
@@ -113,9 +119,9 @@ if __name__ == '__main__':
         sys.exit(launch_ranks(_ARGS, sys.argv[1:]))
 
 # The HIP runtime multiplexes streams onto 4 hardware queues by default; streams that land on the same queue serialise.
-# With a transform stream, 2-3 coder streams and optional extra transform streams that aliasing was measured to cost up to
-# 30 % (and the one-image-per-step leg keeps 14 streams busy). Must be set before the runtime initialises; an explicit
-# setting of the caller wins.
+# With two transform streams, 3-8 coder streams and copy streams that aliasing was measured to cost up to 30 % (and the
+# one-image-per-step leg keeps 14 streams busy). Must be set before the runtime initialises; an explicit setting of the
+# caller wins.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 
 import numpy          # noqa: E402
@@ -131,13 +137,18 @@ from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as
 from autoencoder_based_image_compression_amd.kodak.lossless import stats as lossless_stats   # noqa: E402
 from autoencoder_based_image_compression_amd.kodak.tools import tools as tls   # noqa: E402
 
-H_IN, W_IN = 512, 768          # Kodak luminance (datasets/kodak/kodak.py:10-83: uint8 (24, 512, 768))
 IDX_MAP_EXCEPTION = 67         # lossless/results/1_10000/training_index_10/idx_map_exception.pkl
 TRUNCATED_UNARY_LENGTH = 10    # collecting_stats_eae_extra.py:44
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_TBS = 8.0             # MI355X_MICROARCH.md: HBM3E
 # bin widths of the `realistic_entropy` side figures: with the random-init weights of `synthetic_model` they put the rate
-# near 1 and 2 bits per pixel, the range SURVEY.md 8(d) expects from trained models (the rates are measured and printed)
-REALISTIC_BIN_WIDTHS = (0.25, 0.125)
+# near 1, 1.4, 2 and 3 bits per pixel, the range SURVEY.md 8(d) expects from trained models (the rates are measured and printed)
+REALISTIC_BIN_WIDTHS = (0.25, 0.125, 0.05, 0.0125)
+# Algorithmic work of every timed launch per INPUT pixel: FLOP (pipeline.FLOP_PER_PIXEL) and HBM bytes of the
+# layer-boundary model (fp32 activations in and out once, uint8 image / reconstruction, int16 symbols)
+BYTES_PER_PIXEL = {'conv1_gdn1': 1 + 32, 'conv2_gdn2': 32 + 8, 'conv3': 8 + 2, 'latent': 2 + 2 + 1, 'tconv1_igdn5': 2 + 8,
+                   'tconv2_igdn6': 8 + 32, 'tconv3': 32 + 1 + 1}
+GEMM_LAUNCHES = ('conv2_gdn2', 'conv3', 'tconv1_igdn5', 'tconv2_igdn6')
 
 
 def usable_cpus():
@@ -170,6 +181,15 @@ def synthetic_model(bin_width=1.):
     return v
 
 
+def auto_coder_streams(h, w):
+    """Batches of coder work to keep in flight. A feature map is ONE serial chain (its symbols x ~0.3-0.4 us each to encode,
+    the same again to decode, stretched 2-4x next to the transforms), whatever the batch; the transforms of a batch take a
+    time that grows with the batch instead. Kodak-sized maps (1,536 symbols) hide behind three batches; a 2048x2048 image
+    has maps of 16,384 symbols and needs about eight."""
+    map_size = (h//16)*(w//16)
+    return int(min(8, max(3, 3 + map_size//3072)))
+
+
 class Context(object):
     """What every leg of the benchmark shares: the process group, the device, the CPU budget."""
 
@@ -197,24 +217,30 @@ class Context(object):
         return tensor
 
 
-def run_pipeline(ctx, batch, steps, warmup, variables, coder='device', coder_streams=2, transform_streams=1, use_graphs=False,
-                 min_seconds=0., max_blocks=1, record_gemm=False, coder_events=False):
-    """Builds the resident state for `batch` images per step (codec.BatchCodec: weights, tables, per-slot buffers), runs
-    `warmup` untimed steps, then BLOCKS of exactly `steps` timed steps -- each block bracketed by barrier + synchronize on
-    both sides, its wall time the MAX over ranks -- until `min_seconds` have been timed (at most `max_blocks` blocks; the
+def run_pipeline(ctx, batch, steps, warmup, variables, h, w, coder='device', coder_streams=3, transform_streams=1, use_graphs=False,
+                 min_seconds=0., max_blocks=1, record=False, coder_events=False, pcie=False):
+    """Builds the resident state for `batch` images of h x w per step (codec.BatchCodec: weights, tables, per-slot buffers),
+    runs `warmup` untimed steps, then BLOCKS of exactly `steps` timed steps -- each block bracketed by barrier + synchronize
+    on both sides, its wall time the MAX over ranks -- until `min_seconds` have been timed (at most `max_blocks` blocks; the
     count is the same on every rank because it is decided from the all-reduced times). Everything up to the first barrier
-    is outside the timed region."""
+    is outside the timed region.
+    record: HIP events around every named launch of the step (launch-by-launch path, one transform stream: a launch then has
+    the GPU to itself apart from the coder's side streams). pcie: the images of every step come from pinned host memory (uint8,
+    one async copy on a copy stream) and the uint8 reconstructions go back to pinned host memory (the feed / fetch of the
+    reference's `sess.run`, eae/batching.py:95-99, 49-53)."""
     args = ctx.args
     (device, world, rank) = (ctx.device, ctx.world, ctx.rank)
-    images = torch.from_numpy(synthetic_images(1000 + rank + args.seed_offset, batch, H_IN, W_IN)).to(device)
+    images_host = torch.from_numpy(synthetic_images(1000 + rank + args.seed_offset, batch, h, w))
+    images = images_host.to(device)
     bin_widths = variables[var.BIN_WIDTHS_NAME]
     # statistics that feed the coder, from this build's own a26/a27 path on the first batch (lossless/stats.py:306, :13-68)
     encoder = pipeline.DeviceEncoder(variables, False, device)
     y0 = encoder(images)
     map_mean_host = dev.map_means(y0).cpu().numpy()
     probabilities = lossless_stats.compute_binary_probabilities(y0.cpu().numpy(), bin_widths, map_mean_host, TRUNCATED_UNARY_LENGTH)
+    encoder.check()
     del y0, encoder
-    gemm_events = []            # (start, stop, launch name) around every conv_gemm launch of the timed region
+    events = []            # (start, stop, launch name) around every named launch of the timed region
     recording = [False]
 
     def timed_launch(name, fn):
@@ -224,64 +250,103 @@ def run_pipeline(ctx, batch, steps, warmup, variables, coder='device', coder_str
         a.record()
         out = fn()
         b.record()
-        gemm_events.append((a, b, name))
+        events.append((a, b, name))
         return out
 
     coder_mode = 'none' if os.environ.get('EAE_BENCH_NO_CODER') else coder      # 'none': diagnostic only
     coder_threads = args.coder_threads if args.coder_threads > 0 else max(1, ctx.cores//max(world, 1) - 2)
-    with codec.BatchCodec(variables, False, bin_widths, map_mean_host, probabilities, IDX_MAP_EXCEPTION, batch, H_IN, W_IN,
-                          device=device, nb_in_flight=coder_streams, launch_hook=timed_launch if record_gemm else None,
+    with codec.BatchCodec(variables, False, bin_widths, map_mean_host, probabilities, IDX_MAP_EXCEPTION, batch, h, w,
+                          device=device, nb_in_flight=coder_streams, launch_hook=timed_launch if record else None,
                           coder=coder_mode, host_coder_threads=coder_threads, nb_transform_streams=transform_streams,
-                          use_graphs=use_graphs, time_coder=coder_events, fuse_latent=args.fuse_latent) as the_codec:
+                          use_graphs=use_graphs, time_coder=coder_events, fuse_latent=args.fuse_latent,
+                          keep_reconstruction=pcie) as the_codec:
+        if pcie:
+            pinned_in = images_host.pin_memory()
+            depth = the_codec.nb_slots
+            staging = [torch.empty_like(images) for _ in range(depth)]
+            pinned_out = [torch.empty((batch, h, w), dtype=torch.uint8).pin_memory() for _ in range(depth)]
+            (h2d, d2h) = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+            fetched = [None]*depth          # event behind the device -> host copy that last read slot k's buffers
+            counter = [0]
+
+            def submit():
+                k = counter[0] % depth
+                counter[0] += 1
+                if fetched[k] is not None:
+                    fetched[k].synchronize()          # long done: the slot's previous reconstruction is on the host
+                with torch.cuda.stream(h2d):
+                    staging[k].copy_(pinned_in, non_blocking=True)
+                    fed = torch.cuda.Event()
+                    fed.record()
+                torch.cuda.current_stream().wait_event(fed)
+                ticket = the_codec.submit(staging[k])
+                with torch.cuda.stream(d2h):
+                    d2h.wait_event(ticket.decoded_event)
+                    pinned_out[k].copy_(ticket.reconstruction_uint8, non_blocking=True)
+                    fetched[k] = torch.cuda.Event()
+                    fetched[k].record()
+                return ticket
+        else:
+            def submit():
+                return the_codec.submit(images)
         for _ in range(warmup):
-            the_codec.submit(images)
+            submit()
         the_codec.drain()
         # the launch thread allocates only short-lived wrappers: keep the cyclic collector (a 30 ms pause every ~75 steps) out of it
         gc.collect()
         gc.disable()
-        recording[0] = True
-        block_seconds = []
-        stats = torch.zeros(4, dtype=torch.float64, device=device)
-        coder_ms = []
-        while True:
-            ctx.barrier()
-            t0 = time.perf_counter()
-            tickets = [the_codec.submit(images) for _ in range(steps)]
-            the_codec.drain()
-            results = [t.result() for t in tickets]          # raises here if any map of any batch failed
-            # the path's only exchange step: sum the rate / PSNR accumulators over ranks
-            block_stats = torch.tensor([float(sum(int(r['nb_bits'].sum()) for r in results)), float(sum(int(r['sse'].sum()) for r in results)),
-                                        float(sum(int(r['nb_deads'].sum()) for r in results)), float(steps*batch)],
-                                       dtype=torch.float64, device=device)
-            ctx.all_reduce(block_stats, 'SUM')
-            ctx.barrier()
-            elapsed = time.perf_counter() - t0
-            te = ctx.all_reduce(torch.tensor([elapsed], dtype=torch.float64, device=device), 'MAX')
-            block_seconds.append(float(te.item()))
-            stats += block_stats
-            coder_ms.extend(t.coder_ms() for t in tickets if coder_events)
-            if sum(block_seconds) >= min_seconds or len(block_seconds) >= max_blocks:
-                break
-        gc.enable()
-    ordered = sorted(block_seconds)
-    median = ordered[(len(ordered) - 1)//2]      # an actual block (the lower median when the count is even)
-    return {'elapsed': median, 'block_seconds': block_seconds, 'stats': stats, 'gemm_events': gemm_events,
+        try:
+            recording[0] = True
+            (block_seconds, block_cpu) = ([], [])
+            stats = torch.zeros(4, dtype=torch.float64, device=device)
+            coder_ms = []
+            while True:
+                ctx.barrier()
+                t0 = time.perf_counter()
+                c0 = time.process_time()
+                tickets = [submit() for _ in range(steps)]
+                the_codec.drain()
+                results = [t.result() for t in tickets]          # raises here if any map of any batch failed
+                # the path's only exchange step: sum the rate / PSNR accumulators over ranks
+                block_stats = torch.tensor([float(sum(int(r['nb_bits'].sum()) for r in results)), float(sum(int(r['sse'].sum()) for r in results)),
+                                            float(sum(int(r['nb_deads'].sum()) for r in results)), float(steps*batch)],
+                                           dtype=torch.float64, device=device)
+                ctx.all_reduce(block_stats, 'SUM')
+                ctx.barrier()
+                elapsed = time.perf_counter() - t0
+                cpu = time.process_time() - c0
+                te = ctx.all_reduce(torch.tensor([elapsed], dtype=torch.float64, device=device), 'MAX')
+                block_seconds.append(float(te.item()))
+                block_cpu.append(cpu)
+                stats += block_stats
+                coder_ms.extend(t.coder_ms() for t in tickets if coder_events)
+                if sum(block_seconds) >= min_seconds or len(block_seconds) >= max_blocks:
+                    break
+        finally:
+            gc.enable()
+    order = sorted(range(len(block_seconds)), key=lambda i: block_seconds[i])
+    mid = order[(len(order) - 1)//2]      # an actual block (the lower median when the count is even)
+    # host CPU of this process (all its threads: launch thread, result worker, runtime helpers) per step, every rank's figure
+    cpu_ms = torch.zeros(max(world, 1), dtype=torch.float64, device=device)
+    cpu_ms[rank] = block_cpu[mid]/steps*1e3
+    ctx.all_reduce(cpu_ms, 'SUM')
+    return {'elapsed': block_seconds[mid], 'block_seconds': block_seconds, 'stats': stats, 'events': events,
             'probabilities': probabilities, 'map_mean_host': map_mean_host, 'host_coder': coder_mode == 'host',
-            'coder_threads': coder_threads, 'coder_ms': coder_ms}
+            'coder_threads': coder_threads, 'coder_ms': coder_ms, 'host_cpu_ms_per_step': [round(float(v), 4) for v in cpu_ms.tolist()]}
 
 
-def rate_and_psnr(stats):
+def rate_and_psnr(stats, h, w):
     nb_images = stats[3].item()
-    bpp = stats[0].item()/(nb_images*H_IN*W_IN)
-    psnr = float(tls.psnr_from_sse(stats[1].item(), nb_images*H_IN*W_IN))   # PSNR of the pooled MSE
+    bpp = stats[0].item()/(nb_images*h*w)
+    psnr = float(tls.psnr_from_sse(stats[1].item(), nb_images*h*w))   # PSNR of the pooled MSE
     return (bpp, psnr)
 
 
-def coder_alone_ms(ctx, batch, variables, repeats=20):
+def coder_alone_ms(ctx, batch, variables, h, w, repeats=20):
     """The coder chain of one batch (binarise + encode, decode + compare) timed with HIP events on an otherwise idle GPU:
     the serial depth the transforms of the batches in flight have to cover."""
     device = ctx.device
-    images = torch.from_numpy(synthetic_images(1000 + ctx.rank, batch, H_IN, W_IN)).to(device)
+    images = torch.from_numpy(synthetic_images(1000 + ctx.rank, batch, h, w)).to(device)
     bin_widths = variables[var.BIN_WIDTHS_NAME]
     y = pipeline.DeviceEncoder(variables, False, device)(images)
     map_mean = dev.map_means(y)
@@ -312,9 +377,40 @@ def coder_alone_ms(ctx, batch, variables, repeats=20):
     return (sorted(enc_ms)[len(enc_ms)//2], sorted(dec_ms)[len(dec_ms)//2])
 
 
+def launch_rooflines(run_events, pixels_per_step, fuse_latent, map_symbols):
+    """Per-launch figures from the HIP events of the roofline leg: average duration, algorithmic FLOP/s and B/s (SURVEY.md
+    8(d)'s per-pixel figures x the pixels of a launch), the larger of the two fractions of peak, and which roof that is."""
+    flops = dict(pipeline.FLOP_PER_PIXEL)
+    flops = {'conv1_gdn1': flops['conv1_gdn1'], 'conv2_gdn2': flops['conv2_gdn2'],
+             # gdn_3 and inverse_gdn_4 run in the latent-stage kernel unless that stage is the conv_3 launch's epilogue
+             'conv3': 2*1600 + (flops['conv3_gdn3'] - 2*1600 + flops['igdn4'] if fuse_latent else 0),
+             'latent': flops['conv3_gdn3'] - 2*1600 + flops['igdn4'],
+             'tconv1_igdn5': flops['tconv1_igdn5'], 'tconv2_igdn6': flops['tconv2_igdn6'], 'tconv3': flops['tconv3']}
+    per_launch_ms = {}
+    for (a, b, name) in run_events:
+        per_launch_ms.setdefault(name, []).append(a.elapsed_time(b))
+    out = {}
+    for (name, values) in per_launch_ms.items():
+        ms = sum(values)/len(values)
+        entry = {'avg_ms': round(ms, 4), 'launches': len(values)}
+        if name in flops:
+            tf = flops[name]*pixels_per_step/(ms*1e-3)/1e12
+            tb = BYTES_PER_PIXEL[name]*pixels_per_step/(ms*1e-3)/1e12
+            (f_frac, b_frac) = (tf/PEAK_F32_MFMA_TFLOPS, tb/PEAK_HBM_TBS)
+            entry.update({'flop_per_px': flops[name], 'bytes_per_px': BYTES_PER_PIXEL[name], 'tflops': round(tf, 2), 'tbytes_per_s': round(tb, 3),
+                          'frac_mfma': round(f_frac, 4), 'frac_hbm': round(b_frac, 4), 'bound': 'mfma' if f_frac >= b_frac else 'hbm',
+                          'frac': round(max(f_frac, b_frac), 4)})
+        else:
+            # the coder: a serial chain per map (64 maps per wavefront in step); neither roof applies, the figure is symbols / s
+            entry.update({'bound': 'latency (one serial chain per feature map)', 'msymbols_per_s': round(map_symbols/(ms*1e-3)/1e6, 2),
+                          'bytes_per_symbol': 2 if name == 'coder_encode' else 4,
+                          'frac_hbm': round((2 if name == 'coder_encode' else 4)*map_symbols/(ms*1e-3)/1e12/PEAK_HBM_TBS, 6)})
+        out[name] = entry
+    return (out, per_launch_ms, flops)
+
+
 def main(args):
-    global H_IN, W_IN
-    (H_IN, W_IN) = (args.height, args.width)
+    (h_in, w_in) = (args.height, args.width)
 
     # two Python threads share the GIL (kernel launches; the codec's result worker): hand it over quickly
     sys.setswitchinterval(1e-4)
@@ -335,7 +431,8 @@ def main(args):
         count = torch.tensor([1.], dtype=torch.float64)
         dist.all_reduce(count)
         if rank == 0:
-            print(json.dumps({'dry_launch': True, 'n_gpus': world, 'ranks_seen': int(count.item()), 'local_rank': local_rank}))
+            print(json.dumps({'dry_launch': True, 'n_gpus': world, 'ranks_seen': int(count.item()), 'local_rank': local_rank,
+                              'coder_streams': args.coder_streams or auto_coder_streams(h_in, w_in), 'usable_cpus': usable_cpus()}))
         dist.destroy_process_group()
         return
     if not torch.cuda.is_available():
@@ -353,48 +450,53 @@ def main(args):
     cores = usable_cpus()
     os.environ.setdefault('OMP_NUM_THREADS', str(cores))      # the oracle's OpenMP transforms (cpu_baseline only)
     ctx = Context(args, device, world, rank, cores)
+    coder_streams = args.coder_streams or auto_coder_streams(h_in, w_in)
 
     variables = synthetic_model(args.bin_width)
-    run = run_pipeline(ctx, args.batch, args.steps, args.warmup, variables, coder=args.coder, coder_streams=args.coder_streams,
+    # ---- the headline: the product's default mode (two transform streams, the step replayed as hipGraphs) -------------
+    run = run_pipeline(ctx, args.batch, args.steps, args.warmup, variables, h_in, w_in, coder=args.coder, coder_streams=coder_streams,
                        transform_streams=args.transform_streams, use_graphs=args.graphs, min_seconds=args.min_seconds,
-                       max_blocks=args.max_blocks, record_gemm=True)
-    (elapsed, stats, gemm_events, probabilities, map_mean_host) = (run['elapsed'], run['stats'], run['gemm_events'],
-                                                                    run['probabilities'], run['map_mean_host'])
+                       max_blocks=args.max_blocks)
+    (elapsed, stats, probabilities, map_mean_host) = (run['elapsed'], run['stats'], run['probabilities'], run['map_mean_host'])
     (host_coder, coder_threads) = (run['host_coder'], run['coder_threads'])
+    # ---- the roofline leg: the same steps launched kernel by kernel on ONE transform stream, HIP events around every launch
+    # (on the stream it goes to), so that a duration is that kernel's own next to nothing but the coder's side streams ------
+    roof = run_pipeline(ctx, args.batch, min(args.steps, 30), min(args.warmup, 5), variables, h_in, w_in, coder=args.coder,
+                        coder_streams=coder_streams, transform_streams=1, use_graphs=False, min_seconds=0.3, max_blocks=5, record=True)
 
     # ---- derived figures (outside the timed region) ------------------------------------------------------------------
-    pixels_per_step = args.batch*H_IN*W_IN
+    pixels_per_step = args.batch*h_in*w_in
     value = pixels_per_step*args.steps*world/elapsed/1e6
     nb_images_total = stats[3].item()
-    (bpp, mean_psnr) = rate_and_psnr(stats)
-    flops = {'conv2_gdn2': pipeline.FLOP_PER_PIXEL['conv2_gdn2'],
-             # gdn_3 (and inverse_gdn_4) run in the latent-stage kernel unless that stage is the conv_3 launch's epilogue
-             'conv3': 2*1600 + (pipeline.FLOP_PER_PIXEL['conv3_gdn3'] - 2*1600 + pipeline.FLOP_PER_PIXEL['igdn4'] if args.fuse_latent else 0),
-             'tconv1_igdn5': pipeline.FLOP_PER_PIXEL['tconv1_igdn5'], 'tconv2_igdn6': pipeline.FLOP_PER_PIXEL['tconv2_igdn6']}
-    per_launch_ms = {}
-    for (a, b, name) in gemm_events:
-        per_launch_ms.setdefault(name, []).append(a.elapsed_time(b))
-    gemm_ms = sum(sum(v) for v in per_launch_ms.values())
-    gemm_launches = sum(len(v) for v in per_launch_ms.values())
-    gemm_flop = sum(flops[name]*pixels_per_step*len(v) for (name, v) in per_launch_ms.items())
+    (bpp, mean_psnr) = rate_and_psnr(stats, h_in, w_in)
+    (per_kernel, per_launch_ms, flops) = launch_rooflines(roof['events'], pixels_per_step, args.fuse_latent, args.batch*128*(h_in//16)*(w_in//16))
+    gemm = {k: v for (k, v) in per_launch_ms.items() if k in GEMM_LAUNCHES}
+    gemm_ms = sum(sum(v) for v in gemm.values())
+    gemm_launches = sum(len(v) for v in gemm.values())
+    gemm_flop = sum(flops[name]*pixels_per_step*len(v) for (name, v) in gemm.items())
     achieved = gemm_flop/(gemm_ms*1e-3)/1e12 if gemm_ms > 0 else 0.
-    traffic = None
+    (traffic, traffic_source) = (None, None)
     traffic_file = os.path.join(ROOT, 'profiles', 'traffic_conv_gemm.json')
     if os.path.isfile(traffic_file):
         with open(traffic_file) as f:
             traffic = json.load(f).get('hbm_bytes_per_launch')
+        traffic_source = ('profiles/traffic_conv_gemm.json: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, separate runs) of this '
+                          'command at the default shape, committed with the profile summaries -- a constant of the build, not measured by this run')
     blocks = run['block_seconds']
+    roof_ms = roof['elapsed']/min(args.steps, 30)*1e3
     line = {
         'metric': 'Mpixels/s encode+decode (Kodak 768x512 luma), bitstream bit-exact',
         'value': round(value, 3), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed/args.steps*1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '{0}_{1}x{2}_luma_batch{3}_per_gpu_bin_width_{4}_lossless_roundtrip'.format(
-                       'kodak' if (H_IN, W_IN) == (512, 768) else 'synthetic', H_IN, W_IN, args.batch, args.bin_width),
-                   'images_per_gpu_per_step': args.batch, 'height': H_IN, 'width': W_IN, 'bin_width_multiplier': args.bin_width,
+                       'kodak' if (h_in, w_in) == (512, 768) else 'synthetic', h_in, w_in, args.batch, args.bin_width),
+                   'images_per_gpu_per_step': args.batch, 'height': h_in, 'width': w_in, 'bin_width_multiplier': args.bin_width,
                    'truncated_unary_length': TRUNCATED_UNARY_LENGTH, 'idx_map_exception': IDX_MAP_EXCEPTION,
                    'weights': 'random-init fixed-bin-width architecture (trained checkpoints absent from the reference)',
                    'parallelism': 'image shards, one process per GPU' if world > 1 else 'single GPU',
+                   'mode': '{0} transform stream(s), {1} batches of coder work in flight, {2}'.format(
+                       args.transform_streams, coder_streams, 'three hipGraph launches per step' if args.graphs else 'launched kernel by kernel'),
                    'coder': 'device, 64 maps per wavefront, encode + decode + compare' if not host_coder else
                             'host C-ABI coder, {} threads, after one device -> host copy of the symbols'.format(coder_threads)},
         'timing': {'blocks': len(blocks), 'steps_per_block': args.steps, 'reported': 'median block',
@@ -402,66 +504,87 @@ def main(args):
                    'max_block_ms': round(max(blocks)*1e3, 3), 'spread_pct': round((max(blocks) - min(blocks))/elapsed*100., 2),
                    'timed_seconds': round(sum(blocks), 4)},
         'images_per_s': round(args.batch*args.steps*world/elapsed, 2),
+        # process CPU time (all threads) per step during the median block, one entry per rank: 8 ranks share the node's CPU quota
+        'host_cpu_ms_per_step': run['host_cpu_ms_per_step'], 'usable_cpus': cores,
         # summed over ranks by the path's one all-reduce, over all timed blocks: exact integers (tests compare them across world sizes)
         'totals': {'bits': int(stats[0].item()), 'sse': int(stats[1].item()), 'dead_maps': int(stats[2].item()), 'images': int(nb_images_total)},
         'rate_bpp': round(bpp, 5), 'psnr_db_pooled': round(mean_psnr, 4), 'dead_maps_per_image': round(stats[2].item()/nb_images_total, 3),
+        'one_stream_leg': {'ms_per_step': round(roof_ms, 4), 'value': round(pixels_per_step*world/roof_ms/1e3, 3), 'unit': 'Mpixels/s',
+                           'flags': '--transform-streams 1 --no-graphs', 'host_cpu_ms_per_step': roof['host_cpu_ms_per_step'],
+                           'note': 'source of `roofline`: every launch bracketed by HIP events on its own stream'},
         'roofline': {'bound': 'mfma', 'kernel': 'conv_gemm_split_kernel (conv2+GDN2, conv3, tconv1+IGDN5, tconv2+IGDN6)',
                      'achieved': round(achieved, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': round(achieved/PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                     'frac': round(achieved/PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic, 'traffic_source': traffic_source,
                      'avg_launch_ms': round(gemm_ms/max(gemm_launches, 1), 4),
-                     'per_launch_ms': {k: round(sum(v)/len(v), 4) for (k, v) in per_launch_ms.items()},
+                     'per_launch_ms': {k: round(sum(v)/len(v), 4) for (k, v) in gemm.items()},
                      'per_launch_frac': {k: round(flops[k]*pixels_per_step/(sum(v)/len(v)*1e-3)/1e12/PEAK_F32_MFMA_TFLOPS, 4)
-                                         for (k, v) in per_launch_ms.items()},
-                     'algorithmic_flop_per_launch': {k: flops[k]*pixels_per_step for k in flops}},
+                                         for (k, v) in gemm.items()},
+                     'algorithmic_flop_per_launch': {k: flops[k]*pixels_per_step for k in GEMM_LAUNCHES},
+                     'per_kernel': per_kernel, 'peak_hbm_tbytes_per_s': PEAK_HBM_TBS},
     }
-    del run, gemm_events
+    del run, roof
     side = rank == 0 and world == 1 and not args.no_single_image
-    if side and args.batch != 1 and (H_IN, W_IN) == (512, 768):
+    if side and args.batch != 1 and (h_in, w_in) == (512, 768):
         # BASELINE.json configs[1] is ONE Kodak image: the same path with one image per step (launch-bound, not the headline)
-        one = run_pipeline(ctx, 1, 300, 30, variables, coder_streams=8, transform_streams=6, use_graphs=True)
+        one = run_pipeline(ctx, 1, 300, 30, variables, h_in, w_in, coder_streams=8, transform_streams=6, use_graphs=True)
         line['single_image'] = {'ms_per_image': round(one['elapsed']/300*1e3, 4),
-                                'mpixels_per_s': round(300*H_IN*W_IN/one['elapsed']/1e6, 2), 'steps': 300, 'warmup': 30,
+                                'mpixels_per_s': round(300*h_in*w_in/one['elapsed']/1e6, 2), 'steps': 300, 'warmup': 30,
                                 'note': 'one 512x768 image per step; a step is a chain of short latency-bound kernels, so steps '
                                         'are pipelined: 6 transform streams, 8 coder streams, three hipGraph launches per step'}
-    if side and args.transform_streams == 1 and not args.graphs:
-        # the same batch in the opt-in overlapped mode (consecutive batches on alternating transform streams, three batches of
-        # coder work in flight, a step replayed as three hipGraphs): whole-job rate only -- launches share the GPU, so there
-        # are no per-launch durations to report
-        over = run_pipeline(ctx, args.batch, 100, 15, variables, coder_streams=3, transform_streams=2, use_graphs=True)
-        line['overlapped_mode'] = {'value': round(100*args.batch*H_IN*W_IN/over['elapsed']/1e6, 3), 'unit': 'Mpixels/s',
-                                   'ms_per_step': round(over['elapsed']/100*1e3, 4), 'steps': 100, 'warmup': 15,
-                                   'flags': '--transform-streams 2 --coder-streams 3 --graphs'}
+    if side and (h_in, w_in, args.batch) == (512, 768, 24):
+        # the other shapes BASELINE.json names, same default flags (what `python bench.py --height H --width W --batch B` prints)
+        line['other_shapes'] = []
+        for (b2, h2, w2, steps2, what) in ((64, 256, 256, 40, 'one rank of configs[3] (512 images of 256x256 over 8 GPUs)'),
+                                           (2, 2048, 2048, 30, 'configs[4]: 2048x2048, untiled (fits HBM), two images per step')):
+            leg = run_pipeline(ctx, b2, steps2, 8, variables, h2, w2, coder_streams=auto_coder_streams(h2, w2),
+                               transform_streams=args.transform_streams, use_graphs=args.graphs, min_seconds=0.4, max_blocks=5)
+            line['other_shapes'].append({'workload': '{0}x{1}x{2}'.format(b2, h2, w2), 'what': what,
+                                         'value': round(steps2*b2*h2*w2/leg['elapsed']/1e6, 3), 'unit': 'Mpixels/s',
+                                         'ms_per_step': round(leg['elapsed']/steps2*1e3, 4), 'coder_streams': auto_coder_streams(h2, w2),
+                                         'rate_bpp': round(rate_and_psnr(leg['stats'], h2, w2)[0], 5)})
     if side and args.coder == 'device':
+        # the feed / fetch of the reference's sess.run (uint8 images from pinned host memory in, uint8 reconstructions out)
+        feed = run_pipeline(ctx, args.batch, 60, 10, variables, h_in, w_in, coder_streams=coder_streams, transform_streams=args.transform_streams,
+                            use_graphs=args.graphs, min_seconds=0.4, max_blocks=5, pcie=True)
+        line['pcie_inclusive'] = {'value': round(60*pixels_per_step/feed['elapsed']/1e6, 3), 'unit': 'Mpixels/s',
+                                  'ms_per_step': round(feed['elapsed']/60*1e3, 4), 'steps': 60, 'warmup': 10,
+                                  'bytes_per_step': {'host_to_device': pixels_per_step, 'device_to_host': pixels_per_step},
+                                  'note': 'uint8 batch copied from pinned host memory on a copy stream before every step, uint8 '
+                                          'reconstruction copied back on another; never the headline'}
         # north_star's original shape (one device -> host copy of the symbols, the host C-ABI coder on the CPUs the quota allows)
-        host = run_pipeline(ctx, args.batch, 30, 5, variables, coder='host', coder_streams=args.coder_streams, min_seconds=0.5, max_blocks=5)
-        line['host_coder'] = {'value': round(30*args.batch*H_IN*W_IN/host['elapsed']/1e6, 3), 'unit': 'Mpixels/s',
+        host = run_pipeline(ctx, args.batch, 30, 5, variables, h_in, w_in, coder='host', coder_streams=3, min_seconds=0.5, max_blocks=5)
+        line['host_coder'] = {'value': round(30*pixels_per_step/host['elapsed']/1e6, 3), 'unit': 'Mpixels/s',
                               'ms_per_step': round(host['elapsed']/30*1e3, 4), 'steps': 30, 'warmup': 5, 'blocks': len(host['block_seconds']),
-                              'threads': host['coder_threads'], 'usable_cpus': cores, 'rate_bpp': round(rate_and_psnr(host['stats'])[0], 5),
+                              'threads': host['coder_threads'], 'usable_cpus': cores, 'rate_bpp': round(rate_and_psnr(host['stats'], h_in, w_in)[0], 5),
                               'flags': '--coder host'}
         # a latent with the entropy of a trained model: the same path at smaller bin widths. How long the coder chain of a batch
         # is on its own, what a step costs with and without it, hence whether the transforms still hide it.
         line['realistic_entropy'] = []
         os.environ['EAE_BENCH_NO_CODER'] = '1'
-        bare = run_pipeline(ctx, args.batch, 30, 5, variables, coder_streams=args.coder_streams, min_seconds=0.3, max_blocks=5)
+        bare = run_pipeline(ctx, args.batch, 30, 5, variables, h_in, w_in, coder_streams=coder_streams, transform_streams=args.transform_streams,
+                            use_graphs=args.graphs, min_seconds=0.3, max_blocks=5)
         del os.environ['EAE_BENCH_NO_CODER']
-        for width in (args.bin_width,) + tuple(w for w in REALISTIC_BIN_WIDTHS if w < args.bin_width):
+        ms_bare = bare['elapsed']/30*1e3
+        for width in (args.bin_width,) + tuple(wd for wd in REALISTIC_BIN_WIDTHS if wd < args.bin_width):
             v_w = synthetic_model(width)
-            leg = run_pipeline(ctx, args.batch, 30, 5, v_w, coder_streams=args.coder_streams, min_seconds=0.5, max_blocks=5, coder_events=True)
-            (enc_ms, dec_ms) = coder_alone_ms(ctx, args.batch, v_w)
-            (leg_bpp, leg_psnr) = rate_and_psnr(leg['stats'])
+            leg = run_pipeline(ctx, args.batch, 30, 5, v_w, h_in, w_in, coder_streams=coder_streams, transform_streams=args.transform_streams,
+                               use_graphs=args.graphs, min_seconds=0.5, max_blocks=5)
+            # the coder's span in the pipeline needs events on its stream: the launch-by-launch path, one transform stream
+            span = run_pipeline(ctx, args.batch, 20, 5, v_w, h_in, w_in, coder_streams=coder_streams, min_seconds=0., max_blocks=1, coder_events=True)
+            (enc_ms, dec_ms) = coder_alone_ms(ctx, args.batch, v_w, h_in, w_in)
+            (leg_bpp, leg_psnr) = rate_and_psnr(leg['stats'], h_in, w_in)
             ms_step = leg['elapsed']/30*1e3
-            ms_bare = bare['elapsed']/30*1e3
-            in_pipe = sorted(leg['coder_ms'])[len(leg['coder_ms'])//2]
+            in_pipe = sorted(span['coder_ms'])[len(span['coder_ms'])//2]
             line['realistic_entropy'].append({
                 'bin_width': width, 'rate_bpp': round(leg_bpp, 4), 'psnr_db_pooled': round(leg_psnr, 3),
-                'value': round(30*args.batch*H_IN*W_IN/leg['elapsed']/1e6, 3), 'ms_per_step': round(ms_step, 4),
-                'ms_per_step_without_coder': round(ms_bare, 4),
+                'value': round(30*pixels_per_step/leg['elapsed']/1e6, 3), 'ms_per_step': round(ms_step, 4),
+                'ms_per_step_without_coder': round(ms_bare, 4), 'step_over_no_coder_step': round(ms_step/ms_bare, 4),
                 'coder_alone_ms_per_batch': {'binarise_encode': round(enc_ms, 4), 'decode_compare': round(dec_ms, 4)},
-                'coder_in_pipeline_ms_per_batch': round(in_pipe, 4), 'coder_streams': args.coder_streams,
-                'coder_on_critical_path': bool(in_pipe > args.coder_streams*ms_step*0.95)})
+                'coder_in_pipeline_ms_per_batch': round(in_pipe, 4), 'coder_streams': coder_streams,
+                'coder_on_critical_path': bool(in_pipe > coder_streams*ms_step*0.95)})
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(variables, probabilities, map_mean_host, cores)
+            line['cpu_baseline'] = cpu_baseline(variables, probabilities, map_mean_host, cores, h_in, w_in)
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:
@@ -469,14 +592,16 @@ def main(args):
         dist.destroy_process_group()
 
 
-def cpu_baseline(variables, probabilities, map_mean, cores):
+def cpu_baseline(variables, probabilities, map_mean, cores, h, w):
     """The same path on the host cores, on a BOUNDED sample (checker code, timed only here, never shipped):
-    transforms = oracle/transforms_oracle.c (plain-C restatement, OpenMP over all cores);
-    coder = the reference's own C++ coder compiled into oracle/_ref (single thread, as the reference runs it),
+    transforms twice -- on torch-CPU (oneDNN convolutions, `cores` threads: the stand-in for the TensorFlow-CPU kernels behind the
+    reference's sess.run, oracle/transforms_torch.py) and by the plain-C oracle (oracle/transforms_oracle.c, OpenMP, the bit-exact
+    checker); coder = the reference's own C++ coder compiled into oracle/_ref (single thread, as the reference runs it),
     falling back to the oracle's C restatement when the reference build is absent; numpy quantiser / PSNR.
-    One image calibrates, then as many images as fit in about 20 s of CPU work (2..64) are timed together."""
+    `value` uses the FASTER transform leg. One image calibrates, then as many images as fit in about 20 s of CPU work."""
     from oracle import coder as oracle_coder
     from oracle import transforms as oracle_transforms
+    from oracle import transforms_torch
     import ctypes
     try:        # libgomp was initialised when torch was imported: set the team size for this thread explicitly
         ctypes.CDLL('libgomp.so.1').omp_set_num_threads(int(cores))
@@ -485,13 +610,20 @@ def cpu_baseline(variables, probabilities, map_mean, cores):
     bw = variables[var.BIN_WIDTHS_NAME]
     kind_coder = 'ref' if oracle_coder.available('ref') else 'oracle'
     lib = oracle_coder.CoderLib(kind_coder)
+    cpu = transforms_torch.CpuTransforms(variables, False, threads=cores)
+    coder_key = 'coder_{}_single_thread'.format('reference_cpp' if kind_coder == 'ref' else 'oracle_c')
 
-    def run(n_img):
-        x = synthetic_images(999, n_img, H_IN, W_IN)
+    def run(n_img, with_oracle):
+        x = synthetic_images(999, n_img, h, w)
+        xf = x.astype(numpy.float32)[..., None]
         t = {}
         t0 = time.perf_counter()
-        y = oracle_transforms.encoder(x.astype(numpy.float32)[..., None], variables, False)
-        t['encoder_oracle_c_openmp'] = time.perf_counter() - t0
+        y = cpu.encoder(xf)
+        t['encoder_torch_cpu'] = time.perf_counter() - t0
+        if with_oracle:
+            t0 = time.perf_counter()
+            oracle_transforms.encoder(xf, variables, False)
+            t['encoder_oracle_c_openmp'] = time.perf_counter() - t0
         t0 = time.perf_counter()
         tiled = numpy.tile(bw.reshape(1, 1, 1, 128), y.shape[:3] + (1,))
         cq = tiled*numpy.round((y - map_mean)/tiled)
@@ -505,22 +637,35 @@ def cpu_baseline(variables, probabilities, map_mean, cores):
                     continue
                 (rec, nb) = lib.compress_lossless(numpy.ascontiguousarray(sym[j, :, :, c]).reshape(-1), probabilities[c])
                 bits += nb
-        t['coder_{}_single_thread'.format('reference_cpp' if kind_coder == 'ref' else 'oracle_c')] = time.perf_counter() - t0
+        t[coder_key] = time.perf_counter() - t0
         t0 = time.perf_counter()
-        rec = oracle_transforms.decoder(cq + map_mean, variables, False)[..., 0]
+        rec = cpu.decoder(cq + map_mean)[..., 0]
         rec_u8 = numpy.round(rec.clip(min=16., max=235.)).astype(numpy.uint8)
         mse = numpy.mean((x.astype(numpy.float64) - rec_u8.astype(numpy.float64))**2)
-        t['decoder_oracle_c_openmp_plus_psnr'] = time.perf_counter() - t0
+        t['decoder_torch_cpu_plus_psnr'] = time.perf_counter() - t0
+        if with_oracle:
+            t0 = time.perf_counter()
+            oracle_transforms.decoder(cq + map_mean, variables, False)
+            t['decoder_oracle_c_openmp'] = time.perf_counter() - t0
         return (t, bits, float(mse))
 
-    (t1, _, _) = run(1)
-    n_img = int(max(2, min(64, round(20./max(sum(t1.values()), 1e-3)))))
-    (t, bits, mse) = run(n_img)
-    total = sum(t.values())
-    return {'value': round(n_img*H_IN*W_IN/total/1e6, 4), 'unit': 'Mpixels/s', 'cores': cores, 'kind': 'port',
-            'sample': ('{0} synthetic {1}x{2} images, encode+quantise+code(enc+dec)+decode+PSNR, {3:.1f} s of CPU work; '
-                       'transforms OpenMP on the {4} usable CPUs, coder single-threaded like the reference'
-                       ).format(n_img, H_IN, W_IN, total, cores),
+    run(1, False)                 # first touch: oneDNN primitive creation, thread pool
+    (t1, _, _) = run(1, True)
+    per_image = sum(t1.values())
+    n_img = int(max(2, min(64, round(20./max(per_image, 1e-3)))))
+    (t, bits, mse) = run(n_img, True)
+    torch_total = t['encoder_torch_cpu'] + t['quantiser_numpy'] + t[coder_key] + t['decoder_torch_cpu_plus_psnr']
+    oracle_total = t['encoder_oracle_c_openmp'] + t['quantiser_numpy'] + t[coder_key] + t['decoder_oracle_c_openmp']
+    total = min(torch_total, oracle_total)
+    return {'value': round(n_img*h*w/total/1e6, 4), 'unit': 'Mpixels/s', 'cores': cores, 'kind': 'port',
+            'transform_leg_used': 'torch_cpu' if torch_total <= oracle_total else 'oracle_c_openmp',
+            'value_with_torch_cpu_transforms': round(n_img*h*w/torch_total/1e6, 4),
+            'value_with_oracle_c_transforms': round(n_img*h*w/oracle_total/1e6, 4),
+            'threads': {'torch_intraop': cpu.threads, 'openmp': cores, 'coder': 1},
+            'sample': ('{0} synthetic {1}x{2} images, encode+quantise+code(enc+dec)+decode+PSNR, {3:.1f} s of CPU work in all; transforms '
+                       'on torch-CPU/oneDNN ({4} threads: the stand-in for the reference\'s TensorFlow-CPU kernels) and, as a second '
+                       'entry, by the plain-C oracle (OpenMP, {4} threads); coder single-threaded like the reference'
+                       ).format(n_img, h, w, sum(t.values()), cores),
             'seconds': {k: round(val, 3) for (k, val) in t.items()}, 'bits': int(bits), 'mse': round(mse, 4)}
 
 

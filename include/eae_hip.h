@@ -83,6 +83,11 @@ void eae_hip_model_destroy(eae_hip_model* model);
 int eae_hip_model_are_bin_widths_learned(const eae_hip_model* model);
 uint64_t eae_hip_encode_scratch_bytes(int n, int h, int w);                 /* 0 for sizes eae_hip_encode rejects */
 uint64_t eae_hip_decode_scratch_bytes(int n, int h_latent, int w_latent);
+/* eae_hip_transform_status: the failure word of the MOST RECENT encode / decode call issued on `stream` with this scratch
+ * block (the hand-off timeout of a cut launch, see eae_hip_conv_workspace_collect). Waits for `stream`, writes the count to
+ * *host_count (0 = the results are valid) and returns 0, or a hipError_t. Not calling it forgoes the check; it never
+ * affects later calls (encode / decode zero their workspace and the word on entry). */
+int eae_hip_transform_status(void* scratch, uint32_t* host_count, void* stream);
 int eae_hip_encode(const eae_hip_model* model, const uint8_t* images, int n, int h, int w, float* latents, void* scratch,
                    uint64_t scratch_bytes, void* stream);
 int eae_hip_decode(const eae_hip_model* model, const float* quantized_latents, int n, int h_latent, int w_latent,
@@ -129,6 +134,14 @@ int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const float* bias,
  * when the launch has completed (zero it once); launches that may run concurrently need their own. Whether a launch is cut
  * is decided from its shape (only the convolutions, only when the last round would be less than ~97 % full). */
 uint64_t eae_hip_conv_workspace_bytes(void);
+/* Failure mode of a cut launch, and how it surfaces. The second half of a cut tile waits for the first half's accumulators;
+ * the first half is always dispatched earlier (workgroups start in grid order on gfx950, the only device on which launches
+ * are cut), so the wait is finite. Should it ever exceed ~1 s, the waiting wave writes NO result for its tile and counts
+ * itself in the workspace's error word. eae_hip_conv_workspace_collect, enqueued behind the launch(es), adds that count to
+ * *error_word (device memory or device-mapped pinned host memory; non-zero = the outputs of the launches since the last
+ * collect are INVALID) and restores the all-zero workspace, so later launches are unaffected. A caller that cuts launches
+ * must collect before trusting their outputs (codec.BatchCodec does per batch and raises from Ticket.result()). */
+int eae_hip_conv_workspace_collect(void* workspace, uint32_t* error_word, void* stream);
 int eae_hip_conv5x5s2_ws(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma_packed,
                          const float* beta, float* out, int n, int h, int w_in, void* workspace, void* stream);
 int eae_hip_tconv5x5s2_ws(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma_packed,

@@ -27,7 +27,17 @@ def test_launcher_starts_one_process_per_rank(world):
     (proc, lines) = run_bench(['--gpus', str(world), '--dry-launch'])
     assert proc.returncode == 0, proc.stderr
     assert len(lines) == 1
-    assert lines[0] == {'dry_launch': True, 'n_gpus': world, 'ranks_seen': world, 'local_rank': 0}
+    assert {k: lines[0][k] for k in ('dry_launch', 'n_gpus', 'ranks_seen', 'local_rank')} == {
+        'dry_launch': True, 'n_gpus': world, 'ranks_seen': world, 'local_rank': 0}
+
+
+def test_eight_ranks_of_configs_3_rendezvous():
+    """BASELINE.json configs[3] as the driver will launch it on an 8-GPU node (`--gpus 8 --height 256 --width 256 --batch 64`),
+    rendezvous only (no GPU here): eight children, eight ranks seen, the shape-derived number of coder batches in flight."""
+    (proc, lines) = run_bench(['--gpus', '8', '--height', '256', '--width', '256', '--batch', '64', '--dry-launch'], timeout=600)
+    assert proc.returncode == 0, proc.stderr
+    assert len(lines) == 1
+    assert lines[0]['n_gpus'] == 8 and lines[0]['ranks_seen'] == 8 and lines[0]['coder_streams'] == 3 and lines[0]['usable_cpus'] >= 1
 
 
 def test_world_size_mismatch_is_an_error():
@@ -50,7 +60,7 @@ def test_under_an_external_launcher_the_flag_must_agree():
                           stderr=subprocess.PIPE, universal_newlines=True, timeout=600, cwd=ROOT)
     assert proc.returncode == 0, proc.stderr
     lines = [json.loads(line) for line in proc.stdout.splitlines() if line.startswith('{')]
-    assert lines == [{'dry_launch': True, 'n_gpus': 2, 'ranks_seen': 2, 'local_rank': 0}]
+    assert len(lines) == 1 and lines[0]['dry_launch'] is True and lines[0]['n_gpus'] == 2 and lines[0]['ranks_seen'] == 2
 
 
 @pytest.mark.gpu
@@ -72,3 +82,19 @@ def test_two_ranks_through_the_flag_on_one_gpu():
     for key in ('bits', 'sse', 'dead_maps', 'images'):
         assert two['totals'][key] == singles[0][key] + singles[1][key], key
     assert two['totals']['images'] == 2*3*4
+    assert len(two['host_cpu_ms_per_step']) == 2 and all(v > 0. for v in two['host_cpu_ms_per_step'])
+
+
+@pytest.mark.gpu
+def test_four_ranks_share_the_gpu_and_the_host_cpu_budget_is_reported():
+    """Four ranks through the flag on this box's one GPU (gloo): what an 8-GPU node asks of the HOST is 8 x one rank's CPU time per
+    step inside the container's CPU quota -- the line reports every rank's `host_cpu_ms_per_step` and `usable_cpus`, and the
+    all-reduced totals cover four ranks."""
+    common = ['--steps', '3', '--warmup', '1', '--batch', '2', '--no-cpu-baseline', '--no-side', '--min-seconds', '0']
+    (proc, lines) = run_bench(['--gpus', '4'] + common, {'EAE_BENCH_SHARE_GPU': '1'})
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert len(lines) == 1
+    four = lines[0]
+    assert four['n_gpus'] == 4 and four['totals']['images'] == 4*3*2
+    assert len(four['host_cpu_ms_per_step']) == 4 and all(v > 0. for v in four['host_cpu_ms_per_step'])
+    assert four['usable_cpus'] >= 1 and 'one_stream_leg' in four and four['roofline']['per_kernel']['conv1_gdn1']['avg_ms'] > 0.

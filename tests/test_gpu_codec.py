@@ -249,3 +249,64 @@ def test_fused_latent_stage_gives_the_same_results(learned, shape):
     for key in ('nb_bits', 'coder_bits', 'exception_bits', 'sse', 'nb_deads'):
         assert numpy.array_equal(results[0][0][key], results[1][0][key]), key
     assert numpy.array_equal(results[0][1], results[1][1])
+
+
+def test_a_failed_hand_off_raises_from_the_ticket_and_the_next_batches_are_right(monkeypatch):
+    """The cut-tile hand-off of the conv launches forced to fail (csrc/hip/conv_gemm_split.hip, EAE_HIP_TEST_SPLIT_MUTE):
+    `Ticket.result()` raises for exactly those batches; with the hook off again the same codec -- every slot, hence every
+    workspace, used once more -- returns what a fresh codec returns."""
+    from autoencoder_based_image_compression_amd import codec, device as dev
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    for name in ('EAE_HIP_GEMM', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_TEST_SPLIT_MUTE'):
+        monkeypatch.delenv(name, raising=False)
+    with numpy.load(GOLD) as g:
+        probabilities = g['real_probabilities_1']
+    v = var.random_variables(1., False, seed=8, bias_std=0.01)
+    v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
+    images = torch.from_numpy(numpy.random.RandomState(9).randint(16, 236, size=(3, 64, 96)).astype(numpy.uint8)).cuda()
+    ones = numpy.ones(128, dtype=numpy.float32)
+    with codec.BatchCodec(v, False, ones, 0*ones, probabilities, 67, 3, 64, 96) as fresh:
+        expected = fresh.submit(images).result()
+    monkeypatch.setenv('EAE_HIP_GEMM', 's')                  # cut every conv launch, small as they are
+    with codec.BatchCodec(v, False, ones, 0*ones, probabilities, 67, 3, 64, 96) as c:
+        first = c.submit(images).result()
+        for key in expected:
+            assert numpy.array_equal(first[key], expected[key]), key
+        monkeypatch.setenv('EAE_HIP_TEST_SPLIT_MUTE', '1')
+        failed = [c.submit(images) for _ in range(2)]
+        for ticket in failed:
+            with pytest.raises(dev.SplitHandOffTimeout):
+                ticket.result()
+        monkeypatch.delenv('EAE_HIP_TEST_SPLIT_MUTE')
+        for _ in range(c.nb_slots + 1):
+            r = c.submit(images).result()
+            for key in expected:
+                assert numpy.array_equal(r[key], expected[key]), key
+
+
+def test_exception_map_symbols_beyond_the_histogram_radius_are_counted_again(tmp_path):
+    """The reference's exception-map cost is a histogram from the smallest to the largest symbol, whatever they are
+    (lossless/compression.py:68-75): a codec whose first histogram is too narrow must return the same bits (it counts the map
+    again over all of int16), not raise."""
+    from autoencoder_based_image_compression_amd import codec
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    with numpy.load(GOLD) as g:
+        probabilities = g['real_probabilities_1']
+    path = str(tmp_path/'binary_probabilities.npy')
+    numpy.save(path, probabilities)
+    v = var.random_variables(1., False, seed=10, bias_std=0.01)
+    v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
+    images = numpy.random.RandomState(11).randint(16, 236, size=(2, 64, 96)).astype(numpy.uint8)
+    bin_widths = numpy.full(128, 0.05, dtype=numpy.float32)      # symbols of a few tens
+    map_mean = numpy.zeros(128, dtype=numpy.float32)
+    (nb_bits, nb_deads, rec, psnr) = reference_shaped_path(v, False, images, bin_widths, map_mean, path, 67)
+    device_images = torch.from_numpy(images).cuda()
+    with codec.BatchCodec(v, False, bin_widths, map_mean, probabilities, 67, 2, 64, 96) as wide:
+        a = wide.submit(device_images).result()
+    with codec.BatchCodec(v, False, bin_widths, map_mean, probabilities, 67, 2, 64, 96, hist_radius=1) as narrow:
+        b = narrow.submit(device_images).result()
+        b2 = narrow.submit(device_images).result()
+    assert int(numpy.abs(a['exception_bits']).sum()) > 0
+    for key in a:
+        assert numpy.array_equal(a[key], b[key]) and numpy.array_equal(a[key], b2[key]), key
+    assert numpy.array_equal(a['nb_bits'], nb_bits)

@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-ENV = ('EAE_HIP_GEMM', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_FORCE_TILE', 'EAE_HIP_FORCE_NT')
+ENV = ('EAE_HIP_GEMM', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_FORCE_TILE', 'EAE_HIP_FORCE_NT', 'EAE_HIP_TEST_SPLIT_MUTE')
 
 
 def _vars(seed):
@@ -142,3 +142,76 @@ def test_workspace_entry_points_check_their_arguments(monkeypatch):
     assert lib.eae_hip_conv5x5s2_ws(x.data_ptr(), w.data_ptr(), None, 0, None, None, out.data_ptr(), 1, 3, 4, ws.data_ptr(), None) == -2
     monkeypatch.setenv('EAE_HIP_GEMM', 's')      # a forced cut needs the workspace
     assert lib.eae_hip_conv5x5s2(x.data_ptr(), w.data_ptr(), None, 0, None, None, out.data_ptr(), 1, 4, 4, None) == -1
+
+
+def _collect(dev, ws):
+    word = torch.zeros(1, dtype=torch.int32, device='cuda')
+    dev.conv_workspace_collect(ws, word)
+    return int(word.item())
+
+
+@pytest.mark.parametrize('forced', [False, True])
+def test_a_hand_off_that_never_happens_is_loud_and_leaves_no_trace(forced, monkeypatch):
+    """EAE_HIP_TEST_SPLIT_MUTE=1 (build-independent test hook, read per launch): the heads of the cut tiles park their
+    accumulators but never publish. Every tail must give up (after ~1 ms with the hook), write NOTHING into its tile, and be
+    counted in the workspace's error word; eae_hip_conv_workspace_collect hands the count over and zeroes the workspace, so
+    that the next launch -- hook off -- gives the oracle's bits with the same workspace."""
+    from autoencoder_based_image_compression_amd import device as dev
+    for name in ENV:
+        monkeypatch.delenv(name, raising=False)
+    v = _vars(41)
+    x = torch.from_numpy(numpy.random.RandomState(42).standard_normal(size=(6, 128, 192, 128)).astype(numpy.float32)).cuda()
+    args = (x, dev.pack_conv_weights(torch.from_numpy(v['encoder/weights_2']).cuda()), torch.from_numpy(v['encoder/biases_2']).cuda(),
+            1, dev.pack_gamma(torch.from_numpy(v['encoder/gamma_2']).cuda()), torch.from_numpy(v['encoder/beta_2']).cuda())
+    good = dev.conv5x5s2(*args, workspace=False)
+    ws = dev.conv_workspace('cuda')
+    if forced:
+        monkeypatch.setenv('EAE_HIP_GEMM', 's')      # every XCD share cut as deep as it goes
+    monkeypatch.setenv('EAE_HIP_TEST_SPLIT_MUTE', '1')
+    sentinel = torch.full_like(good, 12345.0)
+    out = dev.conv5x5s2(*args, out=sentinel.clone(), workspace=ws)
+    torch.cuda.synchronize()
+    unfinished = _collect(dev, ws)
+    assert unfinished > 0
+    assert _workspace_is_clean(ws)
+    # pixels are either finished tiles (the oracle's bits), or untouched / parked accumulators of an abandoned tile: at
+    # least `unfinished` tiles of 32 positions differ, and no abandoned tile carries a finished result
+    differs = (out != good).any(dim=-1)
+    assert int(differs.sum().item()) > 0
+    monkeypatch.delenv('EAE_HIP_TEST_SPLIT_MUTE')
+    again = dev.conv5x5s2(*args, workspace=ws)       # the same workspace, no memset by the caller
+    assert torch.equal(again, good)
+    assert _collect(dev, ws) == 0 and _workspace_is_clean(ws)
+
+
+def test_the_whole_path_entry_points_report_the_failure(monkeypatch):
+    """eae_hip_encode with the hook on: eae_hip_transform_status (C ABI) and device.Model.check() (what the reference-shaped
+    `sess.run` nodes call after their copy to the host) both report it; the next call on the same model is clean."""
+    import ctypes
+    from autoencoder_based_image_compression_amd import _native, device as dev, pipeline
+    for name in ENV:
+        monkeypatch.delenv(name, raising=False)
+    v = _vars(43)
+    images = torch.from_numpy(numpy.random.RandomState(44).randint(16, 236, size=(2, 128, 192)).astype(numpy.uint8)).cuda()
+    enc = pipeline.DeviceEncoder(v, False)
+    good = enc(images)
+    enc.check()
+    monkeypatch.setenv('EAE_HIP_GEMM', 's')
+    monkeypatch.setenv('EAE_HIP_TEST_SPLIT_MUTE', '1')
+    enc(images)
+    with pytest.raises(dev.SplitHandOffTimeout):
+        enc.check()
+    # straight through the C ABI
+    lib = _native.hip()
+    nbytes = int(lib.eae_hip_encode_scratch_bytes(2, 128, 192))
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    latents = torch.empty_like(good)
+    assert lib.eae_hip_encode(enc.model._handle, images.data_ptr(), 2, 128, 192, latents.data_ptr(), scratch.data_ptr(), nbytes, None) == 0
+    count = ctypes.c_uint32(0)
+    assert lib.eae_hip_transform_status(scratch.data_ptr(), ctypes.byref(count), None) == 0 and count.value > 0
+    monkeypatch.delenv('EAE_HIP_TEST_SPLIT_MUTE')
+    assert lib.eae_hip_encode(enc.model._handle, images.data_ptr(), 2, 128, 192, latents.data_ptr(), scratch.data_ptr(), nbytes, None) == 0
+    assert lib.eae_hip_transform_status(scratch.data_ptr(), ctypes.byref(count), None) == 0 and count.value == 0
+    assert torch.equal(latents, good)
+    assert torch.equal(enc(images), good)
+    enc.check()

@@ -79,6 +79,15 @@ def _select_form(monkeypatch, form, tile):
         monkeypatch.setenv('EAE_HIP_FORCE_NT', form[2:])
 
 
+def _assert_handed_over(T, dev, ws):
+    """No tail of a cut launch gave up (eae_hip_conv_workspace_collect reports 0) and the workspace is all zero again."""
+    if ws is None:
+        return
+    word = T.zeros(1, dtype=T.int32, device='cuda')
+    dev.conv_workspace_collect(ws, word)
+    assert int(word.item()) == 0 and int(T.count_nonzero(ws).item()) == 0
+
+
 FORMS = [('wave', '32'), ('wave', '64'), ('wave', '128'), ('lds', '64'), ('lds', '128'), ('nt1', '32'), ('nt2', '32'),
          ('whole', ''), ('cut1', ''), ('cut2', ''), ('cut3', '')]
 
@@ -117,9 +126,11 @@ def test_conv5x5s2(T, dev, orc, shape, norm, form, tile, monkeypatch):
     expect_w = numpy.empty((25, 128, 128), dtype=numpy.float32)
     expect_w[:, :, perm] = v['encoder/weights_2'].reshape(25, 128, 128)
     assert numpy.array_equal(wp.cpu().numpy(), expect_w)
+    ws = dev.conv_workspace('cuda') if form.startswith('cut') else None      # a cut launch needs a workspace, and its owner collects
     got = dev.conv5x5s2(_cuda(T, x), wp, _cuda(T, v['encoder/biases_2']), norm,
-                        dev.pack_gamma(_cuda(T, v['encoder/gamma_2'])), _cuda(T, v['encoder/beta_2'])).cpu().numpy()
+                        dev.pack_gamma(_cuda(T, v['encoder/gamma_2'])), _cuda(T, v['encoder/beta_2']), workspace=ws).cpu().numpy()
     assert numpy.array_equal(got, ref)
+    _assert_handed_over(T, dev, ws)
 
 
 @pytest.mark.parametrize('form,tile', FORMS)
@@ -138,9 +149,11 @@ def test_tconv5x5s2(T, dev, orc, shape, norm, form, tile, monkeypatch):
     expect_w = numpy.empty((25, 128, 128), dtype=numpy.float32)
     expect_w[:, :, perm] = v['decoder/weights_4'].transpose(0, 1, 3, 2).reshape(25, 128, 128)
     assert numpy.array_equal(wp.cpu().numpy(), expect_w)
+    ws = dev.conv_workspace('cuda') if form.startswith('cut') else None
     got = dev.tconv5x5s2(_cuda(T, x), wp, _cuda(T, v['decoder/biases_4']), norm,
-                         dev.pack_gamma(_cuda(T, v['decoder/gamma_5'])), _cuda(T, v['decoder/beta_5'])).cpu().numpy()
+                         dev.pack_gamma(_cuda(T, v['decoder/gamma_5'])), _cuda(T, v['decoder/beta_5']), workspace=ws).cpu().numpy()
     assert numpy.array_equal(got, ref)
+    _assert_handed_over(T, dev, ws)
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 24), (1, 4, 16), (1, 5, 7), (3, 1, 1), (1, 12, 40)])

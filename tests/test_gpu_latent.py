@@ -89,10 +89,16 @@ def test_conv3_with_the_latent_stage_as_its_epilogue(shape, form, learned, monke
     if form:
         monkeypatch.setenv('EAE_HIP_GEMM', form)
     ws = dev.conv_workspace('cuda')
-    for _ in range(2):
-        got = dev.conv5x5s2_latent(x, w3, b3, bw, mean, gdn_in=gdn_in, igdn_out=igdn_out, want_y=True, want_shifted=True, want_flags=True,
-                                   workspace=ws)
-        for key in ('y', 'shifted', 'symbols', 'nonzero_flags', 'checks') + (() if learned else ('t',)):
-            assert torch.equal(got[key].reshape(ref[key].shape), ref[key]), key
-        assert int(torch.count_nonzero(ws).item()) == 0
+    # small layers run the stage IN PLACE on the convolution's output inside the entry point: every form of the stage kernel
+    # ('' = four waves per tile, 'w' = one wave per tile, 'l' = block-cooperative LDS form) must cope with x == its output
+    for stage_form in ('', 'w', 'l') if shape[1] <= 16 else ('',):
+        if stage_form:
+            monkeypatch.setenv('EAE_HIP_LATENT', stage_form)
+        for _ in range(2):
+            got = dev.conv5x5s2_latent(x, w3, b3, bw, mean, gdn_in=gdn_in, igdn_out=igdn_out, want_y=True, want_shifted=True,
+                                       want_flags=True, workspace=ws)
+            for key in ('y', 'shifted', 'symbols', 'nonzero_flags', 'checks') + (() if learned else ('t',)):
+                assert torch.equal(got[key].reshape(ref[key].shape), ref[key]), (key, stage_form)
+            assert int(torch.count_nonzero(ws).item()) == 0
+        monkeypatch.delenv('EAE_HIP_LATENT', raising=False)
     assert int(ref['symbols'].abs().max().item()) > 2            # the quantiser is exercised, not a field of zeros

@@ -241,7 +241,7 @@ def test_save_statistics_writes_the_three_kinds_of_files(tmp_path, capsys):
         bin_widths = ae.get_bin_widths()
     map_mean = numpy.load(path_mean)
     assert map_mean.shape == (128,) and map_mean.dtype == numpy.float32
-    assert numpy.allclose(map_mean, y.astype(numpy.float64).mean(axis=(0, 1, 2)), rtol=1e-6, atol=1e-7)
+    assert numpy.array_equal(map_mean, numpy.mean(y, axis=(0, 1, 2)))      # lossless/stats.py:306, bit for bit (test_map_means)
     with open(path_idx, 'rb') as f:
         idx = pickle.load(f)
     assert isinstance(idx, int) and idx == stats.find_index_map_exception(y)

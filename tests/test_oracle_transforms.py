@@ -140,3 +140,22 @@ def test_oracle_reproduces_the_committed_transform_fixture():
             for (name, a) in (('gdn_1', enc['gdn_1']), ('conv_3', enc['conv_3']), ('igdn_3', dec['igdn_3'])):
                 a = numpy.ascontiguousarray(a, dtype=numpy.float32)
                 assert float(zlib.crc32(a.tobytes())) == g[tag + '_sum_crc_' + name][1], (tag, name)
+
+
+@pytest.mark.parametrize('learned', [False, True])
+def test_the_torch_cpu_stand_in_of_the_cpu_baseline_follows_the_oracle(learned):
+    """oracle/transforms_torch.py (what `bench.py: cpu_baseline` times as the stand-in for TF-CPU's kernels) computes the same
+    graph as the C oracle: equal to float32 rounding of a different summation order (never used as a checker)."""
+    from oracle import transforms as orc, transforms_torch
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    v = var.random_variables(1., learned, seed=21, bias_std=0.01)
+    v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
+    x = numpy.random.RandomState(22).randint(16, 236, size=(2, 48, 80, 1)).astype(numpy.float32)
+    cpu = transforms_torch.CpuTransforms(v, learned)
+    y_ref = orc.encoder(x, v, learned)
+    y = cpu.encoder(x)
+    assert y.shape == y_ref.shape and numpy.allclose(y, y_ref, rtol=1e-4, atol=1e-4*float(numpy.abs(y_ref).max()))
+    q = numpy.round(y_ref)
+    rec_ref = orc.decoder(q, v, learned)
+    rec = cpu.decoder(q)
+    assert rec.shape == rec_ref.shape and numpy.allclose(rec, rec_ref, rtol=1e-4, atol=1e-4*float(numpy.abs(rec_ref).max()))

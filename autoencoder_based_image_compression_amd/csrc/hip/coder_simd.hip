@@ -1,31 +1,40 @@
-// coder_simd.hip -- the lossless coder reorganised for a 64-wide machine: 64 maps per wavefront, every lane in step.
+// coder_simd.hip -- the lossless coder reorganised for a 64-wide machine: the SERIAL part of a map's arithmetic coder cut down
+// to the interval arithmetic itself (64 maps per wavefront, every lane in step), everything else data-parallel around it.
 //
-// A binary arithmetic coder is a serial chain per stream (lossless/c++/source/BinaryArithmeticCoder.cpp:144-252), so the
-// only parallelism is across the feature maps of a batch. The per-lane kernels of coder_device.hip run the reference's
-// control flow in every lane; lanes diverge at every symbol, and the many long-lived waves cost the transform kernels
-// that run next to them about a tenth of their rate. Here the work is split so that the serial part is the same
-// instruction stream for all 64 lanes:
+// A binary arithmetic coder is a serial chain per stream (lossless/c++/source/BinaryArithmeticCoder.cpp:144-252), so the only
+// parallelism is across the feature maps of a batch, and what a batch costs is the LENGTH of the longest map's chain (the
+// transforms of the batches in flight have to cover it) times the instructions per link (every one of them delays the MFMA waves
+// the coder's waves share their SIMDs with). Round 2 ran ~75 (encoder) and ~105 (decoder) vector instructions per binary
+// decision, with bit I/O, Exp-Golomb escapes and sign bits inside the chain, and a second pass for streams longer than an LDS
+// window. Here the chain only does what is inherently serial (coder/lean_step.h, pinned to coder_core.h on the CPU by
+// tests/test_lean_coder.py):
 //
-//   encode   (1) binarise_kernel, one wavefront per map, fully parallel over the symbols: UEG0 binarisation
-//                (LosslessCoder.cpp:232-252) -> a list of (bit, context) decisions, one byte each, and the complete
-//                bypass stream (signs, Exp-Golomb suffixes: bit offsets by wave prefix sums).
-//            (2) bac_encode_kernel, 64 maps per wavefront: step j feeds decision j of every lane's map to the interval
-//                update; the renormalisation is closed-form and the pending-bit queue is emitted in one 64-bit put, so
-//                the step is branch-light and the lanes stay converged.
-//   decode   (3) bac_decode_kernel, 64 maps per wavefront: both streams of the 64 maps are staged in LDS; each step decodes
-//                one decision per lane and advances a three-register binarisation state (unary count, symbol index).
-//            (4) compare_kernel: decoded == encoded symbols (the assert of lossless/compression.py:146-153).
+//   encode   (1) binarise_kernel, one wavefront per map, parallel over the symbols: UEG0 binarisation (LosslessCoder.cpp:232-252)
+//                -> a list of (bit, context) decisions, one byte each, and the complete bypass stream (signs, Exp-Golomb
+//                suffixes: bit offsets by wave prefix sums).
+//            (2) bac_encode_core_kernel, 64 maps per wavefront: decision j of every lane's map through the interval update; the
+//                renormalisation is closed-form and NOTHING is written to the stream: each decision leaves a 32-bit record (the 16
+//                bits that may leave, the number of E1/E2 shifts, the number of E3 scalings), four records per 16-byte store.
+//            (3) emit_kernel, one wavefront per map, parallel over the records: the position of every leaving bit is a prefix sum
+//                of the emitted lengths, the pending-E3 queue a segmented sum of the scalings; tiles of 64 records are assembled
+//                in LDS and stored as whole words. Also the flush (stop_encoding) and the capacity check.
+//   decode   (4) bac_decode_core_kernel, 64 maps per wavefront: one decision per lane per step; the stream reaches the lanes through
+//                a 32-word LDS ring per lane that is topped up from memory every 8 steps (16-byte loads issued a checkpoint ahead
+//                of their use: no stream is "too long", nothing waits for memory), the code register and the interval are
+//                top-aligned; the lane tracks the truncated-unary context (it selects the next probability) and stores ONE BYTE per
+//                symbol, the unary prefix 0..L.
+//            (5) debinarise_kernel, one wavefront per map, parallel over the symbols: signs and Exp-Golomb suffixes out of the
+//                bypass stream (prefix sums; the escapes of a tile, whose lengths depend on the stream, in a short serial loop
+//                over LDS), the symbols, and the comparison with the encoder's input (the assert of lossless/compression.py:146-153).
 //
-// A stream longer than the decoder's LDS windows (64 / 16 words; 192 / 48 for maps of more than 4096 symbols) is decoded by
-// a second launch of the same kernel that reads the words beyond the window from memory. Anything else the fast kernels do
-// not handle -- an error of any kind (their exact code and stage matter), L == 0 or L > 32 -- marks the map RETRY, and the general
-// per-lane kernel (the shared core of coder_core.h, statement for statement the reference) recodes that map from
-// scratch. Results are therefore identical to the host library's in every case; tests/test_coder_device.py compares
-// bytes, bit counts, symbols, statuses and stages.
+// Anything these kernels do not handle -- an error of any kind (their exact code and stage matter), L == 0 or L > 32, a pending
+// E3 queue of thousands of bits -- marks the map RETRY, and the general per-lane kernel (the shared core of coder_core.h,
+// statement for statement the reference) recodes that map from scratch. Results are therefore identical to the host library's in
+// every case; tests/test_coder_device.py compares bytes, bit counts, symbols, statuses and stages.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../coder/coder_core.h"
+#include "../coder/lean_step.h"
 #include "eae_hip.h"
 
 // coder_device.hip
@@ -39,27 +48,21 @@ int eae_coder_generic_decode(uint32_t n_maps, uint32_t map_size, int16_t* out, u
 namespace {
 
 using namespace eae_core;
+using namespace eae_lean;
 
 #ifndef EAE_SIMD_PRIO
 #define EAE_SIMD_PRIO 3
 #endif
 
 constexpr int32_t RETRY = -100;           // internal: recode this map with the general kernel
-constexpr uint32_t kMaxFastL = 32;        // contexts staged in LDS: 32 x 64 lanes x 8 B = 16 KB
-// LDS windows per lane of the decoder, in dwords (arithmetic-coded stream, bypass stream). First pass: 2048 + 512 bits,
-// 20 KB per block, small enough to sit next to the transform kernels' blocks. Second pass, only for the maps the first
-// one found too long: 14336 + 3072 bits, 136 KB per block (one block per CU).
-constexpr uint32_t kBacWindowWords = 64, kBypassWindowWords = 16;
-// maps of more than kMediumMapSize symbols (latents of images beyond about 1 Mpixel) start with wider windows: their streams
-// would mostly overflow the small ones and the second pass costs a full serial decode of its own
-constexpr uint32_t kBacWindowWordsMedium = 192, kBypassWindowWordsMedium = 48, kMediumMapSize = 4096;
-// dynamic LDS of bac_decode_kernel<WB, WY>: probabilities [L + 1][64] doubles, windows [WB + 3][64] and [WY + 1][64] words
-constexpr size_t decode_lds_bytes(uint32_t L, uint32_t wb, uint32_t wy) {
-    return ((size_t)L + 1u) * 64u * sizeof(double) + ((size_t)wb + 3u + wy + 1u) * 64u * sizeof(uint32_t);
-}
+constexpr uint32_t kMaxFastL = 32;        // contexts staged in LDS: 33 x 64 lanes x 8 B = 17 KB
+constexpr uint32_t kRecordPad = 12;       // records beyond a map's decisions: the stop record + the tail of the last 16-byte store
+constexpr uint32_t kRing = 32;            // decoder: stream words per lane in LDS (a step takes <= 30 bits: 8 steps <= 8 words)
+constexpr uint32_t kEmitWords = 96;       // emit: 64-bit words of one tile of 64 records in LDS (carry + 63 x 64 + a long run or two)
 
 struct SimdParams {
     uint32_t n_maps, map_size, L, dcap;   // dcap: bytes of decision storage per map (multiple of 8)
+    uint32_t rcap;                        // records per map (dcap + kRecordPad, a multiple of 4)
     const int16_t* symbols;
     int16_t* decoded;
     const double* probs;
@@ -71,14 +74,14 @@ struct SimdParams {
     int32_t* status;
     int32_t* stage;
     uint8_t* decisions;                   // [group][j / 8][lane][8]
-    uint32_t* ndec;                       // [n_maps]
-    int32_t* perm;                        // decode, sorted form: [0..3] header (short blocks, long blocks), then 64 maps per block
+    uint32_t* ndec;                       // [n_maps]: decisions of a map (encode); 1 = handed to the general kernel (decode)
+    uint32_t* records;                    // [n_maps][rcap]
+    uint8_t* prefixes;                    // [n_maps][map_size] (decode; shares the records' memory)
 };
 
 // Exclusive prefix sum over the 64 lanes, and the total. Data-parallel primitives, not cross-lane loads: four row_shr steps scan
 // the rows of 16 lanes, row_bcast:15 / :31 carry the row totals on (the sequence LLVM's atomic optimiser emits for gfx9): 6 DPP
-// additions where six __shfl_up rounds were 6 x (ds_bpermute + compare + add) -- this runs once per 64 symbols of every map,
-// next to the transforms.
+// additions where six __shfl_up rounds were 6 x (ds_bpermute + compare + add).
 __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t& total) {
     int inc = (int)v;
     inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, false);     // row_shr:1
@@ -89,6 +92,24 @@ __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t& to
     inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
     total = (uint32_t)__builtin_amdgcn_readlane(inc, 63);
     return (uint32_t)inc - v;
+}
+// Exclusive running maximum over the lanes below (values >= -1; -1 where there is none): the same six DPP steps on max, applied
+// to the input moved up by one lane (wave_shr:1).
+__device__ __forceinline__ int wave_exclusive_max(int v) {
+    int m = __builtin_amdgcn_update_dpp(-1, v, 0x138, 0xF, 0xF, false);     // wave_shr:1
+#define EAE_MAX_STEP(ctrl_, rows_)                                                        \
+    {                                                                                     \
+        const int o_ = __builtin_amdgcn_update_dpp(-1, m, ctrl_, rows_, 0xF, false);      \
+        m = o_ > m ? o_ : m;                                                              \
+    }
+    EAE_MAX_STEP(0x111, 0xF)
+    EAE_MAX_STEP(0x112, 0xF)
+    EAE_MAX_STEP(0x114, 0xF)
+    EAE_MAX_STEP(0x118, 0xF)
+    EAE_MAX_STEP(0x142, 0xA)
+    EAE_MAX_STEP(0x143, 0xC)
+#undef EAE_MAX_STEP
+    return m;
 }
 __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 #pragma unroll
@@ -174,432 +195,362 @@ __global__ __launch_bounds__(64) void binarise_kernel(const SimdParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// (2) 64 maps per wavefront: decision j of every map through the interval update, in step
+// (2) 64 maps per wavefront: decision j of every map through the interval update, in step; one record per decision
 // ---------------------------------------------------------------------------------------------------------------------
 extern __shared__ double lds_dyn[];
 
-__global__ __launch_bounds__(64) void bac_encode_kernel(const SimdParams p) {
+__global__ __launch_bounds__(64) void bac_encode_core_kernel(const SimdParams p) {
     __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
     const uint32_t lane = threadIdx.x;
     const uint32_t m = blockIdx.x * 64u + lane;
     const bool in_range = m < p.n_maps;
     const int32_t row = in_range ? (p.prob_row ? p.prob_row[m] : (int32_t)m) : -1;
-    bool live = in_range && row >= 0 && p.status[m] == 0;
+    const bool live = in_range && row >= 0 && p.status[m] == 0;
     const uint32_t L = p.L;
-    double* probs = lds_dyn;                            // [context][lane]
+    double* probs = lds_dyn;                            // [context][lane], scaled by 2^-16 (lean_step.h)
     bool retry = false;
     if (live)
         for (uint32_t k = 0; k < L; k++) {
             const double pk = p.probs[(size_t)row * L + k];
-            probs[k * 64u + lane] = pk;
+            probs[k * 64u + lane] = scale_probability(pk);
             // An invalid probability only matters if its context is coded (BinaryArithmeticCoder.cpp:146-153): the general
             // kernel sorts that out; here the whole map is handed over so that the steps below need no check.
             if (!(pk > 0. && pk < 1.)) retry = true;
         }
-    uint32_t nd = live && !retry ? p.ndec[m] : 0u;     // set to 0 when the map leaves for the general kernel: its steps stop
+    const uint32_t nd = live && !retry ? p.ndec[m] : 0u;
     const uint32_t steps = wave_max(nd);
-    uint32_t err = 0;                                  // a condition only the general kernel reports (kept out of the branches)
-    Bac bac;
-    bac.init();
-    bac.bs.init_writer(p.streams + (uint64_t)(in_range ? m : 0u) * p.stride, required_bits(p.map_size, L));
     const uint8_t* dec = p.decisions + (size_t)blockIdx.x * 64u * p.dcap + (size_t)lane * 8u;
-    uint32_t low = 0, high = kRangeMax, e3 = 0;
+    uint32_t* rec = p.records + (size_t)(in_range ? m : 0u) * p.rcap;
+    Interval s = interval_init();
     uint2 ahead = steps ? *reinterpret_cast<const uint2*>(dec) : make_uint2(0, 0);
     for (uint32_t jb = 0; jb < steps; jb += 8) {
         const unsigned long long d8 = (unsigned long long)ahead.x | ((unsigned long long)ahead.y << 32);
         if (jb + 8 < steps) ahead = *reinterpret_cast<const uint2*>(dec + (size_t)((jb >> 3) + 1u) * 512u);
-        // eight steps emit at most the pending E3 bits + 8 x (16 leaving bits + 15 new E3 bits): near the end of the stream's
-        // capacity (Bitstream.cpp:32-35) the map goes to the general kernel, which reproduces the exact point of failure
-        if (bac.bs.write_index + e3 + 8u * 31u > bac.bs.size_bits) { err = 1u; nd = 0u; }
+        // the eight probabilities first: they depend on the decisions only, so their LDS latency stays out of the interval's
+        // dependency chain (a byte beyond the map's last decision may hold anything: its context is masked into the staged rows'
+        // range, the value is never used)
+        double pq[8];
 #pragma unroll
         for (uint32_t q = 0; q < 8; q++) {
-            const uint32_t j = jb + q;
-            if (j < nd) {
-                const uint32_t d = (uint32_t)(d8 >> (8u * q)) & 0xFFu;
-                const uint32_t bit = d & 1u;
-                const double pk = probs[(d >> 1) * 64u + lane];
-                // Bac::update_middle + encode_bit (BinaryArithmeticCoder.cpp:144-180)
-                const uint32_t mid = low + (uint32_t)(pk * (double)(high - low));
-                uint32_t nl = bit ? mid + 1u : low;
-                uint32_t nh = bit ? high : mid;
-                err |= nl > kRangeMax ? 1u : 0u;                     // precision_error (cannot happen with 0 < p < 1)
-                // E1/E2 in closed form (as Bac::encode): n leading equal bits leave, with the pending E3 bits behind the first
-                const uint32_t diff = (nl ^ nh) & 0xFFFFu;
-                const uint32_t n = diff ? (uint32_t)__builtin_clz(diff) - 16u : 16u;
-                if (n) {
-                    const uint32_t out = rev16(nh);
-                    const unsigned long long first = out & 1u;
-                    Bitstream& bs = bac.bs;
-                    auto put = [&](unsigned long long bits, uint32_t cnt) {     // cnt <= 63 bits, first in time at bit 0
-                        const uint32_t sh = bs.write_index & 63u;
-                        bs.acc |= bits << sh;
-                        if (sh + cnt >= 64u) {
-                            store64(bs.data + ((bs.write_index >> 6) << 3), bs.acc);
-                            bs.acc = sh ? bits >> (64u - sh) : 0ull;
-                        }
-                        bs.write_index += cnt;
-                    };
-                    if (e3 > 47u) {
-                        // a long run of pending E3 bits (maps that are almost all zeros): the leaving bit, then the run in
-                        // pieces, so that the single put below again holds at most 1 + 47 + 15 bits
-                        put(first, 1u);
-                        while (e3 > 32u) { put(first ? 0ull : 0xFFFFFFFFull, 32u); e3 -= 32u; }
-                        const unsigned long long run = first ? 0ull : ((1ull << e3) - 1ull);
-                        const unsigned long long rest = (out >> 1) & ((1u << (n - 1u)) - 1u);
-                        put(run | (rest << e3), n - 1u + e3);
-                    } else {
-                        // the leaving bit followed by e3 complements, first in time at bit 0: 1, or 0 then e3 ones = 2^(e3+1) - 2
-                        const unsigned long long head = first ? 1ull : ((2ull << e3) - 2ull);
-                        const unsigned long long rest = (out >> 1) & ((1u << (n - 1u)) - 1u);
-                        put(head | (rest << (1u + e3)), n + e3);
-                    }
-                    e3 = 0;
-                    nl = (nl << n) & 0xFFFFu;
-                    nh = ((nh << n) & 0xFFFFu) | ((1u << n) - 1u);
-                }
-                // E3 (BinaryArithmeticCoder.cpp:238-245) in closed form, see bac_decode_kernel: the number of scalings is the run
-                // of positions below the top bit where `low` has a 1 and `high` a 0, capped where `high` would reach 0xBFFE
-                {
-                    const uint32_t e3_run = (uint32_t)__builtin_clz(~(((nl & ~nh) & 0x7FFFu) << 17));
-                    const uint32_t e3_cap = 14u - (uint32_t)__builtin_ctz(~nh);
-                    const uint32_t k3 = nh > kRangeThreeQuarters || nl <= kRangeQuarter ? 0u : (e3_run < e3_cap ? e3_run : e3_cap);
-                    nl = (((nl - 0x8000u) << k3) + 0x8000u) & kRangeMax;
-                    nh = (((nh - 0x8000u) << k3) + 0x8000u + ((1u << k3) - 1u)) & kRangeMax;
-                    e3 += k3;
-                }
-                low = nl;
-                high = nh;
-            }
+            const uint32_t ctx = (uint32_t)(d8 >> (8u * q + 1u)) & 31u;
+            pq[q] = probs[(ctx < L ? ctx : 0u) * 64u + lane];
         }
+        uint32_t r[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+            r[q] = 0u;
+            if (jb + q < nd) r[q] = encode_step(s, pq[q], ((uint32_t)(d8 >> (8u * q)) & 1u) != 0u);
+        }
+        // four records per 16-byte store (up to three entries beyond the map's last decision: the pad of rcap)
+        if (jb < nd) *reinterpret_cast<uint4*>(rec + jb) = make_uint4(r[0], r[1], r[2], r[3]);
+        if (jb + 4u < nd) *reinterpret_cast<uint4*>(rec + jb + 4u) = make_uint4(r[4], r[5], r[6], r[7]);
     }
-    if (err) retry = true;
     if (live) {
-        int s = OK;
-        if (!retry) {
-            bac.low = low;
-            bac.high = high;
-            bac.nb_e3 = e3;
-            s = bac.stop_encoding();                    // BinaryArithmeticCoder.cpp:61-102, flushes the stream
-        }
-        if (retry || s) p.status[m] = RETRY;            // the general kernel reproduces the exact code and stage
-        else p.bac_bits[m] = bac.bs.write_index;
+        if (retry) p.status[m] = RETRY;                 // the general kernel reproduces the exact code and stage
+        else rec[nd] = stop_record(s);                  // BinaryArithmeticCoder.cpp:61-102; emitted by emit_kernel
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// (3) 64 maps per wavefront: decode, streams staged in LDS
+// (3) one wavefront per map: records -> the arithmetic-coded stream
 // ---------------------------------------------------------------------------------------------------------------------
-// MODE 0 / 1: first / second pass over the maps in their own order (maps 64 b .. 64 b + 63 in block b). MODE 2: ONE launch
-// over the maps sorted by sort_maps_kernel into blocks of short maps (streams fit the windows) and blocks of long ones: a block
-// is either all first-pass or all second-pass work, so no map is walked twice and no wavefront runs both loops. At the rates
-// of trained models (~1 bit per pixel) most maps are long and nearly every group of 64 held both kinds: the two passes then
-// cost two full serial decodes (1.94 ms per Kodak batch at 0.9 bpp against 0.57 ms at 0.19 bpp).
-template <uint32_t WB, uint32_t WY, int MODE, bool SECOND>
-__device__ __forceinline__ void bac_decode_body(const SimdParams& p, const uint32_t m) {
+// Record j shifts n_j bits out (when n_j > 0): the first of them, then the pending-E3 queue as it stands (P_j copies of the
+// complement, BinaryArithmeticCoder.cpp:322-337), then the other n_j - 1; afterwards the queue holds the record's own k_j
+// scalings. So P_j = the k's of the records since (and including) the last one that shifted anything out, and the position of
+// record j's bits is the sum of n + P over the records before it: two prefix sums and a running maximum per tile of 64 records.
+__global__ __launch_bounds__(64) void emit_kernel(const SimdParams p) {
+    __shared__ unsigned long long buf[kEmitWords + 2];
+    const uint32_t m = blockIdx.x, lane = threadIdx.x;
+    const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
+    if (row < 0 || p.status[m] != 0) return;
+    const uint32_t nrec = p.ndec[m] + 1u;               // the stop record closes the stream
+    const uint32_t* rec = p.records + (size_t)m * p.rcap;
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(p.streams + (uint64_t)m * p.stride);
+    const uint32_t size_bits = round_up_to_byte(required_bits(p.map_size, p.L));
+    for (uint32_t w = lane; w < kEmitWords + 2u; w += 64u) buf[w] = 0ull;
+    uint32_t base = 0, pending = 0;                     // bits emitted so far; the queue in front of the tile
+    bool give_up = false;
+    for (uint32_t t = 0; t < nrec; t += 64u) {
+        const uint32_t j = t + lane;
+        const uint32_t r = j < nrec ? rec[j] : 0u;
+        const uint32_t n = record_n(r), k = record_k(r);
+        const bool has = n != 0u;
+        uint32_t ktot;
+        const uint32_t e = wave_exclusive_scan(k, ktot);                               // scalings of the tile's records below this lane
+        const int since = wave_exclusive_max(has ? (int)e : -1);                         // ... below the last record that shifted out
+        const uint32_t queue = (since >= 0 ? e - (uint32_t)since : pending + e) + (record_is_stop(r) ? 1u : 0u);
+        const uint32_t c = has ? n + queue : 0u;
+        uint32_t ctot;
+        const uint32_t o = wave_exclusive_scan(c, ctot);
+        // the queue behind the tile: the k's from the last record that shifted out onwards
+        const unsigned long long mask = __ballot(has);
+        if (mask) {
+            const int last = 63 - __builtin_clzll(mask);
+            pending = ktot - (uint32_t)__builtin_amdgcn_readlane((int)e, last);
+        } else {
+            pending += ktot;
+        }
+        const uint32_t start = base & 63u;              // bits of the carried partial word in buf[0]
+        // the tile must fit the LDS buffer and the stream its capacity (Bitstream.cpp:32-35): otherwise the general kernel
+        if (start + ctot > kEmitWords * 64u || base + ctot > size_bits) { give_up = true; break; }
+        if (has) {
+            const uint32_t lead = record_leaving(r);
+            const unsigned long long first = lead >> 31;
+            // the other n - 1 leaving bits, first in time at bit 0
+            const unsigned long long rest = (unsigned long long)(__builtin_bitreverse32(lead << 1) & ((1u << (n - 1u)) - 1u));
+            const uint32_t pos = start + o;
+            if (c <= 64u) {
+                // first bit, `queue` complements, the rest: at most 64 bits in one piece (queue <= 63 here)
+                const unsigned long long run = first ? 0ull : (((queue < 63u ? (1ull << queue) : (1ull << 63)) - 1ull) | (queue == 63u ? (1ull << 62) : 0ull));
+                const unsigned long long v = first | (run << 1) | (queue + 1u < 64u ? rest << (queue + 1u) : 0ull);
+                const uint32_t sh = pos & 63u;
+                atomicOr(&buf[pos >> 6], v << sh);
+                if (sh + c > 64u) atomicOr(&buf[(pos >> 6) + 1u], v >> (64u - sh));
+            } else {
+                // a long queue (nearly dead maps under a very skewed first probability): the first bit, the run word by word, the rest
+                if (first) atomicOr(&buf[pos >> 6], 1ull << (pos & 63u));
+                if (!first) {
+                    uint32_t b0 = pos + 1u;
+                    const uint32_t b1 = pos + 1u + queue;            // ones over [b0, b1)
+                    while (b0 < b1) {
+                        const uint32_t sh = b0 & 63u;
+                        const uint32_t cnt = (b1 - b0) < (64u - sh) ? (b1 - b0) : (64u - sh);
+                        const unsigned long long ones = cnt == 64u ? ~0ull : (((1ull << cnt) - 1ull) << sh);
+                        atomicOr(&buf[b0 >> 6], ones);
+                        b0 += cnt;
+                    }
+                }
+                const uint32_t pr = pos + 1u + queue, sh = pr & 63u;
+                if (rest) {
+                    atomicOr(&buf[pr >> 6], rest << sh);
+                    if (sh + (n - 1u) > 64u) atomicOr(&buf[(pr >> 6) + 1u], rest >> (64u - sh));
+                }
+            }
+        }
+        // complete words to the stream, the partial one stays as the next tile's carry
+        const uint32_t nfull = (start + ctot) >> 6;
+        for (uint32_t w = lane; w < nfull; w += 64u) out[(base >> 6) + w] = buf[w];
+        const unsigned long long carry = buf[nfull];
+        for (uint32_t w = lane; w <= nfull; w += 64u) buf[w] = 0ull;
+        if (lane == 0) buf[0] = carry;
+        base += ctot;
+    }
+    if (lane == 0) {
+        if (give_up) {
+            p.status[m] = RETRY;
+        } else {
+            if (base & 63u) out[base >> 6] = buf[0];     // Bitstream flush of the partial word (zeros above the last bit)
+            p.bac_bits[m] = base;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (4) 64 maps per wavefront: decode the decisions; one prefix byte per symbol
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS of a block: scaled probabilities [L + 1][64] doubles (one row beyond L: read ahead of an escape, never used), then the ring
+// [kRing][64] words.
+constexpr size_t decode_lds_bytes(uint32_t L) { return ((size_t)L + 1u) * 64u * sizeof(double) + (size_t)kRing * 64u * sizeof(uint32_t); }
+
+__global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p) {
+    __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
     const uint32_t lane = threadIdx.x;
+    const uint32_t m = blockIdx.x * 64u + lane;
     const bool in_range = m < p.n_maps;
     const int32_t row = in_range ? (p.prob_row ? p.prob_row[m] : (int32_t)m) : -1;
     const uint32_t L = p.L;
-    // LDS: probabilities [L + 1][lane], arithmetic-coded window [WB + 3][lane], bypass window [WY + 1][lane]. The extra rows
-    // let the step below read one context / up to three words / one word beyond the valid ones without a guard (see
-    // decode_lds_bytes): a zeroed word is what the reference reads beyond the end of a stream anyway.
     double* probs = lds_dyn;
-    uint32_t* wbac = reinterpret_cast<uint32_t*>(lds_dyn + ((size_t)L + 1u) * 64u);
-    uint32_t* wbyp = wbac + (WB + 3u) * 64u;
-    // First pass (SECOND == false): the streams of the 64 maps must fit the LDS windows of WB / WY words; a map whose streams
-    // do not is marked RETRY. Second pass (same windows, so the same modest LDS request: a launch that asks for most of a
-    // CU's LDS waits for a CU to drain, 0.2 ms next to the transforms even when it has nothing to do): only the RETRY maps,
-    // and a lane whose stream is longer than the window fetches the words beyond it from memory itself, one load per word
-    // (the wave waits for that load: slower, but exact and unbounded).
-    bool live = in_range && row >= 0 && p.status[m] == (MODE == 1 ? RETRY : 0);
-    if (MODE == 1 && !__any(live)) return;                  // nothing was handed on to this pass in this group of 64 maps
+    uint32_t* ring = reinterpret_cast<uint32_t*>(lds_dyn + ((size_t)L + 1u) * 64u) + lane;      // row w of this lane: ring[(w & 31) * 64]
+    const bool live = in_range && row >= 0 && p.status[m] == 0;
     const uint32_t nbac = live ? p.bac_bits[m] : 0u;
-    const uint32_t nbyp = live ? p.bypass_bits[m] : 0u;
-    const uint32_t* gbac = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)(in_range ? m : 0u) * p.stride);
-    const uint32_t* gbyp = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)(in_range ? m : 0u) * p.stride + p.stride / 2);
     bool retry = false;
-    if (live && (nbac > p.stride * 4u || nbyp > p.stride * 4u)) retry = true;    // beyond the buffer: not a stream of ours
-    if (!SECOND && live && (nbac > WB * 32u || nbyp > WY * 32u)) retry = true;   // longer than the window: second pass
+    if (live && (nbac > p.stride * 4u || p.bypass_bits[m] > p.stride * 4u)) retry = true;       // beyond the buffer: not a stream of ours
     if (live) {
         for (uint32_t k = 0; k < L; k++) {
             const double pk = p.probs[(size_t)row * L + k];
-            probs[k * 64u + lane] = pk;
+            probs[k * 64u + lane] = scale_probability(pk);
             if (!(pk > 0. && pk < 1.)) retry = true;     // only an error if that context is decoded: general kernel
         }
-        probs[L * 64u + lane] = 0.5;                     // read ahead of an escape, never used
+        probs[L * 64u + lane] = scale_probability(0.5);
     }
-    // stage the streams of the 64 maps: the wave copies one map per iteration, coalesced
-    for (uint32_t l = 0; l < 64u; l++) {
-        const uint32_t ml = __shfl(m, l, 64);
-        if (ml >= p.n_maps) { if (MODE == 2) continue; else break; }
-        const uint32_t bits_b = __shfl(nbac, l, 64), bits_y = __shfl(nbyp, l, 64);
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)ml * p.stride);
-        for (uint32_t w = lane; w < WB && w * 32u < bits_b; w += 64u) wbac[w * 64u + l] = src[w];
-        const uint32_t* srcy = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)ml * p.stride + p.stride / 2);
-        for (uint32_t w = lane; w < WY && w * 32u < bits_y; w += 64u) wbyp[w * 64u + l] = srcy[w];
-    }
-    {   // zeros behind the last word of this lane's stream: at most three window words are loaded beyond it (a refill happens
-        // at 32 buffered bits or fewer and only stream bits are ever consumed: refills <= bits / 32 + 2)
-        const uint32_t nwords = retry ? 0u : (nbac + 31u) >> 5;
-        if (nwords <= WB)
-            for (uint32_t t = 0; t < 3u; t++) wbac[(nwords + t) * 64u + lane] = 0u;
-    }
-    __syncthreads();
-    int16_t* out = p.decoded + (size_t)(in_range ? m : 0u) * p.map_size;
-    uint32_t low = 0, high = kRangeMax, code = 0, ridx = 0, yidx = 0;
-    // rwin: the next rcount bits of the arithmetic-coded stream, LEFT-aligned with the next bit in time at bit 63, so that
-    // "the next k bits, first in time most significant" (what the 16-bit code register wants) is one shift, not a bit reversal
-    unsigned long long rwin = 0;
-    uint32_t rcount = 0, rword = 0;       // rword: next dword of the window to load
-    auto refill = [&]() {                 // 32 more bits once at most 32 are left, zeros beyond the stream
-        const bool need = rcount <= 32u;
-        const bool have = rword < WB && rword * 32u < nbac;                  // priming reads word 0 only
-        const uint32_t w = wbac[(have ? rword : 0u) * 64u + lane];
-        rwin |= (unsigned long long)(need && have ? __builtin_bitreverse32(w) : 0u) << (need ? 32u - rcount : 0u);
-        rcount += need ? 32u : 0u;
-        rword += need ? 1u : 0u;
+    const uint32_t size = live && !retry ? p.map_size : 0u;
+    const uint4* src = reinterpret_cast<const uint4*>(p.streams + (uint64_t)(in_range ? m : 0u) * p.stride);
+    const uint32_t nwords = size ? (nbac + 31u) >> 5 : 0u;          // words that hold stream bits; everything beyond reads as zero
+    // a group of four words from memory, bit-reversed (the next bit in time most significant) and zero beyond the stream
+    auto fetch = [&](uint32_t w0) {                                  // w0: a multiple of 4
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (w0 < nwords) v = src[w0 >> 2];
+        v.x = w0 + 0u < nwords ? __builtin_bitreverse32(v.x) : 0u;
+        v.y = w0 + 1u < nwords ? __builtin_bitreverse32(v.y) : 0u;
+        v.z = w0 + 2u < nwords ? __builtin_bitreverse32(v.z) : 0u;
+        v.w = w0 + 3u < nwords ? __builtin_bitreverse32(v.w) : 0u;
+        return v;
     };
-    auto take = [&](uint32_t k) {         // k <= 16 bits off the window (k == 0: nothing, returns 0)
-        const uint32_t bits = (uint32_t)((rwin >> 1) >> (63u - k));
-        rwin <<= k;
-        rcount -= k;
-        return bits;
+    auto land = [&](uint32_t w0, const uint4& v) {
+        ring[((w0 + 0u) & (kRing - 1u)) * 64u] = v.x;
+        ring[((w0 + 1u) & (kRing - 1u)) * 64u] = v.y;
+        ring[((w0 + 2u) & (kRing - 1u)) * 64u] = v.z;
+        ring[((w0 + 3u) & (kRing - 1u)) * 64u] = v.w;
     };
-    bool active = live && !retry;
-    if (active) {
-        // Bac::start_decoding (BinaryArithmeticCoder.cpp:104-122): 16 bits, the last one repeated once the stream is exhausted
-        refill();
-        const uint32_t k = nbac < 16u ? nbac : 16u;
-        uint32_t bits = take(k);
+    // the ring starts full: words 0 .. 31
+#pragma unroll
+    for (uint32_t w0 = 0; w0 < kRing; w0 += 4u) land(w0, fetch(w0));
+    uint32_t loaded = kRing;              // words [0, loaded) have been in the ring
+    // the window: the next `rcount` stream bits, left-aligned (the next bit in time at bit 63)
+    unsigned long long rwin = ((unsigned long long)ring[0] << 32) | (unsigned long long)ring[64];
+    uint32_t rcount = 64u, rword = 2u;
+    // Bac::start_decoding (BinaryArithmeticCoder.cpp:104-122): 16 bits, the last one repeated once the stream is exhausted
+    uint32_t left = nbac;                 // stream bits not yet taken
+    uint32_t code32;
+    {
+        const uint32_t k = left < 16u ? left : 16u;
+        uint32_t bits = (uint32_t)((rwin >> 1) >> (63u - k));
         const uint32_t sticky = bits & 1u;
         bits = (bits << (16u - k)) | (sticky ? ((1u << (16u - k)) - 1u) : 0u);
-        code = bits;
-        ridx = k;
+        rwin <<= k;
+        rcount -= k;
+        left -= k;
+        code32 = bits << 16;
     }
-    uint32_t unary = 0, i = 0;
-    const uint32_t size = p.map_size;
-    if (size == 0) active = false;
-    // One decision per lane per iteration. The body is written without lane-divergent branches except for the rare events
-    // (E3 scalings, Exp-Golomb escapes): a lone wavefront issues an instruction every 6-7 cycles, so the length of this loop
-    // IS the decoder's speed, and every divergent `if` costs a handful of scalar mask instructions on top of its body.
-    // The three LDS reads of a step are issued one step ahead of their use (the window word of the next refill, the
-    // probability of the context the next decision will be in if this one is a one, the bypass word holding the next sign
-    // bit): none of their latencies sits in the decision -> decision dependency chain.
-    const double p0 = active ? probs[lane] : 0.5;
+    Interval s = interval_init();
+    const double p0 = probs[lane];
     double pk = p0;
-    uint32_t gw = 0, gw_ahead = 0, gw_row = 0xFFFFFFF0u, gy = 0, gy_row = 0xFFFFFFFFu;   // the words held from beyond the windows
-    // (macros, not lambdas: with the held words captured by reference the compiler kept them in scratch memory and turned
-    // the LDS read into a flat load selecting between LDS and scratch, waited for in every step)
-#define EAE_WINDOW_WORD(dst_)                                                                                         \
-    {                                                                                                                 \
-        dst_ = wbac[(!SECOND || rword < WB + 2u ? rword : WB + 2u) * 64u + lane];                                     \
-        if (SECOND && rword >= WB) {                                                                                  \
-            /* beyond the window: the word comes from memory. The word after it is requested at the same time and has */  \
-            /* the ~30 steps it takes to use up 32 bits to arrive (a load per word on demand stalled the wave for a   */  \
-            /* memory round trip every time any of its 64 lanes crossed a word boundary)                              */  \
-            if (rword != gw_row) {                                                                                    \
-                gw = rword == gw_row + 1u ? gw_ahead : (rword * 32u < nbac ? gbac[rword] : 0u);                       \
-                gw_row = rword;                                                                                       \
-                gw_ahead = (rword + 1u) * 32u < nbac ? gbac[rword + 1u] : 0u;                                         \
-            }                                                                                                         \
-            dst_ = gw;                                                                                                \
-        }                                                                                                             \
-    }
-#define EAE_BYPASS_WORD(dst_, yrow_)                                                                                  \
-    {                                                                                                                 \
-        const uint32_t yr_ = (yrow_);                                                                                 \
-        dst_ = wbyp[(yr_ < WY ? yr_ : WY) * 64u + lane];                                                              \
-        if (SECOND && yr_ >= WY) {                                                                                    \
-            if (yr_ != gy_row) { gy = yr_ * 32u < nbyp ? gbyp[yr_] : 0u; gy_row = yr_; }                              \
-            dst_ = gy;                                                                                                \
-        }                                                                                                             \
-    }
-    uint32_t wnext = 0u;
-    if (active) EAE_WINDOW_WORD(wnext)
-    uint32_t err = 0;
-    while (active) {
-        {   // refill: 32 more bits once at most 32 are left, zeros beyond the stream
-            const bool need = rcount <= 32u;
-            rwin |= (unsigned long long)(need ? __builtin_bitreverse32(wnext) : 0u) << (need ? 32u - rcount : 0u);
-            rcount += need ? 32u : 0u;
-            rword += need ? 1u : 0u;
-        }
-        uint32_t wload;
-        EAE_WINDOW_WORD(wload)
-        const double pspec = probs[(unary + 1u) * 64u + lane];
-        uint32_t yword;
-        EAE_BYPASS_WORD(yword, yidx >> 5)
-        // Bac::decode (BinaryArithmeticCoder.cpp:124-134, 254-320) with the closed-form renormalisation of coder_core.h
-        const uint32_t mid = low + (uint32_t)(pk * (double)(high - low));
-        const uint32_t bit = code > mid ? 1u : 0u;
-        uint32_t nl = bit ? mid + 1u : low;
-        uint32_t nh = bit ? high : mid;
-        const uint32_t diff = (nl ^ nh) & 0xFFFFu;
-        const uint32_t n = diff ? (uint32_t)__builtin_clz(diff) - 16u : 16u;
-        nl = (nl << n) & kRangeMax;
-        nh = ((nh << n) & kRangeMax) | ((1u << n) - 1u);
-        // E3 in closed form too. After E1/E2 the intervals' top bits are 0 / 1; one E3 scaling (BinaryArithmeticCoder.cpp:
-        // 238-245, 300-318) deletes the bit below them when it is 1 in `low` and 0 in `high`, so the loop runs once per
-        // leading position where that holds (e3_run) -- except that the reference compares `high` with 3 * 0x3FFF = 0xBFFD,
-        // not 0xBFFF: it also stops as soon as `high` has become 0xBFFE / 0xBFFF, i.e. after 14 - (trailing ones of high)
-        // scalings. k scalings map v to 2^k (v - 2^15) + 2^15 (+ 2^k - 1 for `high`, + the k new stream bits for the code
-        // register), all modulo 2^16 like the loop's masks.
-        const uint32_t e3_run = (uint32_t)__builtin_clz(~(((nl & ~nh) & 0x7FFFu) << 17));
-        const uint32_t e3_cap = 14u - (uint32_t)__builtin_ctz(~nh);
-        const uint32_t k3 = nh > kRangeThreeQuarters ? 0u : (e3_run < e3_cap ? e3_run : e3_cap);
-        {
-            // the n bits that E1/E2 shift in and the k3 bits of the E3 scalings leave the window together (at most 30 of the
-            // 33 or more buffered); beyond the end of the stream the last real bit repeats, and no bit at all reads as 0
-            const uint32_t total = n + k3;
-            const uint32_t avail = nbac - ridx;
-            const uint32_t k = total < avail ? total : avail;
-            uint32_t bits = take(k);                                       // first in time most significant
-            const uint32_t sticky = bits & 1u;
-            const uint32_t ext = total - k;
-            bits = (bits << ext) | (sticky ? ((1u << ext) - 1u) : 0u);
-            ridx += k;
-            code = ((code << n) & kRangeMax) | (bits >> k3);
-            code = (((code - 0x8000u) << k3) + 0x8000u + (bits & ((1u << k3) - 1u))) & kRangeMax;
-            nl = (((nl - 0x8000u) << k3) + 0x8000u) & kRangeMax;
-            nh = (((nh - 0x8000u) << k3) + 0x8000u + ((1u << k3) - 1u)) & kRangeMax;
-        }
-        low = nl;
-        high = nh;
-        // binarisation state (LosslessCoder.cpp:193-230, 254-276): a one advances the unary count up to L, a zero ends it
-        const bool escape = bit && unary + 1u == L;
-        const bool done = !bit || escape;
-        uint32_t a = bit ? L : unary;
-        bool bad = false;
-        if (escape) {
-            // Exp-Golomb suffix from the bypass stream (LosslessCoder.cpp:113-165)
-            uint32_t nn = 0;
-            for (;;) {
-                if (yidx >= nbyp) { bad = true; break; }
-                uint32_t yw;
-                EAE_BYPASS_WORD(yw, yidx >> 5)
-                const uint32_t b = (yw >> (yidx & 31u)) & 1u;
-                yidx++;
-                if (!b) break;
-                nn++;
-                if (nn > 16u) { bad = true; break; }
+    uint32_t unary = 0, i = 0;
+    uint8_t* prefix = p.prefixes + (size_t)(in_range ? m : 0u) * p.map_size;
+    const uint32_t steps_left_any = wave_max(size);       // 0: nothing to do in this block
+    uint4 fa = make_uint4(0u, 0u, 0u, 0u), fb = fa;        // eight words on their way from memory
+    bool flying = false;
+    if (steps_left_any) {
+        for (;;) {
+            // ---- checkpoint, every 8 steps: the words requested at the last checkpoint enter the ring (their rows hold words this
+            // lane has already moved to its window: it was at most 24 words behind `loaded` when they were requested), and the next
+            // eight are requested when this lane is at most 24 words behind. A step takes at most 30 bits, so the ring cannot run dry.
+            if (flying) {
+                land(loaded, fa);
+                land(loaded + 4u, fb);
+                loaded += 8u;
             }
-            uint32_t suffix = 0;
-            for (uint32_t q = 0; q < nn && !bad; q++) {
-                if (yidx >= nbyp) { bad = true; break; }
-                uint32_t yw;
-                EAE_BYPASS_WORD(yw, yidx >> 5)
-                suffix = (suffix << 1) | ((yw >> (yidx & 31u)) & 1u);
-                yidx++;
+            flying = loaded - rword <= kRing - 8u;
+            if (flying) {
+                fa = fetch(loaded);
+                fb = fetch(loaded + 4u);
             }
-            a = (L + ((suffix + (1u << nn) - 1u) & 0xFFFFu)) & 0xFFFFu;    // uint16 arithmetic of the reference
-            EAE_BYPASS_WORD(yword, yidx >> 5)                              // the sign now sits further on
-            if (bad) err = 1u;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                if (i < size) {
+                    // top the window up: 32 more bits once at most 32 are left (the read is unconditional, its use is not)
+                    const uint32_t wnext = ring[(rword & (kRing - 1u)) * 64u];
+                    const double pspec = probs[(unary + 1u) * 64u + lane];
+                    const bool need = rcount <= 32u;
+                    rwin |= (unsigned long long)(need ? wnext : 0u) << (need ? 32u - rcount : 0u);
+                    rcount += need ? 32u : 0u;
+                    rword += need ? 1u : 0u;
+                    // Bac::decode (BinaryArithmeticCoder.cpp:124-134, 254-320), lean_step.h
+                    const DecodeStep d = decode_step(s, code32, pk);
+                    // the d.take stream bits of this step; beyond the end of the stream the last real bit of THIS step repeats,
+                    // and no bit at all reads as 0 (the `storage` of rescale_decoding)
+                    const uint32_t k = d.take < left ? d.take : left;
+                    uint32_t bits = (uint32_t)((rwin >> 1) >> (63u - k));
+                    const uint32_t ext = d.take - k;
+                    bits = (bits << ext) | ((bits & 1u) ? ((1u << ext) - 1u) : 0u);
+                    rwin <<= k;
+                    rcount -= k;
+                    left -= k;
+                    code32 = shift_code(code32, d, bits);
+                    // binarisation state (LosslessCoder.cpp:193-230): a one advances the unary count up to L, a zero ends it
+                    const bool done = !d.one || unary + 1u == L;
+                    if (done) prefix[i] = (uint8_t)(d.one ? L : unary);
+                    i += done ? 1u : 0u;
+                    unary = done ? 0u : unary + 1u;
+                    pk = done ? p0 : pspec;
+                }
+            }
+            if (!__any(i < size)) break;
         }
+    }
+    if (live && retry) p.status[m] = RETRY;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// (5) one wavefront per map: prefixes + bypass stream -> symbols; compare with the encoder's input
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void debinarise_kernel(const SimdParams p) {
+    __shared__ uint32_t ytile[80];                     // the bypass words a tile of 64 symbols can touch: 64 x 34 bits + alignment
+    const uint32_t m = blockIdx.x, lane = threadIdx.x;
+    const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
+    if (lane == 0 && p.ndec) p.ndec[m] = 0u;           // 1: handed to the general kernel (compare_kernel looks at it afterwards)
+    if (row < 0 || p.status[m] != 0) {
+        if (row >= 0 && p.status[m] == RETRY && lane == 0 && p.ndec) p.ndec[m] = 1u;
+        return;
+    }
+    const uint32_t L = p.L, size = p.map_size;
+    const uint32_t nbyp = p.bypass_bits[m];
+    const uint32_t* gbyp = reinterpret_cast<const uint32_t*>(p.streams + (uint64_t)m * p.stride + p.stride / 2);
+    const uint32_t ywords = (nbyp + 31u) >> 5;
+    const uint8_t* prefix = p.prefixes + (size_t)m * size;
+    const int16_t* expected = p.symbols ? p.symbols + (size_t)m * size : nullptr;
+    int16_t* out = p.decoded ? p.decoded + (size_t)m * size : nullptr;
+    uint32_t ybase = 0;                                // bypass bits consumed so far
+    bool bad = false, differ = false;
+    for (uint32_t t = 0; t < size; t += 64u) {
+        // the window of the bypass stream this tile can touch, zero beyond the stream
+        const uint32_t w0 = ybase >> 5;
+        ytile[lane] = w0 + lane < ywords ? gbyp[w0 + lane] : 0u;
+        if (lane < 16u) ytile[64u + lane] = w0 + 64u + lane < ywords ? gbyp[w0 + 64u + lane] : 0u;
+        auto bits_at = [&](uint32_t pos) {             // 32 stream bits from position `pos`, the first in time at bit 0
+            const uint32_t rel = pos - (w0 << 5), q = rel >> 5, sh = rel & 31u;
+            const unsigned long long two = (unsigned long long)ytile[q] | ((unsigned long long)ytile[q + 1u] << 32);
+            return (uint32_t)(two >> sh);
+        };
+        const uint32_t i = t + lane;
+        const bool valid = i < size;
+        uint32_t a = valid ? (uint32_t)prefix[i] : 0u;
+        const bool nonzero = a != 0u;
+        uint32_t ntot;
+        uint32_t at = wave_exclusive_scan(nonzero ? 1u : 0u, ntot);      // sign bits of the symbols below this lane ...
+        uint32_t extra = 0;                                             // ... and Exp-Golomb codes up to and including this lane's
+        unsigned long long escapes = __ballot(valid && a == L);
+        uint32_t extra_tot = 0;
+        while (escapes) {
+            // one escape of the tile at a time, in symbol order (its position depends on the lengths of the ones before it);
+            // every lane reads the same bits (LosslessCoder.cpp:113-165): nn ones, a zero, nn suffix bits (most significant first)
+            const int e = __builtin_ctzll(escapes);
+            escapes &= escapes - 1ull;
+            const uint32_t pos = ybase + (uint32_t)__builtin_amdgcn_readlane((int)at, e) + extra_tot;
+            const uint32_t w = bits_at(pos);
+            const uint32_t nn = (uint32_t)__builtin_ctz(~w | 0x80000000u);
+            if (nn > 16u || pos + 2u * nn + 1u > nbyp) { bad = true; break; }     // malformed or truncated: general kernel
+            const uint32_t suffix = nn ? __builtin_bitreverse32(bits_at(pos + nn + 1u)) >> (32u - nn) : 0u;
+            const uint32_t value = (L + ((suffix + (1u << nn) - 1u) & 0xFFFFu)) & 0xFFFFu;      // uint16 arithmetic of the reference
+            const uint32_t len = 2u * nn + 1u;
+            if ((int)lane == e) a = value;
+            if ((int)lane >= e) extra += len;
+            extra_tot += len;
+        }
+        if (bad) break;
+        // the sign of a non-zero symbol follows its Exp-Golomb code (LosslessCoder.cpp:39-56, 254-276): 0 = negative
+        const uint32_t spos = ybase + at + extra;
+        if (nonzero && spos >= nbyp) bad = true;        // resource_error: the general kernel reports it
+        if (__any(bad)) { bad = true; break; }
         int v = (int)(int16_t)a;
-        // sign bit of a non-zero symbol (LosslessCoder.cpp:39-56). A sign missing from the bypass stream (resource_error) is
-        // noticed after the loop (yidx > nbyp): the lane runs on over zero bits and the general kernel reports the exact status
-        const bool nonzero = done && v != 0;
-        const uint32_t sign = (yword >> (yidx & 31u)) & 1u;
-        v = nonzero && !sign ? -v : v;
-        yidx += nonzero ? 1u : 0u;
-        if (done) out[i] = (int16_t)v;
-        i += done ? 1u : 0u;
-        unary = done ? 0u : unary + 1u;
-        pk = done ? p0 : pspec;
-        wnext = wload;
-        active = i < size && err == 0u;
+        if (nonzero && !(bits_at(spos) & 1u)) v = -v;
+        if (valid) {
+            if (out) out[i] = (int16_t)v;
+            if (expected && expected[i] != (int16_t)v) differ = true;
+        }
+        ybase += ntot + extra_tot;
     }
-    if (live && !retry && (err != 0u || yidx > nbyp || i < size)) retry = true;   // something only the general kernel reports
-    if (live) p.status[m] = retry ? RETRY : 0;
-#undef EAE_WINDOW_WORD
-#undef EAE_BYPASS_WORD
-}
-
-template <uint32_t WB, uint32_t WY, int MODE>
-__global__ __launch_bounds__(64) void bac_decode_kernel(const SimdParams p) {
-    __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
-    const uint32_t lane = threadIdx.x;
-    if (MODE == 2) {
-        const uint32_t short_blocks = (uint32_t)p.perm[0], long_blocks = (uint32_t)p.perm[1];
-        if (blockIdx.x >= short_blocks + long_blocks) return;
-        const uint32_t m = (uint32_t)p.perm[4u + blockIdx.x * 64u + lane];          // 0xFFFFFFFF pads the last block of a kind
-        // two copies of the loop, each with its windows' bounds known at compile time (a block-uniform flag inside ONE copy
-        // cost the short maps 18 %: three more compares and branches in a step of ~105 instructions)
-        if (blockIdx.x >= short_blocks) bac_decode_body<WB, WY, MODE, true>(p, m);
-        else bac_decode_body<WB, WY, MODE, false>(p, m);
-    } else {
-        bac_decode_body<WB, WY, MODE, MODE == 1>(p, blockIdx.x * 64u + lane);
+    const bool any_differ = __any(differ);
+    if (lane == 0) {
+        if (bad) { p.status[m] = RETRY; if (p.ndec) p.ndec[m] = 1u; }
+        else if (expected && any_differ) p.status[m] = MISMATCH;
     }
 }
 
-// Sorts the maps of a launch into blocks of 64 for bac_decode_kernel<.., 2>: first the maps whose streams fit the windows of
-// WB / WY words (and the ones there is nothing to decode for: skipped, failed), in their own order, padded to a multiple of 64
-// with 0xFFFFFFFF; then the long ones, padded likewise. perm[0] / perm[1] = number of blocks of each kind. One block of 1024
-// threads walks the maps in chunks (a few thousand maps: microseconds).
-__global__ __launch_bounds__(1024) void sort_maps_kernel(const SimdParams p, uint32_t wb_bits, uint32_t wy_bits) {
-    __shared__ uint32_t wave_sums[2][16];
-    __shared__ uint32_t base[2];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    int32_t* slots = p.perm + 4;
-    // pass A: how many long maps there are, i.e. where the long blocks start
-    uint32_t n_long = 0;
-    for (uint32_t m = tid; m < p.n_maps; m += 1024u) {
-        const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
-        if (row >= 0 && p.status[m] == 0 && (p.bac_bits[m] > wb_bits || p.bypass_bits[m] > wy_bits)) n_long++;
-    }
-    for (int off = 32; off > 0; off >>= 1) n_long += __shfl_down(n_long, off, 64);
-    if (lane == 0) wave_sums[0][wave] = n_long;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t total_long = 0;
-        for (int w = 0; w < 16; w++) total_long += wave_sums[0][w];
-        const uint32_t total_short = p.n_maps - total_long;
-        const uint32_t short_blocks = (total_short + 63u) / 64u, long_blocks = (total_long + 63u) / 64u;
-        p.perm[0] = (int32_t)short_blocks; p.perm[1] = (int32_t)long_blocks; p.perm[2] = (int32_t)total_short; p.perm[3] = (int32_t)total_long;
-        base[0] = 0u;
-        base[1] = short_blocks * 64u;
-    }
-    __syncthreads();
-    const uint32_t total_short = (uint32_t)p.perm[2], total_long = (uint32_t)p.perm[3];
-    const uint32_t short_end = ((total_short + 63u) / 64u) * 64u, long_start = short_end, long_end = long_start + ((total_long + 63u) / 64u) * 64u;
-    // padding slots
-    for (uint32_t i = total_short + tid; i < short_end; i += 1024u) slots[i] = -1;
-    for (uint32_t i = long_start + total_long + tid; i < long_end; i += 1024u) slots[i] = -1;
-    // pass B: stable placement, chunk by chunk (exclusive scans over the 1024 threads of a chunk)
-    for (uint32_t m0 = 0; m0 < p.n_maps; m0 += 1024u) {
-        const uint32_t m = m0 + tid;
-        uint32_t is_long = 0, is_short = 0;
-        if (m < p.n_maps) {
-            const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
-            is_long = (row >= 0 && p.status[m] == 0 && (p.bac_bits[m] > wb_bits || p.bypass_bits[m] > wy_bits)) ? 1u : 0u;
-            is_short = 1u - is_long;
-        }
-        // both exclusive scans inside the wavefront at once: short maps in the low half, long ones in the high half
-        uint32_t both_tot;
-        const uint32_t both = wave_exclusive_scan(is_short | (is_long << 16), both_tot);
-        const uint32_t off_s = both & 0xFFFFu, off_l = both >> 16, tot_s = both_tot & 0xFFFFu, tot_l = both_tot >> 16;
-        if (lane == 0) { wave_sums[0][wave] = tot_s; wave_sums[1][wave] = tot_l; }
-        __syncthreads();
-        uint32_t before_s = 0, before_l = 0;
-        for (uint32_t w = 0; w < wave; w++) { before_s += wave_sums[0][w]; before_l += wave_sums[1][w]; }
-        if (m < p.n_maps) {
-            if (is_long) slots[base[1] + before_l + off_l] = (int32_t)m;
-            else slots[base[0] + before_s + off_s] = (int32_t)m;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t cs = 0, cl = 0;
-            for (int w = 0; w < 16; w++) { cs += wave_sums[0][w]; cl += wave_sums[1][w]; }
-            base[0] += cs;
-            base[1] += cl;
-        }
-        __syncthreads();
-    }
-}
-
-// (4) decoded == encoded, one wavefront per map
+// decoded == encoded for the maps the general kernel decoded (debinarise_kernel compares its own), one wavefront per map
 __global__ __launch_bounds__(64) void compare_kernel(const SimdParams p) {
     const uint32_t m = blockIdx.x, lane = threadIdx.x;
+    if (p.ndec[m] == 0u) return;
     const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
     if (row < 0 || p.status[m] != 0) return;
     const int16_t* a = p.symbols + (size_t)m * p.map_size;
@@ -615,6 +566,7 @@ __global__ void mark_kernel(const SimdParams p) {
     if (m >= p.n_maps) return;
     const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
     if (row >= 0 && p.status[m] == 0) p.status[m] = RETRY;
+    if (p.ndec) p.ndec[m] = 1u;
 }
 
 uint32_t decision_capacity(uint32_t map_size, uint8_t L) { return ((map_size * ((uint32_t)L + 1u)) + 7u) & ~7u; }
@@ -624,21 +576,29 @@ bool fast_applies(uint8_t L) { return L >= 1 && L <= kMaxFastL; }
 
 extern "C" {
 
-// workspace: [per-map decision counts][decisions of an encode | decoded symbols of a verify], 256-byte aligned pieces
+// workspace: [per-map decision counts][decisions of an encode | decoded symbols of a verify][records of an encode | prefix bytes of
+// a decode], 256-byte aligned pieces
 static uint64_t round256(uint64_t v) { return (v + 255u) & ~(uint64_t)255u; }
-uint64_t eae_hip_coder_workspace_bytes(uint32_t n_maps, uint32_t map_size, uint8_t L) {
+static uint64_t piece_a_bytes(uint32_t n_maps, uint32_t map_size, uint8_t L) {
     const uint64_t groups = ((uint64_t)n_maps + 63u) / 64u;
     const uint64_t decisions = fast_applies(L) ? groups * 64u * decision_capacity(map_size, L) : 0u;
     const uint64_t decoded = (uint64_t)n_maps * map_size * sizeof(int16_t);
-    return 256u + round256((uint64_t)n_maps * sizeof(uint32_t)) + round256(decisions > decoded ? decisions : decoded) +
-           round256(((uint64_t)n_maps + 128u + 4u) * sizeof(int32_t));        // + the decoder's sorted map order
+    return round256(decisions > decoded ? decisions : decoded);
+}
+static uint64_t piece_b_bytes(uint32_t n_maps, uint32_t map_size, uint8_t L) {
+    const uint64_t records = fast_applies(L) ? (uint64_t)n_maps * (decision_capacity(map_size, L) + kRecordPad) * sizeof(uint32_t) : 0u;
+    const uint64_t prefixes = (uint64_t)n_maps * map_size;
+    return round256(records > prefixes ? records : prefixes);
+}
+uint64_t eae_hip_coder_workspace_bytes(uint32_t n_maps, uint32_t map_size, uint8_t L) {
+    return 256u + round256((uint64_t)n_maps * sizeof(uint32_t)) + piece_a_bytes(n_maps, map_size, L) + piece_b_bytes(n_maps, map_size, L);
 }
 
 static SimdParams make_params(uint32_t n_maps, uint32_t map_size, uint8_t L, const int16_t* symbols, const double* probs,
                               const int32_t* prob_row, uint8_t* streams, uint64_t stride, uint32_t* bac_bits,
                               uint32_t* bypass_bits, int32_t* status, int32_t* stage, void* workspace) {
     SimdParams p{};
-    p.n_maps = n_maps; p.map_size = map_size; p.L = L; p.dcap = decision_capacity(map_size, L);
+    p.n_maps = n_maps; p.map_size = map_size; p.L = L; p.dcap = decision_capacity(map_size, L); p.rcap = p.dcap + kRecordPad;
     p.symbols = symbols; p.probs = probs; p.prob_row = prob_row; p.streams = streams; p.stride = stride;
     p.bac_bits = bac_bits; p.bypass_bits = bypass_bits; p.status = status; p.stage = stage;
     if (workspace) {
@@ -646,10 +606,8 @@ static SimdParams make_params(uint32_t n_maps, uint32_t map_size, uint8_t L, con
         p.ndec = reinterpret_cast<uint32_t*>(ws);
         p.decisions = ws + round256((uint64_t)n_maps * sizeof(uint32_t));
         p.decoded = reinterpret_cast<int16_t*>(p.decisions);
-        const uint64_t groups = ((uint64_t)n_maps + 63u) / 64u;
-        const uint64_t decisions = fast_applies(L) ? groups * 64u * decision_capacity(map_size, L) : 0u;
-        const uint64_t decoded = (uint64_t)n_maps * map_size * sizeof(int16_t);
-        p.perm = reinterpret_cast<int32_t*>(p.decisions + round256(decisions > decoded ? decisions : decoded));
+        p.records = reinterpret_cast<uint32_t*>(p.decisions + piece_a_bytes(n_maps, map_size, L));
+        p.prefixes = reinterpret_cast<uint8_t*>(p.records);
     }
     return p;
 }
@@ -657,7 +615,7 @@ static SimdParams make_params(uint32_t n_maps, uint32_t map_size, uint8_t L, con
 static int check_simd_layout(uint32_t map_size, uint8_t L, const uint8_t* streams, uint64_t stride) {
     const uint64_t half = stride / 2;
     return (half < (uint64_t)(round_up_to_byte(required_bits(map_size, L)) >> 3) + 16 || (stride & 15u) ||
-            (reinterpret_cast<uintptr_t>(streams) & 7u)) ? 1 : 0;
+            (reinterpret_cast<uintptr_t>(streams) & 15u)) ? 1 : 0;
 }
 
 int eae_hip_coder_encode_batch(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, uint8_t L, const double* probs,
@@ -677,7 +635,8 @@ int eae_hip_coder_encode_batch(uint32_t n_maps, uint32_t map_size, const int16_t
     const SimdParams p = make_params(n_maps, map_size, L, symbols, probs, prob_row, streams, stride, bac_bits, bypass_bits,
                                      status, stage, workspace);
     hipLaunchKernelGGL(binarise_kernel, dim3(n_maps), dim3(64), 0, s, p);
-    hipLaunchKernelGGL(bac_encode_kernel, dim3((n_maps + 63u) / 64u), dim3(64), (size_t)L * 64u * sizeof(double), s, p);
+    hipLaunchKernelGGL(bac_encode_core_kernel, dim3((n_maps + 63u) / 64u), dim3(64), (size_t)L * 64u * sizeof(double), s, p);
+    hipLaunchKernelGGL(emit_kernel, dim3(n_maps), dim3(64), 0, s, p);
     const int rc = eae_coder_generic_encode(n_maps, map_size, symbols, L, probs, prob_row, streams, stride, bac_bits,
                                             bypass_bits, status, stage, RETRY, s);
     return rc ? rc : (int)hipGetLastError();
@@ -689,63 +648,32 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
                                void* workspace, uint64_t workspace_bytes, void* stream) {
     if (!probs || !streams || !bac_bits || !bypass_bits || !status) return -1;
     if (!symbols_out && (!expected || !workspace)) return -1;
-    if (!symbols_out && workspace_bytes < eae_hip_coder_workspace_bytes(n_maps, map_size, L)) return 1;
+    const bool have_ws = workspace && workspace_bytes >= eae_hip_coder_workspace_bytes(n_maps, map_size, L);
+    if (!symbols_out && !have_ws) return 1;
     if (n_maps == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     SimdParams p = make_params(n_maps, map_size, L, expected, probs, prob_row, const_cast<uint8_t*>(streams), stride,
-                               const_cast<uint32_t*>(bac_bits), const_cast<uint32_t*>(bypass_bits), status, stage, workspace);
+                               const_cast<uint32_t*>(bac_bits), const_cast<uint32_t*>(bypass_bits), status, stage,
+                               have_ws ? workspace : nullptr);
     if (symbols_out) p.decoded = symbols_out;
     if (!expected) (void)hipMemsetAsync(status, 0, (size_t)n_maps * sizeof(int32_t), s);   // a pure decode starts from a clean slate
-    if (fast_applies(L) && map_size) {
-        const dim3 grid((n_maps + 63u) / 64u);
-        // with a workspace (large enough for the sorted map order): ONE launch over blocks of short maps and blocks of long
-        // maps; without: first pass over every group of 64, second pass over the maps the first one found too long
-        const bool sorted = workspace && workspace_bytes >= eae_hip_coder_workspace_bytes(n_maps, map_size, L);
-        const dim3 sorted_grid((n_maps + 63u) / 64u + 1u);
-        if (map_size > kMediumMapSize) {
-            const size_t lds = decode_lds_bytes(L, kBacWindowWordsMedium, kBypassWindowWordsMedium);
-            static const hipError_t medium_ok = [] {
-                hipError_t e = hipSuccess;
-                const void* kernels[3] = {
-                    reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, 0>),
-                    reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, 1>),
-                    reinterpret_cast<const void*>(&bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, 2>)};
-                for (const void* k : kernels) {
-                    e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-                    if (e != hipSuccess) return e;
-                }
-                return e;
-            }();
-            if (medium_ok != hipSuccess) return (int)medium_ok;
-            if (sorted) {
-                hipLaunchKernelGGL(sort_maps_kernel, dim3(1), dim3(1024), 0, s, p, kBacWindowWordsMedium * 32u, kBypassWindowWordsMedium * 32u);
-                hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, 2>), sorted_grid, dim3(64), lds, s, p);
-            } else {
-                hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, 0>), grid, dim3(64), lds, s, p);
-                hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWordsMedium, kBypassWindowWordsMedium, 1>), grid, dim3(64), lds, s, p);
-            }
-        } else {
-            const size_t lds = decode_lds_bytes(L, kBacWindowWords, kBypassWindowWords);
-            if (sorted) {
-                hipLaunchKernelGGL(sort_maps_kernel, dim3(1), dim3(1024), 0, s, p, kBacWindowWords * 32u, kBypassWindowWords * 32u);
-                hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, 2>), sorted_grid, dim3(64), lds, s, p);
-            } else {
-                hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, 0>), grid, dim3(64), lds, s, p);
-                hipLaunchKernelGGL((bac_decode_kernel<kBacWindowWords, kBypassWindowWords, 1>), grid, dim3(64), lds, s, p);
-            }
-        }
-        // whatever a map reported that only the general kernel can name (errors of any kind)
-        const int rc = eae_coder_generic_decode(n_maps, map_size, p.decoded, L, probs, prob_row, streams, stride, bac_bits,
-                                                bypass_bits, status, stage, RETRY, s);
-        if (rc) return rc;
+    // the 64-maps-per-wavefront kernels need the workspace (prefix bytes) and 16-byte aligned streams; otherwise, or for L == 0 or
+    // L > 32, the general kernel decodes every map
+    const bool fast = fast_applies(L) && map_size && have_ws && !check_simd_layout(map_size, L, streams, stride);
+    if (fast) {
+        hipLaunchKernelGGL(bac_decode_core_kernel, dim3((n_maps + 63u) / 64u), dim3(64), decode_lds_bytes(L), s, p);
+        hipLaunchKernelGGL(debinarise_kernel, dim3(n_maps), dim3(64), 0, s, p);
     } else {
-        // general kernel over every map that has not failed already
         hipLaunchKernelGGL(mark_kernel, dim3((n_maps + 255u) / 256u), dim3(256), 0, s, p);
-        const int rc = eae_coder_generic_decode(n_maps, map_size, p.decoded, L, probs, prob_row, streams, stride, bac_bits,
-                                                bypass_bits, status, stage, RETRY, s);
-        if (rc) return rc;
     }
-    if (expected) hipLaunchKernelGGL(compare_kernel, dim3(n_maps), dim3(64), 0, s, p);
+    // whatever a map reported that only the general kernel can name (errors of any kind), or every map
+    const int rc = eae_coder_generic_decode(n_maps, map_size, p.decoded, L, probs, prob_row, streams, stride, bac_bits,
+                                            bypass_bits, status, stage, RETRY, s);
+    if (rc) return rc;
+    if (expected) {
+        if (p.ndec) hipLaunchKernelGGL(compare_kernel, dim3(n_maps), dim3(64), 0, s, p);
+        else return 1;
+    }
     return (int)hipGetLastError();
 }
 

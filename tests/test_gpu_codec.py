@@ -200,7 +200,7 @@ def test_a_failed_submit_does_not_hang_the_codec(graphs, monkeypatch):
         good = c.submit(images).result()
         real = c._launch_coder
 
-        def broken(slot):
+        def broken(slot, hook=None):
             raise RuntimeError('injected')
 
         c._launch_coder = broken

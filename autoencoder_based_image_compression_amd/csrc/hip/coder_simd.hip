@@ -376,25 +376,29 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
     const uint32_t size = live && !retry ? p.map_size : 0u;
     const uint4* src = reinterpret_cast<const uint4*>(p.streams + (uint64_t)(in_range ? m : 0u) * p.stride);
     const uint32_t nwords = size ? (nbac + 31u) >> 5 : 0u;          // words that hold stream bits; everything beyond reads as zero
-    // a group of four words from memory, bit-reversed (the next bit in time most significant) and zero beyond the stream
+    // Four stream words from memory (raw), requested a checkpoint ahead of their use; only groups that hold stream bits are ever
+    // requested (w0 < nwords): what a lane reads beyond the end of its stream -- the tail of the last group, older words still in
+    // the ring -- is never taken (`left` bounds every take).
     auto fetch = [&](uint32_t w0) {                                  // w0: a multiple of 4
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (w0 < nwords) v = src[w0 >> 2];
-        v.x = w0 + 0u < nwords ? __builtin_bitreverse32(v.x) : 0u;
-        v.y = w0 + 1u < nwords ? __builtin_bitreverse32(v.y) : 0u;
-        v.z = w0 + 2u < nwords ? __builtin_bitreverse32(v.z) : 0u;
-        v.w = w0 + 3u < nwords ? __builtin_bitreverse32(v.w) : 0u;
         return v;
     };
+    // ... and into the ring, bit-reversed (the next bit in time most significant)
     auto land = [&](uint32_t w0, const uint4& v) {
-        ring[((w0 + 0u) & (kRing - 1u)) * 64u] = v.x;
-        ring[((w0 + 1u) & (kRing - 1u)) * 64u] = v.y;
-        ring[((w0 + 2u) & (kRing - 1u)) * 64u] = v.z;
-        ring[((w0 + 3u) & (kRing - 1u)) * 64u] = v.w;
+        ring[((w0 + 0u) & (kRing - 1u)) * 64u] = __builtin_bitreverse32(v.x);
+        ring[((w0 + 1u) & (kRing - 1u)) * 64u] = __builtin_bitreverse32(v.y);
+        ring[((w0 + 2u) & (kRing - 1u)) * 64u] = __builtin_bitreverse32(v.z);
+        ring[((w0 + 3u) & (kRing - 1u)) * 64u] = __builtin_bitreverse32(v.w);
     };
     // the ring starts full: words 0 .. 31
+    {
+        uint4 first[kRing / 4u];
 #pragma unroll
-    for (uint32_t w0 = 0; w0 < kRing; w0 += 4u) land(w0, fetch(w0));
+        for (uint32_t g = 0; g < kRing / 4u; g++) first[g] = fetch(4u * g);
+#pragma unroll
+        for (uint32_t g = 0; g < kRing / 4u; g++) land(4u * g, first[g]);
+    }
     uint32_t loaded = kRing;              // words [0, loaded) have been in the ring
     // the window: the next `rcount` stream bits, left-aligned (the next bit in time at bit 63)
     unsigned long long rwin = ((unsigned long long)ring[0] << 32) | (unsigned long long)ring[64];
@@ -424,13 +428,14 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
         for (;;) {
             // ---- checkpoint, every 8 steps: the words requested at the last checkpoint enter the ring (their rows hold words this
             // lane has already moved to its window: it was at most 24 words behind `loaded` when they were requested), and the next
-            // eight are requested when this lane is at most 24 words behind. A step takes at most 30 bits, so the ring cannot run dry.
+            // eight are requested when this lane is at most 24 words behind and the stream has words left. A step takes at most 30
+            // bits, so the ring cannot run dry of stream words.
             if (flying) {
                 land(loaded, fa);
                 land(loaded + 4u, fb);
                 loaded += 8u;
             }
-            flying = loaded - rword <= kRing - 8u;
+            flying = loaded - rword <= kRing - 8u && loaded < nwords;
             if (flying) {
                 fa = fetch(loaded);
                 fb = fetch(loaded + 4u);

@@ -386,3 +386,59 @@ def test_argument_checks(dev):
     assert rc == 1
     with pytest.raises(TypeError):
         dev.coder_compress_maps(sym.int(), p, None, 10)
+
+
+@pytest.mark.parametrize('bin_width', [1.0, 0.125, 0.0125])
+def test_batch_coder_next_to_mfma_kernels(dev, bin_width):
+    """The coder's wavefronts share their SIMDs with the transforms' MFMA waves in the product (codec.BatchCodec): every kernel of
+    the batch coder must give the same bytes and symbols while conv GEMM launches saturate the GPU from another stream. (Round 3:
+    a first form of the decoder core passed every stand-alone test and derailed exactly there; this test is the guard.) The
+    benchmark's own latents, 24 Kodak-sized images, from 0.2 to 3 bits per pixel: streams of up to ~150 words, so the ring refill
+    runs too."""
+    import bench
+    from autoencoder_based_image_compression_amd import pipeline
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    from autoencoder_based_image_compression_amd.kodak.lossless import stats as lossless_stats
+    batch = 24
+    variables = bench.synthetic_model(bin_width)
+    images = torch.from_numpy(bench.synthetic_images(1000, batch, 512, 768)).cuda()
+    bin_widths = variables[var.BIN_WIDTHS_NAME]
+    enc = pipeline.DeviceEncoder(variables, False)
+    y = enc(images)
+    map_mean = dev.map_means(y)
+    probabilities = lossless_stats.compute_binary_probabilities(y.cpu().numpy(), bin_widths, map_mean.cpu().numpy(), 10)
+    q = dev.quantize_maps(y, torch.from_numpy(bin_widths).cuda(), map_mean, want_symbols=True)
+    symbols = q['symbols'].reshape(batch*128, -1).contiguous()
+    planar = symbols.cpu().numpy()
+    rows_host = numpy.tile(numpy.arange(128, dtype=numpy.int32), batch)
+    rows_host[67::128] = -1
+    rows = torch.from_numpy(rows_host).cuda()
+    prob = torch.from_numpy(probabilities).cuda()
+    streams = dev.CoderStreams(batch*128, symbols.shape[1], 10, 'cuda')
+    ws = dev.coder_workspace(batch*128, symbols.shape[1], 10, 'cuda')
+    gdn_1 = dev.conv9x9s4_u8(images, enc.w1, enc.v['encoder/biases_1'], enc.g[1], enc.v['encoder/beta_1'])
+    out = torch.empty((batch, 64, 96, 128), device='cuda')
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def load():
+        for _ in range(6):
+            dev.conv5x5s2(gdn_1, enc.w2, enc.v['encoder/biases_2'], dev.NORM_GDN, enc.g[2], enc.v['encoder/beta_2'], out=out)
+
+    for round_ in range(4):
+        load()
+        with torch.cuda.stream(side):
+            dev.coder_encode_batch(symbols, prob, rows, 10, out=streams, workspace=ws)
+        load()
+        with torch.cuda.stream(side):
+            dev.coder_decode_batch(streams, prob, rows, expected=symbols, workspace=ws)
+        torch.cuda.synchronize()
+        assert int(streams.status.abs().sum().item()) == 0, (round_, numpy.flatnonzero(streams.status.cpu().numpy())[:8])
+        if round_ == 0:
+            assert_equals_host(streams, planar, probabilities, rows_host, ('under load', bin_width))
+    load()
+    with torch.cuda.stream(side):
+        decoded = dev.coder_decode_batch(streams, prob, rows)
+    torch.cuda.synchronize()
+    coded = rows_host >= 0
+    assert numpy.array_equal(decoded.cpu().numpy()[coded], planar[coded])

@@ -218,7 +218,8 @@ class BatchCodec(object):
         assert nb_words % 2 == 0
         self.nb_slots = nb_in_flight + 2
         self._streams = _side_streams(nb_in_flight, self.device)
-        self._transform_streams = _side_streams(nb_in_flight + nb_transform_streams, self.device)[nb_in_flight:] if nb_transform_streams > 1 else []
+        nb_private = nb_transform_streams if (nb_transform_streams > 1 or use_graphs) else 0      # replays never go to the caller's stream
+        self._transform_streams = _side_streams(nb_in_flight + nb_private, self.device)[nb_in_flight:]
         # ... and behind the squared errors one more 64-bit word whose low half is the conv workspace's error word of the step
         self._slot_all = [torch.zeros(nb_words + 2*batch_size + 2, dtype=torch.int32, device=self.device) for _ in range(self.nb_slots)]
         self._slot_out = [t[:nb_words] for t in self._slot_all]
@@ -247,8 +248,7 @@ class BatchCodec(object):
         self._graphs = [None]*self.nb_slots          # per slot: (three graphs, static input, latents, reconstruction)
         self._warm = False
         self._recount_stream = None
-        if self.use_graphs and not self._transform_streams:
-            self._transform_streams = _side_streams(nb_in_flight + 1, self.device)[nb_in_flight:]     # replays never go to the caller's stream
+        assert not self.use_graphs or self._transform_streams      # replays never go to the caller's stream
 
     def _views(self, t):
         out = []

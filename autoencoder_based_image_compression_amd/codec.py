@@ -143,16 +143,28 @@ class _Worker(threading.Thread):
                 ticket._done.set()
 
 
+def default_nb_in_flight(h_in, w_in):
+    """Batches of coder work to keep in flight when the caller does not say. A feature map is ONE serial chain (its symbols x
+    about 0.2-0.4 us each to encode, the same again to decode, stretched next to the transforms), whatever the batch; the
+    transforms of a batch take a time that grows with the batch instead. Measured on MI355X, 24 Kodak-sized images per step
+    (maps of 1,536 symbols; profiles/r03_depth_sweep.txt): three to five in flight are equal within 1 % at 0.2 bpp, five is
+    the best at 1.4 bpp and 16 % ahead of three at 3.2 bpp; a 2048x2048 image has maps of 16,384 symbols and needs eight."""
+    map_size = (h_in//csts.STRIDE_PROD)*(w_in//csts.STRIDE_PROD)
+    return int(min(8, max(5, 3 + map_size//3072)))
+
+
 class BatchCodec(object):
     """Encode -> quantise -> entropy-code (with round trip) -> decode -> squared error for batches of a fixed shape."""
 
     def __init__(self, variables, are_bin_widths_learned, bin_widths_test, map_mean, binary_probabilities, idx_map_exception,
-                 batch_size, h_in, w_in, device='cuda', nb_in_flight=2, keep_reconstruction=False, launch_hook=None,
+                 batch_size, h_in, w_in, device='cuda', nb_in_flight=None, keep_reconstruction=False, launch_hook=None,
                  coder='device', host_coder_threads=0, hist_radius=2047, nb_transform_streams=1, use_graphs=False,
                  time_coder=False, fuse_latent=False):
         """coder: 'device' (the coder kernels on side streams), 'host' (ONE device -> host copy of the symbols per batch, then
         the host C-ABI coder `eae_coder_compress_maps` on `host_coder_threads` threads: the shape BASELINE.json sketches) or
         'none' (transforms only; the bit counts come back as zeros).
+        nb_in_flight: batches whose coder work may be pending at once, each on its own side stream (None:
+        `default_nb_in_flight(h_in, w_in)`).
         nb_transform_streams: 1 = the transforms run on the caller's current stream; more = consecutive batches alternate
         between that many private streams (worth it only for small batches, whose kernels leave most of the GPU idle).
         use_graphs: capture the launches of one step into three hipGraphs per slot on first use (analysis side, coder,
@@ -216,6 +228,9 @@ class BatchCodec(object):
         self._layout = (4*n_maps, nb_hist*(2*self.hist_radius + 1), nb_hist, n_maps, 4)
         nb_words = sum(self._layout)
         assert nb_words % 2 == 0
+        if nb_in_flight is None:
+            nb_in_flight = default_nb_in_flight(h_in, w_in)
+        self.nb_in_flight = nb_in_flight
         self.nb_slots = nb_in_flight + 2
         self._streams = _side_streams(nb_in_flight, self.device)
         nb_private = nb_transform_streams if (nb_transform_streams > 1 or use_graphs) else 0      # replays never go to the caller's stream

@@ -556,8 +556,9 @@ def coder_encode_batch(symbols_planar, probabilities, prob_row, truncated_unary_
 def coder_decode_batch(streams, probabilities, prob_row, expected=None, workspace=None):
     """The 64-maps-per-wavefront decoder. expected=None: returns the decoded symbols [n_maps, map_size] (skipped maps
     zero). With `expected`: decodes into the workspace and compares on the device; failures land in `streams.status`.
-    With a workspace (`coder_workspace`; always there with `expected`) the maps are sorted into short and long ones first and
-    decoded by one launch; without, by a first pass and a second pass for the long ones. Same results."""
+    With a workspace (`coder_workspace`; always there with `expected`) the serial core leaves one prefix byte per symbol there
+    and a data-parallel pass adds signs and suffixes (csrc/hip/coder_simd.hip); without, the general kernel decodes every
+    map. Same results."""
     device = streams.streams.device
     if expected is None:
         out = torch.zeros((streams.n_maps, streams.map_size), dtype=torch.int16, device=device)

@@ -182,12 +182,8 @@ def synthetic_model(bin_width=1.):
 
 
 def auto_coder_streams(h, w):
-    """Batches of coder work to keep in flight. A feature map is ONE serial chain (its symbols x ~0.3-0.4 us each to encode,
-    the same again to decode, stretched 2-4x next to the transforms), whatever the batch; the transforms of a batch take a
-    time that grows with the batch instead. Kodak-sized maps (1,536 symbols) hide behind three batches; a 2048x2048 image
-    has maps of 16,384 symbols and needs about eight."""
-    map_size = (h//16)*(w//16)
-    return int(min(8, max(3, 3 + map_size//3072)))
+    """Batches of coder work to keep in flight: the product's own default (codec.default_nb_in_flight)."""
+    return codec.default_nb_in_flight(h, w)
 
 
 class Context(object):

@@ -290,12 +290,24 @@ int eae_hip_coder_verify_maps(uint32_t n_maps, uint32_t map_size, const int16_t*
                               int32_t* status, int32_t* stage, int lanes_per_wave, void* stream);
 
 /* ---- the same coder, 64 maps per wavefront in step (csrc/hip/coder_simd.hip) -----------------------------------------
- * Same arguments, stream layout and results as the entry points above, organised for the machine: binarisation and the
- * bypass stream are computed in parallel over the symbols, the arithmetic coder runs decision-synchronously with one
- * map per lane, and every map the fast kernels cannot finish (any error, exotic lengths) is recoded by the general
- * kernel, so statuses, stages, bit counts and bytes are identical in every case. These are the launches bench.py times.
+ * Same arguments, stream layout and results as the entry points above, organised for the machine. Only the interval
+ * arithmetic of the binary arithmetic coder is serial (one map per lane, csrc/coder/lean_step.h); everything around it is
+ * data-parallel over the symbols:
+ *   encode_batch: binarise (decisions, the bypass stream of signs / Exp-Golomb suffixes) -> the serial core, which leaves
+ *     one 32-bit record per decision (the bits that may leave, E1/E2 and E3 counts) -> emit (prefix sums over the records
+ *     place the bits and the pending-E3 runs in the stream);
+ *   decode_batch: the serial core reads the stream through a small ring in LDS and leaves one byte per symbol (its
+ *     truncated-unary prefix) -> debinarise (signs, suffixes from the bypass stream) -> compare with `expected`.
+ * Every map the fast kernels cannot finish (any error, streams that outgrow their region, exotic lengths) is recoded by
+ * the general kernel above, so statuses, stages, bit counts and bytes are identical in every case. These are the launches
+ * bench.py times.
+ *   streams / stream_stride_bytes: as above, with every map's two streams on 16-byte boundaries and 16 spare bytes per
+ *   stream (the stride of eae_hip_coder_stream_stride_bytes on a 16-byte aligned base does that): encode_batch returns
+ *   1 (hipErrorInvalidValue) for any other layout, decode_batch hands such streams to the general kernel, map by map.
+ *   L == 0 and L > 32 go to the general kernel too. Same results in every case.
  *   workspace: device scratch of eae_hip_coder_workspace_bytes(n_maps, map_size, L) bytes, private to the call chain
- *   (encode_batch followed by decode_batch of the same maps may share it; concurrent batches need their own).
+ *   (encode_batch followed by decode_batch of the same maps may share it; concurrent batches need their own). It holds the
+ *   decisions and records of the batch: about 4 * (L + 1) + 12 bytes per symbol for the records alone.
  *   encode_batch: symbols -> streams + bac_bits/bypass_bits/status/stage (all written for every map).
  *   decode_batch: streams -> symbols_out (expected == NULL; status/stage written for every map; skipped maps are left
  *   untouched), or, with expected != NULL, decode into the workspace (symbols_out may be NULL) and compare: maps whose

@@ -146,11 +146,13 @@ class _Worker(threading.Thread):
 def default_nb_in_flight(h_in, w_in):
     """Batches of coder work to keep in flight when the caller does not say. A feature map is ONE serial chain (its symbols x
     about 0.2-0.4 us each to encode, the same again to decode, stretched next to the transforms), whatever the batch; the
-    transforms of a batch take a time that grows with the batch instead. Measured on MI355X, 24 Kodak-sized images per step
-    (maps of 1,536 symbols; profiles/r03_depth_sweep.txt): three to five in flight are equal within 1 % at 0.2 bpp, five is
-    the best at 1.4 bpp and 16 % ahead of three at 3.2 bpp; a 2048x2048 image has maps of 16,384 symbols and needs eight."""
+    transforms of a batch take a time that grows with the batch instead. Measured on MI355X in the product mode
+    (profiles/r03_depth_sweep.txt, profiles/r03_i_bench.json): 24 Kodak-sized images per step (maps of 1,536 symbols): three
+    to five in flight are equal within 1 % at 0.2 bpp, five is the best at 1.4 bpp and 16 % ahead of three at 3.2 bpp; 64
+    images of 256x256 (maps of 256 symbols: short chains, short steps) lose 10 % with five against three; a 2048x2048 image
+    has maps of 16,384 symbols and needs eight."""
     map_size = (h_in//csts.STRIDE_PROD)*(w_in//csts.STRIDE_PROD)
-    return int(min(8, max(5, 3 + map_size//3072)))
+    return int(min(8, 3 + map_size//768))
 
 
 class BatchCodec(object):

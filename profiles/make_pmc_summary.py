@@ -37,9 +37,9 @@ def main(session, out_path):
             entry[counter] = round(sum(values)/len(values), 3)
             entry['dispatches'] = len(values)
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in entry and entry.get('GRBM_GUI_ACTIVE'):
-            # MFMA busy as a fraction of the kernel's duration: busy cycles are summed over the 1024 SIMDs' ... per the guide the
-            # counter ticks per CU-level MFMA pipe: normalise by GRBM_GUI_ACTIVE (summed over 8 XCDs) x 32 CUs
-            entry['mfma_busy_frac'] = round(entry['SQ_VALU_MFMA_BUSY_CYCLES']/(entry['GRBM_GUI_ACTIVE']*32.), 4)
+            # MFMA busy as a fraction of the kernel's duration: the counter is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE
+            # over the 8 XCDs (the normalisation of profiles/make_traffic.py; a register-only MFMA stream reads 0.98)
+            entry['mfma_busy_frac'] = round((entry['SQ_VALU_MFMA_BUSY_CYCLES']/1024.)/(entry['GRBM_GUI_ACTIVE']/8.), 4)
         if 'SQ_WAVE_CYCLES' in entry:
             for key in ('SQ_WAIT_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_LDS'):
                 if key in entry:

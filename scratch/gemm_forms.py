@@ -30,6 +30,10 @@ layers = {
 forms = {
     'wave': ({'EAE_HIP_GEMM': 'w'}, False),
     'wave128': ({'EAE_HIP_GEMM': 'w', 'EAE_HIP_FORCE_TILE': '128'}, False),
+    'wave32_nt4': ({'EAE_HIP_GEMM': 'w', 'EAE_HIP_FORCE_TILE': '32', 'EAE_HIP_FORCE_NT': '4'}, False),
+    'wave32_nt2': ({'EAE_HIP_GEMM': 'w', 'EAE_HIP_FORCE_TILE': '32', 'EAE_HIP_FORCE_NT': '2'}, False),
+    'wave32_nt1': ({'EAE_HIP_GEMM': 'w', 'EAE_HIP_FORCE_TILE': '32', 'EAE_HIP_FORCE_NT': '1'}, False),
+    'wave64_nt4': ({'EAE_HIP_GEMM': 'w', 'EAE_HIP_FORCE_TILE': '64', 'EAE_HIP_FORCE_NT': '4'}, False),
     'default': ({}, ws),
     'whole': ({'EAE_HIP_GEMM': 'u'}, ws),
     'cut1': ({'EAE_HIP_GEMM': 's', 'EAE_HIP_SPLIT_WAVES': '1'}, ws),

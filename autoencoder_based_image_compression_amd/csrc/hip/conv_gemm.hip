@@ -243,7 +243,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
     constexpr int PARTS = 4 / NT;
     constexpr int TM = WAVES * 32;
     constexpr int TILE_W = TM / TILE_H;
-    constexpr int RING = 8;
+    constexpr int RING = 8;        // k-pairs of weights in flight (16 for the two-tile form measured slower: 0.136 against 0.128 ms, conv_3 of 64 x 256x256)
     constexpr int ABUF = 32 * AS_STRIDE;                       // one activation buffer of one wave
     constexpr int WAVE_LDS = 2 * ABUF + 2 * EAE_C;             // + bias[128] + beta[128]
     __shared__ __attribute__((aligned(16))) float lds[WAVES * WAVE_LDS];

@@ -119,6 +119,10 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
         while (sp >= cnt_sp) { sp -= cnt_sp; ++ph; }
         const PhaseDesc& pd = p.phase[ph];
         const int ntaps = pd.ntaps;
+        // the phase's tap table, one tap per lane: a K-step picks its tap with v_readlane instead of a scalar load from the
+        // kernel arguments (measured neutral, 0-2 %: profiles/r03_gemm_ab.txt; one memory operation fewer per step)
+        const int tap_of_lane = pd.tap[lane < MAX_TAPS ? lane : 0];
+#define EAE_Q_TAP(ti_) __builtin_amdgcn_readlane(tap_of_lane, (ti_))
         const int T = (EAE_C / KC) * ntaps;
         int s0 = 0, s1 = T;
         if (d >= 0) {
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
             }                                                                                                        \
         }
         // byte offset of the weight slab of (tap index, 32-channel chunk); K order: chunk (outer), then tap
-#define EAE_Q_SLAB(ti_, ch_) ((((pd.tap[ti_] >> 16) * EAE_C + (ch_) * KC) * EAE_C) * 4)
+#define EAE_Q_SLAB(ti_, ch_) ((((EAE_Q_TAP(ti_) >> 16) * EAE_C + (ch_) * KC) * EAE_C) * 4)
 #define EAE_Q_W_LOAD(dst_, slab_, kk_)                                                                               \
         {                                                                                                            \
             const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane + (kk_) * 2 * EAE_C * 4, (slab_), 0); \
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
 #pragma unroll
             for (int i = 0; i < RING; ++i) EAE_Q_W_LOAD(ring[i], slab0, i)
         }
-        EAE_Q_PREFETCH_A(pd.tap[tap_i], chunk * KC)
+        EAE_Q_PREFETCH_A(EAE_Q_TAP(tap_i), chunk * KC)
         EAE_Q_STAGE_A(0)
         for (int step = s0; step < s1; ++step) {
             int nti = tap_i + 1, nch = chunk;
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
             if (step + 1 >= s1) { nti = tap_i; nch = chunk; }      // the last step re-loads itself: loads stay unconditional
             const int slab_cur = EAE_Q_SLAB(tap_i, chunk);
             const int slab_nxt = EAE_Q_SLAB(nti, nch);
-            EAE_Q_PREFETCH_A(pd.tap[nti], nch * KC)
+            EAE_Q_PREFETCH_A(EAE_Q_TAP(nti), nch * KC)
             const float4* a_rd = reinterpret_cast<const float4*>(wlds + ((step - s0) & 1) * ABUF + a_off);
             const float4 a0 = a_rd[0], a1 = a_rd[1], a2 = a_rd[2], a3 = a_rd[3];
             const float av[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
@@ -299,6 +303,7 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
 #undef EAE_Q_PREFETCH_A
 #undef EAE_Q_STAGE_A
 #undef EAE_Q_SLAB
+#undef EAE_Q_TAP
 #undef EAE_Q_W_LOAD
     }
 }

@@ -1,6 +1,8 @@
 """Extended fuzz of the 64-maps-per-wavefront coder against the host library (the committed test runs 150 cases; this one
 runs thousands with sizes and statistics chosen to hit the rare paths: long pending-E3 runs, Exp-Golomb escapes, streams
-longer than the LDS windows, empty / one-symbol maps, invalid probabilities). Exit code 1 on the first difference."""
+longer than the LDS windows, empty / one-symbol maps, invalid probabilities). Exit code 1 on the first difference.
+EAE_FUZZ_LOAD=1: a second thread keeps conv GEMM launches of a Kodak batch running on another stream for the whole run (the first
+form of the lean decoder core passed every stand-alone test and derailed only next to MFMA kernels: DESIGN.md section 5)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy, torch
@@ -27,6 +29,26 @@ def host_decode_one(streams, m, size, prob_row):
 
 
 T.host_decode_one = host_decode_one
+if os.environ.get('EAE_FUZZ_LOAD'):
+    import threading
+    import bench
+    from autoencoder_based_image_compression_amd import pipeline
+    _enc = pipeline.DeviceEncoder(bench.synthetic_model(1.), False)
+    _images = torch.from_numpy(bench.synthetic_images(7, 24, 512, 768)).cuda()
+    _gdn_1 = dev.conv9x9s4_u8(_images, _enc.w1, _enc.v['encoder/biases_1'], _enc.g[1], _enc.v['encoder/beta_1'])
+    _out = torch.empty((24, 64, 96, 128), device='cuda')
+    _load_stream = torch.cuda.Stream()
+    _stop = threading.Event()
+    _launched = [0]
+
+    def _load():
+        with torch.cuda.stream(_load_stream):
+            while not _stop.is_set():
+                for _ in range(8):
+                    dev.conv5x5s2(_gdn_1, _enc.w2, _enc.v['encoder/biases_2'], dev.NORM_GDN, _enc.g[2], _enc.v['encoder/beta_2'], out=_out)
+                _launched[0] += 8
+                _load_stream.synchronize()
+    threading.Thread(target=_load, daemon=True).start()
 rng = numpy.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.
 t0 = time.time()
@@ -95,4 +117,7 @@ while time.time() - t0 < budget:
             expect = h_status if h_status else (0 if numpy.array_equal(h_symbols, planar[m]) else 6)
             assert int(st[m]) == expect, (cases, m, int(st[m]), expect)
     cases += 1
+if os.environ.get('EAE_FUZZ_LOAD'):
+    _stop.set()
+    print('conv GEMM launches beside the coder:', _launched[0])
 print('cases', cases, 'statuses seen', seen)

@@ -48,7 +48,8 @@ if os.environ.get('EAE_FUZZ_LOAD'):
                     dev.conv5x5s2(_gdn_1, _enc.w2, _enc.v['encoder/biases_2'], dev.NORM_GDN, _enc.g[2], _enc.v['encoder/beta_2'], out=_out)
                 _launched[0] += 8
                 _load_stream.synchronize()
-    threading.Thread(target=_load, daemon=True).start()
+    _load_thread = threading.Thread(target=_load, daemon=True)
+    _load_thread.start()
 rng = numpy.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 60.
 t0 = time.time()
@@ -119,5 +120,6 @@ while time.time() - t0 < budget:
     cases += 1
 if os.environ.get('EAE_FUZZ_LOAD'):
     _stop.set()
+    _load_thread.join()
     print('conv GEMM launches beside the coder:', _launched[0])
 print('cases', cases, 'statuses seen', seen)

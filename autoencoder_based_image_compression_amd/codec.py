@@ -57,6 +57,10 @@ class Ticket(object):
         self._error = None
         self._values = None
         self.reconstruction_uint8 = None      # device tensor when the codec keeps reconstructions
+        self.reconstruction_host = None       # numpy uint8 (a view of the slot's pinned buffer) with BatchCodec(fetch_reconstruction=True),
+        #                                       after result(); valid until the slot comes round again (nb_slots submits later)
+        self.fed_event = None                 # host input: recorded behind the host -> device copy (the caller's pinned batch may
+        #                                       be rewritten once it has completed)
         self.decoded_event = None             # recorded behind the synthesis transform: wait for it on another stream before
         #                                       reading `reconstruction_uint8` there (valid until the slot comes round again)
         self._coder_span = None               # (start, stop) timing events on the coder stream (BatchCodec(time_coder=True))
@@ -88,19 +92,34 @@ class _Worker(threading.Thread):
         self.host_threads = host_threads
         self.jobs = queue.Queue()
 
+    @staticmethod
+    def _wait(event):
+        if _POLL_SECONDS > 0.:
+            while not event.query():
+                time.sleep(_POLL_SECONDS)
+        else:
+            event.synchronize()
+
     def run(self):
         while True:
             job = self.jobs.get()
             if job is None:
                 return
-            (ticket, events, views, symbols_host, slot_free, recount) = job
+            (ticket, events, views, symbols_host, slot_free, recount, fetch) = job
             try:
                 for event in events:
-                    if _POLL_SECONDS > 0.:
-                        while not event.query():
-                            time.sleep(_POLL_SECONDS)
-                    else:
-                        event.synchronize()
+                    self._wait(event)
+                if fetch is not None:
+                    # The copy back is issued HERE, behind events that have completed: on this runtime an asynchronous copy
+                    # whose stream still waits for an event holds the calling thread until it can start (the launch thread would
+                    # submit the next step only after this one is decoded: 4.5 instead of 3.2 ms per step).
+                    (reconstruction, pinned, stream) = fetch
+                    with torch.cuda.device(reconstruction.device), torch.cuda.stream(stream):
+                        pinned.copy_(reconstruction, non_blocking=True)
+                        copied = torch.cuda.Event()
+                        copied.record()
+                    self._wait(copied)
+                    ticket.reconstruction_host = pinned.numpy()
                 (results, hist, overflow, flags, checks, sse) = [v.numpy() for v in views]
                 # the last word of the squared-error block: tiles that a cut conv launch of this batch left unfinished
                 # (device.conv_workspace_collect); nothing of this batch can be trusted then
@@ -161,7 +180,7 @@ class BatchCodec(object):
     def __init__(self, variables, are_bin_widths_learned, bin_widths_test, map_mean, binary_probabilities, idx_map_exception,
                  batch_size, h_in, w_in, device='cuda', nb_in_flight=None, keep_reconstruction=False, launch_hook=None,
                  coder='device', host_coder_threads=0, hist_radius=2047, nb_transform_streams=1, use_graphs=False,
-                 time_coder=False, fuse_latent=False):
+                 time_coder=False, fuse_latent=False, fetch_reconstruction=False):
         """coder: 'device' (the coder kernels on side streams), 'host' (ONE device -> host copy of the symbols per batch, then
         the host C-ABI coder `eae_coder_compress_maps` on `host_coder_threads` threads: the shape BASELINE.json sketches) or
         'none' (transforms only; the bit counts come back as zeros).
@@ -176,6 +195,9 @@ class BatchCodec(object):
         its own kernel (device.conv5x5s2_latent; same bits). One launch fewer, but at Kodak batch sizes conv_3 has one tile per
         SIMD and nothing to hide that epilogue behind: 3.41 against 3.44 ms per 24 images, with the conv_3 launch at 0.36 ms
         instead of 0.27 + 0.12. Pays for batches that give conv_3 several tiles per SIMD.
+        fetch_reconstruction: the uint8 reconstructions are copied to pinned host memory by the result worker (on a stream of its
+        own, once the batch is decoded) and `Ticket.reconstruction_host` holds them after `result()`: the fetch of the reference's
+        `decode_mini_batches` (eae/batching.py:49-53). The feed is `submit()` with a pinned HOST tensor.
         hist_radius: the exception map's entropy is formed from an exact histogram of its symbols over [-hist_radius,
         hist_radius]; when a symbol falls outside, the result worker counts that batch's exception maps again over the whole
         int16 range (like the image-by-image functions of `kodak/`; the reference's histogram has no bound,
@@ -213,7 +235,8 @@ class BatchCodec(object):
         if self.idx_map_exception >= 0:
             prob_row[self.idx_map_exception::self.nb_maps] = -1        # costed from its histogram (compression.py:68-75)
         self.prob_row = prob_row.to(self.device)
-        self.keep_reconstruction = keep_reconstruction
+        self.fetch_reconstruction = bool(fetch_reconstruction)
+        self.keep_reconstruction = bool(keep_reconstruction) or self.fetch_reconstruction
         self.hist_radius = int(hist_radius)
         self.coder = coder
         self.time_coder = bool(time_coder)      # Ticket.coder_ms(): the launch-by-launch path only
@@ -265,6 +288,12 @@ class BatchCodec(object):
         self._graphs = [None]*self.nb_slots          # per slot: (three graphs, static input, latents, reconstruction)
         self._warm = False
         self._recount_stream = None
+        # host in / host out: a copy stream each way, a pinned buffer per slot for the reconstructions, device staging for the inputs
+        self._feed_stream = None
+        self._staging = [None]*self.nb_slots
+        self._fetch_stream = torch.cuda.Stream(device=self.device) if self.fetch_reconstruction else None
+        self._pinned_rec = [torch.empty((batch_size, h_in, w_in), dtype=torch.uint8).pin_memory() if self.fetch_reconstruction else None
+                            for _ in range(self.nb_slots)]
         assert not self.use_graphs or self._transform_streams      # replays never go to the caller's stream
 
     def _views(self, t):
@@ -279,12 +308,16 @@ class BatchCodec(object):
                 flags.view(self.batch_size, self.nb_maps), checks)
 
     def submit(self, luminances_uint8):
-        """uint8 device tensor (batch_size, h_in, w_in) -> Ticket. Everything is enqueued; nothing is waited for except a
-        free slot (at most nb_in_flight + 2 batches are pending)."""
+        """uint8 tensor (batch_size, h_in, w_in), on the device or in PINNED host memory -> Ticket. Everything is enqueued; nothing
+        is waited for except a free slot (at most nb_in_flight + 2 batches are pending). A host batch is copied in on a copy
+        stream of the codec's own (`Ticket.fed_event` is recorded behind the copy: leave the batch alone until then)."""
         if luminances_uint8.dtype != torch.uint8:
             raise TypeError('`luminances_uint8.dtype` is not equal to `torch.uint8`.')
         if tuple(luminances_uint8.shape) != (self.batch_size, self.h_in, self.w_in):
             raise ValueError('`luminances_uint8.shape` is not (batch_size, h_in, w_in).')
+        host = luminances_uint8.device.type == 'cpu'
+        if host and not luminances_uint8.is_pinned():
+            raise ValueError('a host batch must be in pinned memory (`torch.Tensor.pin_memory()`): its copy is asynchronous.')
         if self.use_graphs:
             return self._submit_graph(luminances_uint8)
         if not self._transform_streams:
@@ -295,8 +328,20 @@ class BatchCodec(object):
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             ticket = self._submit(luminances_uint8)
-        luminances_uint8.record_stream(stream)
+        if not host:
+            luminances_uint8.record_stream(stream)
         return ticket
+
+    def _feed(self, host_batch, device_batch, ticket_holder):
+        """Host -> device copy of a pinned batch on the codec's feed stream; the CURRENT stream waits for it."""
+        if self._feed_stream is None:
+            self._feed_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._feed_stream):
+            device_batch.copy_(host_batch, non_blocking=True)
+            fed = torch.cuda.Event()
+            fed.record()
+        torch.cuda.current_stream().wait_event(fed)
+        ticket_holder.append(fed)
 
     def _submit_graph(self, luminances_uint8):
         """One step = three hipGraph launches: the analysis side (conv1 .. symbols) and the synthesis side on a transform
@@ -322,9 +367,13 @@ class BatchCodec(object):
             if self._graphs[slot] is None:
                 raise RuntimeError('slot {} has no captured graphs (a capture failed earlier)'.format(slot))
             (graphs, static_input, _, reconstruction) = self._graphs[slot]
-            stream.wait_stream(caller)
+            fed = []
             with torch.cuda.stream(stream):
-                static_input.copy_(luminances_uint8, non_blocking=True)
+                if luminances_uint8.device.type == 'cpu':
+                    self._feed(luminances_uint8, static_input, fed)
+                else:
+                    stream.wait_stream(caller)
+                    static_input.copy_(luminances_uint8, non_blocking=True)
                 graphs[0].replay()
                 quantized = torch.cuda.Event()
                 quantized.record()
@@ -337,13 +386,15 @@ class BatchCodec(object):
                 graphs[2].replay()
                 decoded = torch.cuda.Event()
                 decoded.record()
-            luminances_uint8.record_stream(stream)
+            if not fed:
+                luminances_uint8.record_stream(stream)
             ticket = Ticket(self.batch_size)
             ticket.decoded_event = decoded
+            ticket.fed_event = fed[0] if fed else None
             if self.keep_reconstruction:
                 ticket.reconstruction_uint8 = reconstruction       # valid until this slot is replayed again
             self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],), None,
-                                   self._slot_free[slot], lambda: self._recount_exception_maps(slot)))
+                                   self._slot_free[slot], lambda: self._recount_exception_maps(slot), self._fetch_job(slot, reconstruction)))
             return ticket
         except BaseException:
             self._slot_free[slot].set()       # nobody will report on this slot: without this, drain() / close() wait for ever
@@ -361,7 +412,7 @@ class BatchCodec(object):
             # `_submit_graph` picks from the submission index (slots and streams go round at different periods)
             stream = self._transform_streams[slot % len(self._transform_streams)]
             coder_stream = self._streams[slot % len(self._streams)]
-            static_input = torch.empty_like(like)
+            static_input = torch.empty(tuple(like.shape), dtype=torch.uint8, device=self.device)      # `like` may be a host batch
             graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
             with torch.cuda.graph(graphs[0], stream=stream, capture_error_mode='thread_local'):
                 latents = self._launch_analysis(static_input, slot, None)
@@ -379,6 +430,12 @@ class BatchCodec(object):
         self._slot_free[slot].clear()
         try:
             hook = self.launch_hook
+            fed = []
+            if luminances_uint8.device.type == 'cpu':
+                if self._staging[slot] is None:
+                    self._staging[slot] = torch.empty((self.batch_size, self.h_in, self.w_in), dtype=torch.uint8, device=self.device)
+                self._feed(luminances_uint8, self._staging[slot], fed)
+                luminances_uint8 = self._staging[slot]
             latents = self._launch_analysis(luminances_uint8, slot, hook)
             quantized = torch.cuda.Event()
             quantized.record()
@@ -397,14 +454,23 @@ class BatchCodec(object):
             decoded = torch.cuda.Event()
             decoded.record()
             ticket.decoded_event = decoded
+            ticket.fed_event = fed[0] if fed else None
             if self.keep_reconstruction:
                 ticket.reconstruction_uint8 = reconstruction
             self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],),
-                                   self._pinned_symbols[slot], self._slot_free[slot], lambda: self._recount_exception_maps(slot)))
+                                   self._pinned_symbols[slot], self._slot_free[slot], lambda: self._recount_exception_maps(slot),
+                                   self._fetch_job(slot, reconstruction)))
             return ticket
         except BaseException:
             self._slot_free[slot].set()       # as in _submit_graph
             raise
+
+    def _fetch_job(self, slot, reconstruction):
+        """What the result worker needs to copy the slot's reconstruction to the host (None: not asked for)."""
+        if not self.fetch_reconstruction:
+            return None
+        reconstruction.record_stream(self._fetch_stream)
+        return (reconstruction, self._pinned_rec[slot], self._fetch_stream)
 
     def _recount_exception_maps(self, slot):
         """Histograms of the slot's exception maps over all of int16, as a host array [batch, 65535] (called by the result

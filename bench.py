@@ -18,11 +18,9 @@ import gc
 import json
 import math
 import os
-import queue
 import socket
 import subprocess
 import sys
-import threading
 import time
 
 
@@ -257,77 +255,20 @@ def run_pipeline(ctx, batch, steps, warmup, variables, h, w, coder='device', cod
                           device=device, nb_in_flight=coder_streams, launch_hook=timed_launch if record else None,
                           coder=coder_mode, host_coder_threads=coder_threads, nb_transform_streams=transform_streams,
                           use_graphs=use_graphs, time_coder=coder_events, fuse_latent=args.fuse_latent,
-                          keep_reconstruction=pcie) as the_codec:
-        flush = None
+                          fetch_reconstruction=pcie) as the_codec:
         if pcie:
+            # the codec's own feed and fetch: a pinned host batch in (copied on its feed stream), the reconstruction back to
+            # pinned host memory (copied by its result worker once the batch is decoded)
             pinned_in = images_host.pin_memory()
-            depth = the_codec.nb_slots
-            staging = [torch.empty_like(images) for _ in range(depth)]
-            pinned_out = [torch.empty((batch, h, w), dtype=torch.uint8).pin_memory() for _ in range(depth)]
-            (h2d, d2h) = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
-            fetched = [None]*depth          # event behind the device -> host copy that last read slot k's buffers
-            fetch_issued = [threading.Event() for _ in range(depth)]
-            for e in fetch_issued:
-                e.set()
-            fetch_jobs = queue.Queue()
-            fetch_errors = []
-            counter = [0]
-
-            # The copy back is issued by a thread of its own: on this runtime an asynchronous copy whose stream still waits
-            # for an event holds the CALLING thread until the copy can start (the whole depth of the step, here), and the launch
-            # thread would submit the next step only after this one is decoded.
-            def fetcher():
-                torch.cuda.set_device(device)
-                while True:
-                    job = fetch_jobs.get()
-                    try:
-                        if job is None:
-                            return
-                        (ticket, k) = job
-                        try:
-                            with torch.cuda.stream(d2h):
-                                d2h.wait_event(ticket.decoded_event)
-                                pinned_out[k].copy_(ticket.reconstruction_uint8, non_blocking=True)
-                                fetched[k] = torch.cuda.Event()
-                                fetched[k].record()
-                        except BaseException as exc:       # surfaced by flush_fetches(); the queue keeps moving
-                            fetch_errors.append(exc)
-                        fetch_issued[k].set()
-                    finally:
-                        fetch_jobs.task_done()
-
-            fetch_thread = threading.Thread(target=fetcher, name='fetcher', daemon=True)
-            fetch_thread.start()
-
-            def flush_fetches():
-                fetch_jobs.join()
-                if fetch_errors:
-                    raise fetch_errors[0]
-            flush = flush_fetches
 
             def submit():
-                k = counter[0] % depth
-                counter[0] += 1
-                fetch_issued[k].wait()
-                fetch_issued[k].clear()
-                if fetched[k] is not None:
-                    fetched[k].synchronize()          # long done: the slot's previous reconstruction is on the host
-                with torch.cuda.stream(h2d):
-                    staging[k].copy_(pinned_in, non_blocking=True)
-                    fed = torch.cuda.Event()
-                    fed.record()
-                torch.cuda.current_stream().wait_event(fed)
-                ticket = the_codec.submit(staging[k])
-                fetch_jobs.put((ticket, k))
-                return ticket
+                return the_codec.submit(pinned_in)
         else:
             def submit():
                 return the_codec.submit(images)
         for _ in range(warmup):
             submit()
         the_codec.drain()
-        if flush is not None:
-            flush()
         # the launch thread allocates only short-lived wrappers: keep the cyclic collector (a 30 ms pause every ~75 steps) out of it
         gc.collect()
         gc.disable()
@@ -342,9 +283,9 @@ def run_pipeline(ctx, batch, steps, warmup, variables, h, w, coder='device', cod
                 c0 = time.process_time()
                 tickets = [submit() for _ in range(steps)]
                 the_codec.drain()
-                if flush is not None:
-                    flush()               # every copy back has been issued (the closing synchronize waits for them)
                 results = [t.result() for t in tickets]          # raises here if any map of any batch failed
+                if pcie and any(t.reconstruction_host is None for t in tickets):
+                    raise RuntimeError('a reconstruction did not reach the host')
                 # the path's only exchange step: sum the rate / PSNR accumulators over ranks
                 block_stats = torch.tensor([float(sum(int(r['nb_bits'].sum()) for r in results)), float(sum(int(r['sse'].sum()) for r in results)),
                                             float(sum(int(r['nb_deads'].sum()) for r in results)), float(steps*batch)],
@@ -362,10 +303,6 @@ def run_pipeline(ctx, batch, steps, warmup, variables, h, w, coder='device', cod
                     break
         finally:
             gc.enable()
-            if flush is not None:
-                fetch_jobs.put(None)
-                fetch_thread.join()
-                torch.cuda.synchronize()      # the last copies read the codec's buffers: before `the_codec` closes
     order = sorted(range(len(block_seconds)), key=lambda i: block_seconds[i])
     mid = order[(len(order) - 1)//2]      # an actual block (the lower median when the count is even)
     # host CPU of this process (all its threads: launch thread, result worker, runtime helpers) per step, every rank's figure
@@ -591,9 +528,9 @@ def main(args):
         line['pcie_inclusive'] = {'value': round(60*pixels_per_step/feed['elapsed']/1e6, 3), 'unit': 'Mpixels/s',
                                   'ms_per_step': round(feed['elapsed']/60*1e3, 4), 'steps': 60, 'warmup': 10,
                                   'bytes_per_step': {'host_to_device': pixels_per_step, 'device_to_host': pixels_per_step},
-                                  'note': 'uint8 batch copied from pinned host memory on a copy stream before every step, uint8 '
-                                          'reconstruction copied back on another (issued by a thread of its own: an asynchronous '
-                                          'copy behind an event holds its calling thread on this runtime); never the headline'}
+                                  'note': 'codec.BatchCodec(fetch_reconstruction=True).submit(pinned host batch): the uint8 batch is '
+                                          'copied in on the codec\'s feed stream before every step, the uint8 reconstruction copied '
+                                          'back to pinned host memory by its result worker; never the headline'}
         # north_star's original shape (one device -> host copy of the symbols, the host C-ABI coder on the CPUs the quota allows)
         host = run_pipeline(ctx, args.batch, 30, 5, variables, h_in, w_in, coder='host', coder_streams=3, min_seconds=0.5, max_blocks=5)
         line['host_coder'] = {'value': round(30*pixels_per_step/host['elapsed']/1e6, 3), 'unit': 'Mpixels/s',

@@ -332,10 +332,15 @@ class BatchCodec(object):
             luminances_uint8.record_stream(stream)
         return ticket
 
-    def _feed(self, host_batch, device_batch, ticket_holder):
-        """Host -> device copy of a pinned batch on the codec's feed stream; the CURRENT stream waits for it."""
+    def _feed(self, host_batch, device_batch, ticket_holder, fresh=False):
+        """Host -> device copy of a pinned batch on the codec's feed stream; the CURRENT stream waits for it. fresh: the
+        destination has just come from the caching allocator, which may have handed out a block that kernels still queued on
+        the current stream use (freed intermediates of the previous steps: safe to reuse in stream order only): the copy
+        then goes behind everything the current stream holds."""
         if self._feed_stream is None:
             self._feed_stream = torch.cuda.Stream(device=self.device)
+        if fresh:
+            self._feed_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._feed_stream):
             device_batch.copy_(host_batch, non_blocking=True)
             fed = torch.cuda.Event()
@@ -432,9 +437,10 @@ class BatchCodec(object):
             hook = self.launch_hook
             fed = []
             if luminances_uint8.device.type == 'cpu':
-                if self._staging[slot] is None:
+                fresh = self._staging[slot] is None
+                if fresh:
                     self._staging[slot] = torch.empty((self.batch_size, self.h_in, self.w_in), dtype=torch.uint8, device=self.device)
-                self._feed(luminances_uint8, self._staging[slot], fed)
+                self._feed(luminances_uint8, self._staging[slot], fed, fresh)
                 luminances_uint8 = self._staging[slot]
             latents = self._launch_analysis(luminances_uint8, slot, hook)
             quantized = torch.cuda.Event()

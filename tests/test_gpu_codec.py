@@ -341,12 +341,10 @@ def test_host_in_host_out_equals_the_device_resident_path(mode):
         tickets = [c.submit(p) for p in pinned]                        # nine batches through four slots
         for (k, t) in enumerate(tickets):
             r = t.result()
-            # a slot's pinned buffer is rewritten when the slot comes round: nothing had to be kept here, every ticket is read
-            # before its slot's next result can be delivered only if we look at it now -- so compare at once
             assert t.fed_event is not None and t.fed_event.query()
             for key in ('nb_bits', 'sse', 'nb_deads'):
                 assert numpy.array_equal(r[key], want[k][0][key]), (k, key)
-        # the last nb_slots reconstructions are still in their pinned buffers
+        # a slot's pinned buffer is rewritten when the slot comes round: the last nb_slots reconstructions are still there
         for k in range(len(batches) - c.nb_slots, len(batches)):
             assert numpy.array_equal(tickets[k].reconstruction_host, want[k][1]), k
 

@@ -482,8 +482,19 @@ int launch(ConvGemmParams& p, hipStream_t stream) {
     // A layer with fewer waves than ~2 per SIMD runs in coarse rounds (conv_3 at Kodak batch 24: 1152 waves on 1024 SIMDs
     // = two rounds, 48 % MFMA utilisation). Spread the output channels of each position tile over 2 (or 4) blocks and run
     // the normalisation as its own small pass over the output (gdn_kernel, in place: same arithmetic, same bits).
+    // Below one wave per SIMD the launch is as long as ONE wave's chain, so the finer split wins as long as its waves still fit
+    // the machine at once (one Kodak image, launches alone: conv_2 0.156 -> 0.121 ms, conv_3 0.122 -> 0.081, transpose_conv_1
+    // 0.078 -> 0.063 with quarter tiles; transpose_conv_2, 768 items, 0.107 -> 0.093 ms with WHOLE tiles and the fused
+    // epilogue instead of two rounds of half tiles and the extra normalisation pass: profiles/r03_gemm_forms_1x512x768.txt).
     int nt = 4;
-    if (waves == 1 && ((long)tiles * p.n_phases < 2048 || small_conv)) nt = 2;
+    if (waves == 1) {
+        const long items = (long)tiles * p.n_phases, simds = 4L * eae_compute_units();
+        if (items * 4 <= simds) nt = 1;
+        else if (items * 2 <= simds || (small_conv && items >= simds)) nt = 2;
+        else if (items < 2048 && p.norm == EAE_NORM_NONE) nt = 2;
+        // between half a wave and one wave per SIMD, a layer with a normalisation keeps whole tiles (conv_2 of four Kodak
+        // images, 768 items: 0.223 ms whole, 0.252 as half tiles + the normalisation pass)
+    }
     if (const char* force = std::getenv("EAE_HIP_FORCE_NT")) nt = std::atoi(force) == 1 ? 1 : (std::atoi(force) == 2 ? 2 : 4);
     if (nt != 4 && waves == 1) {
         grid *= 4 / nt;

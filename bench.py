@@ -54,11 +54,12 @@ def parse_args(argv=None):
                         help='batches whose entropy coding may be in flight at once (each on its own HIP stream). 0 (default): '
                              'decided from the shape (`auto_coder_streams`: a map is one serial chain, so large maps need more '
                              'batches in flight for the transforms to cover it)')
-    parser.add_argument('--transform-streams', type=int, default=int(os.environ.get('EAE_TRANSFORM_STREAMS', '2')),
-                        help='2 (default, the product mode): consecutive batches alternate between two private streams, so the '
-                             'tail of one batch\'s kernel is filled by the next batch\'s. 1: the transforms of consecutive batches '
-                             'back to back on one stream (what the `roofline` leg always uses, so that the HIP events around a '
-                             'launch time that kernel alone)')
+    parser.add_argument('--transform-streams', type=int, default=int(os.environ.get('EAE_TRANSFORM_STREAMS', '3')),
+                        help='3 (default, the product mode): consecutive batches go round three private streams, so the tail of '
+                             'one batch\'s kernel is filled by the next batches\' (2 / 3 / 4 / 5 streams: 3,020 / 3,075 / 3,060 / '
+                             '3,030 Mpx/s at the default shape, 2,550 / 2,770 / 2,740 for 64 x 256x256: profiles/r03_transform_streams2.txt). '
+                             '1: the transforms of consecutive batches back to back on one stream (what the `roofline` leg always '
+                             'uses, so that the HIP events around a launch time that kernel alone)')
     parser.add_argument('--fuse-latent', action='store_true',
                         help='the latent stage as the epilogue of the conv_3 launch (codec.BatchCodec(fuse_latent=True)); the roofline '
                              'figure then counts gdn_3 and inverse_gdn_4 in that launch')

@@ -514,14 +514,14 @@ def main(args):
     if side and (h_in, w_in, args.batch) == (512, 768, 24):
         # the other shapes BASELINE.json names, same default flags (what `python bench.py --height H --width W --batch B` prints)
         line['other_shapes'] = []
-        for (b2, h2, w2, steps2, what) in ((64, 256, 256, 40, 'one rank of configs[3] (512 images of 256x256 over 8 GPUs)'),
-                                           (2, 2048, 2048, 30, 'configs[4]: 2048x2048, untiled (fits HBM), two images per step')):
+        for (b2, h2, w2, steps2, what) in ((64, 256, 256, 100, 'one rank of configs[3] (512 images of 256x256 over 8 GPUs)'),
+                                           (2, 2048, 2048, 50, 'configs[4]: 2048x2048, untiled (fits HBM), two images per step')):
             leg = run_pipeline(ctx, b2, steps2, 8, variables, h2, w2, coder_streams=auto_coder_streams(h2, w2),
                                transform_streams=args.transform_streams, use_graphs=args.graphs, min_seconds=0.4, max_blocks=5)
             line['other_shapes'].append({'workload': '{0}x{1}x{2}'.format(b2, h2, w2), 'what': what,
                                          'value': round(steps2*b2*h2*w2/leg['elapsed']/1e6, 3), 'unit': 'Mpixels/s',
-                                         'ms_per_step': round(leg['elapsed']/steps2*1e3, 4), 'coder_streams': auto_coder_streams(h2, w2),
-                                         'rate_bpp': round(rate_and_psnr(leg['stats'], h2, w2)[0], 5)})
+                                         'ms_per_step': round(leg['elapsed']/steps2*1e3, 4), 'steps': steps2,
+                                         'coder_streams': auto_coder_streams(h2, w2), 'rate_bpp': round(rate_and_psnr(leg['stats'], h2, w2)[0], 5)})
     if side and args.coder == 'device':
         # the feed / fetch of the reference's sess.run (uint8 images from pinned host memory in, uint8 reconstructions out)
         feed = run_pipeline(ctx, args.batch, 60, 10, variables, h_in, w_in, coder_streams=coder_streams, transform_streams=args.transform_streams,

@@ -352,8 +352,16 @@ __global__ __launch_bounds__(64) void emit_kernel(const SimdParams p) {
 // [kRing][64] words.
 constexpr size_t decode_lds_bytes(uint32_t L) { return ((size_t)L + 1u) * 64u * sizeof(double) + (size_t)kRing * 64u * sizeof(uint32_t); }
 
+#ifdef EAE_HWID_PROBE      // scratch/r03_hwid_probe.py: does a long-lived coder wave ever resume on another CU / SIMD / slot (context save / restore)?
+__device__ unsigned int g_hwid_probe[8];     // [0] waves, [1] waves whose HW_ID[15:0] or XCC_ID changed, [2..5] an example (before, after)
+#endif
+
 __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p) {
     __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
+#ifdef EAE_HWID_PROBE
+    const unsigned int probe_hw0 = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);      // HW_REG_HW_ID
+    const unsigned int probe_xcc0 = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);     // HW_REG_XCC_ID
+#endif
     const uint32_t lane = threadIdx.x;
     const uint32_t m = blockIdx.x * 64u + lane;
     const bool in_range = m < p.n_maps;
@@ -474,7 +482,26 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
         }
     }
     if (live && retry) p.status[m] = RETRY;
+#ifdef EAE_HWID_PROBE
+    {
+        const unsigned int hw1 = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);
+        const unsigned int xcc1 = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);
+        if (lane == 0) {
+            atomicAdd(&g_hwid_probe[0], 1u);
+            if (((hw1 ^ probe_hw0) & 0xFFFFu) != 0u || xcc1 != probe_xcc0) {
+                atomicAdd(&g_hwid_probe[1], 1u);
+                g_hwid_probe[2] = probe_hw0; g_hwid_probe[3] = probe_xcc0; g_hwid_probe[4] = hw1; g_hwid_probe[5] = xcc1;
+            }
+        }
+    }
+#endif
 }
+
+#ifdef EAE_HWID_PROBE
+extern "C" int eae_hip_debug_hwid_probe(unsigned int* out8) {
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_hwid_probe), 8 * sizeof(unsigned int));
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // (5) one wavefront per map: prefixes + bypass stream -> symbols; compare with the encoder's input

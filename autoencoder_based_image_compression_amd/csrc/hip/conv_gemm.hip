@@ -518,11 +518,15 @@ int launch(ConvGemmParams& p, hipStream_t stream) {
 }  // namespace
 
 namespace {
+// The kernels address inside ONE image with 32-bit byte offsets (buffer descriptors): an activation plane of 128 channels must
+// stay below 2 GB, i.e. at most 4,194,303 positions (2048 x 2047) per image on the larger side of the layer.
+bool plane_fits(long h, long w) { return h * w * EAE_C * (long)sizeof(float) <= 0x7FFFFFFFL; }
+
 int conv5x5s2(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma_packed, const float* beta,
               float* out, int n, int h, int w_in, unsigned int* workspace, void* stream) {
     if (!x || !w_packed || !out || n <= 0 || h <= 0 || w_in <= 0) return EAE_HIP_BAD_ARGUMENT;
     if (norm != EAE_NORM_NONE && (!gamma_packed || !beta)) return EAE_HIP_BAD_ARGUMENT;
-    if ((h & 1) || (w_in & 1)) return EAE_HIP_BAD_SHAPE;
+    if ((h & 1) || (w_in & 1) || !plane_fits(h, w_in)) return EAE_HIP_BAD_SHAPE;
     ConvGemmParams p{};
     p.in = x; p.out = out; p.w = w_packed; p.bias = bias; p.gamma = gamma_packed; p.beta = beta; p.norm = norm;
     p.n = n; p.hin = h; p.win = w_in; p.hp = h / 2; p.wp = w_in / 2; p.hout = h / 2; p.wout = w_in / 2;
@@ -539,6 +543,7 @@ int tconv5x5s2(const float* x, const float* w_packed, const float* bias, int nor
                float* out, int n, int h, int w_in, unsigned int* workspace, void* stream) {
     if (!x || !w_packed || !out || n <= 0 || h <= 0 || w_in <= 0) return EAE_HIP_BAD_ARGUMENT;
     if (norm != EAE_NORM_NONE && (!gamma_packed || !beta)) return EAE_HIP_BAD_ARGUMENT;
+    if (!plane_fits(2L * h, 2L * w_in)) return EAE_HIP_BAD_SHAPE;
     ConvGemmParams p{};
     p.in = x; p.out = out; p.w = w_packed; p.bias = bias; p.gamma = gamma_packed; p.beta = beta; p.norm = norm;
     p.n = n; p.hin = h; p.win = w_in; p.hp = h; p.wp = w_in; p.hout = 2 * h; p.wout = 2 * w_in;
@@ -586,7 +591,7 @@ extern "C" int eae_hip_conv5x5s2_latent(const float* x, const float* w_packed, c
     const bool fixed = gamma_in_packed != nullptr;
     float* main_out = fixed ? t_out : shifted_out;        // the decoder's input: also where a cut tile's accumulators wait
     if (!main_out) return EAE_HIP_BAD_ARGUMENT;
-    if ((h & 1) || (w_in & 1)) return EAE_HIP_BAD_SHAPE;
+    if ((h & 1) || (w_in & 1) || !plane_fits(h, w_in)) return EAE_HIP_BAD_SHAPE;
     ConvGemmParams p{};
     p.in = x; p.out = main_out; p.w = w_packed; p.bias = bias; p.gamma = gamma_in_packed; p.beta = beta_in;
     p.norm = fixed ? NORM_LATENT : NORM_LATENT_PLAIN;

@@ -160,6 +160,7 @@ extern "C" int eae_hip_encode(const eae_hip_model* m, const uint8_t* images, int
                               void* scratch, uint64_t scratch_bytes, void* stream) {
     if (!m || !m->has_encoder || !images || !latents || !scratch || n <= 0 || h <= 0 || w <= 0) return EAE_HIP_BAD_ARGUMENT;
     if ((h % 16) || (w % 16)) return EAE_HIP_BAD_SHAPE;      // "not divisible by the product of the three strides"
+    if ((long)(h / 4) * (w / 4) * 512L > 0x7FFFFFFFL) return EAE_HIP_BAD_SHAPE;   // conv_2's input plane: 32-bit offsets inside an image
     const ScratchLayout s = encode_layout(n, h, w);
     if (scratch_bytes < s.total) return EAE_HIP_BAD_ARGUMENT;
     char* base = static_cast<char*>(scratch);
@@ -190,6 +191,7 @@ extern "C" int eae_hip_decode(const eae_hip_model* m, const float* quantized_lat
                               uint64_t scratch_bytes, void* stream) {
     if (!m || !m->has_decoder || !quantized_latents || !scratch || n <= 0 || h_latent <= 0 || w_latent <= 0) return EAE_HIP_BAD_ARGUMENT;
     if (!out_f32 && !out_u8 && !ref_u8) return EAE_HIP_BAD_ARGUMENT;
+    if (16L * h_latent * w_latent * 512L > 0x7FFFFFFFL) return EAE_HIP_BAD_SHAPE;   // transpose_conv_3's input plane, as in eae_hip_encode
     const ScratchLayout s = decode_layout(n, h_latent, w_latent);
     if (scratch_bytes < s.total) return EAE_HIP_BAD_ARGUMENT;
     char* base = static_cast<char*>(scratch);

@@ -294,7 +294,7 @@ extern "C" int eae_hip_tconv9x9s4_luma(const float* x, const float* w_phase, flo
     if (!x || !w_phase || n <= 0 || h <= 0 || w_in <= 0) return EAE_HIP_BAD_ARGUMENT;
     if (!out_f32 && !out_u8 && !ref_u8) return EAE_HIP_BAD_ARGUMENT;
     if ((ref_u8 != nullptr) != (sse != nullptr)) return EAE_HIP_BAD_ARGUMENT;
-    if ((long)h * w_in * EAE_C * (long)sizeof(float) > 0x7FFFFFFFL) return EAE_HIP_BAD_ARGUMENT;    // 32-bit offsets inside an image
+    if ((long)h * w_in * EAE_C * (long)sizeof(float) > 0x7FFFFFFFL) return EAE_HIP_BAD_SHAPE;       // 32-bit offsets inside an image
     const int tiles_r = (h + TH - 1) / TH, tiles_c = (w_in + TW - 1) / TW;
     const long n_tiles = (long)n * tiles_r * tiles_c;
     if (n_tiles > 0x7FFFFFFFL) return EAE_HIP_BAD_ARGUMENT;

@@ -106,7 +106,9 @@ int eae_hip_conv9x9s4_u8(const uint8_t* x, const float* w_packed, const float* b
 
 /* conv_2 / conv_3 + bias_add (+ gdn_2 / gdn_3)  (components.py:126-142; tf.nn.conv2d 5x5, 128->128, stride 2,
  * 'SAME' = pad 1/2). x: f32 [N][H][W][128]; w_packed: from eae_hip_pack_conv_weights (HWIO [5][5][128][128] with the
- * output channels in packed order); out: [N][H/2][W/2][128]. H, W even.
+ * output channels in packed order); out: [N][H/2][W/2][128]. H, W even, and H * W * 512 bytes (one image's input plane; the
+ * kernels address inside an image with 32-bit byte offsets) below 2 GB: EAE_HIP_BAD_SHAPE otherwise. For the whole path that is
+ * an image of at most 67 megapixels (conv_2's input is the 1/16-size plane: 8192 x 8176 passes, 8192 x 8192 does not).
  * norm: EAE_NORM_NONE (learned-bin-width model, components.py:137-138) or EAE_NORM_GDN (gamma_packed, beta). */
 int eae_hip_conv5x5s2(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma_packed,
                       const float* beta, float* out, int n, int h, int w_in, void* stream);
@@ -121,7 +123,7 @@ int eae_hip_gdn(const float* x, const float* gamma_packed, const float* beta, in
 
 /* transpose_conv_1 / _2 + bias_add + inverse_gdn of the next layer (components.py:63-78; tf.nn.conv2d_transpose 5x5,
  * 128->128, stride 2, 'SAME'). x: [N][h][w][128]; w_packed: from eae_hip_pack_tconv_weights (the TF filter
- * [5][5][out][in] as [25][in][packed out]); out: [N][2h][2w][128]. */
+ * [5][5][out][in] as [25][in][packed out]); out: [N][2h][2w][128] (one image's output plane below 2 GB, as above). */
 int eae_hip_tconv5x5s2(const float* x, const float* w_packed, const float* bias, int norm, const float* gamma_packed,
                        const float* beta, float* out, int n, int h, int w_in, void* stream);
 

@@ -61,3 +61,19 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, name)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), os.path.join(dirpath, name)
                 assert 'liboracle' not in text and '_ref/' not in text, os.path.join(dirpath, name)
+
+
+def test_planes_beyond_32_bit_offsets_are_rejected_before_anything_is_launched():
+    """The conv kernels address inside one image with 32-bit byte offsets: an activation plane of 2 GB or more (an image beyond
+    67 megapixels) must come back as EAE_HIP_BAD_SHAPE from the argument checks -- no launch, no device needed, nothing read."""
+    lib = _native.hip()
+    buf = (ctypes.c_float*64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    (ok_h, ok_w, big_h, big_w) = (2048, 2046, 2048, 2048)        # planes of 2047.0 MB and 2048 MB
+    assert lib.eae_hip_conv5x5s2(p, p, None, 0, None, None, p, 1, big_h, big_w, None) == -2
+    assert lib.eae_hip_conv5x5s2_ws(p, p, None, 0, None, None, p, 1, big_h, big_w, p, None) == -2
+    assert lib.eae_hip_tconv5x5s2(p, p, None, 0, None, None, p, 1, big_h//2, big_w//2, None) == -2
+    assert lib.eae_hip_tconv9x9s4_luma(p, p, p, None, None, None, 1, big_h, big_w, None) == -2
+    # odd sizes still win over everything else, NULL pointers over the shape
+    assert lib.eae_hip_conv5x5s2(p, p, None, 0, None, None, p, 1, ok_h + 1, ok_w, None) == -2
+    assert lib.eae_hip_conv5x5s2(None, p, None, 0, None, None, p, 1, big_h, big_w, None) == -1

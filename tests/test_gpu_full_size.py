@@ -119,3 +119,49 @@ def test_map_means(shape):
     got = stats.compute_map_mean(y)
     assert got.dtype == numpy.float32 and got.shape == (128,)
     assert numpy.array_equal(got, numpy.mean(y, axis=(0, 1, 2)))
+
+
+def test_the_largest_image_the_kernels_accept_equals_its_crops():
+    """Maximum size: 8192 x 8176 (66.98 Mpx) puts conv_2's input plane and transpose_conv_2's output plane at 2,143 MB, 4 MB under the
+    2 GB that the kernels' 32-bit in-image offsets reach (include/eae_hip.h). The oracle does not finish in seconds there, but the
+    transforms are local: away from a crop's cut edges, the big image's latents and reconstruction must equal, bit for bit, those
+    of the crop on its own (and a crop IS held against the oracle: the 1024 x 1024 case below) -- including the bottom-right corner,
+    where the offsets are largest."""
+    import torch
+    from autoencoder_based_image_compression_amd import device as dev
+    from autoencoder_based_image_compression_amd import pipeline
+    (H, W, C) = (8192, 8176, 1024)
+    v = _model()
+    rng = numpy.random.RandomState(21)
+    x = rng.randint(16, 236, size=(1, H, W), dtype=numpy.uint8)
+    encoder = pipeline.DeviceEncoder(v, False)
+    decoder = pipeline.DeviceDecoder(v, False)
+    bw = torch.ones(128, dtype=torch.float32, device='cuda')
+    mean = torch.zeros(128, dtype=torch.float32, device='cuda')
+    xd = torch.from_numpy(x).cuda()
+    y_big = encoder(xd)
+    assert tuple(y_big.shape) == (1, H//16, W//16, 128)
+    shifted_big = dev.quantize_maps(y_big, bw, mean, want_shifted=True)['shifted']
+    (_, rec_big, sse_big) = decoder(shifted_big, reference_uint8=xd)
+    assert int(sse_big[0]) == int(((x.astype(numpy.int64) - rec_big.cpu().numpy().astype(numpy.int64))**2).sum())
+    m = 3                                    # latent positions next to a cut edge see pixels the crop does not have
+    for (r0, c0) in ((0, 0), (H - C, W - C), (H - C, 0), (0, W - C), (3584, 3568)):
+        crop = xd[:, r0:r0 + C, c0:c0 + C].contiguous()
+        y_crop = encoder(crop)
+        (lo_r, hi_r) = (0 if r0 == 0 else m, C//16 - (0 if r0 + C == H else m))
+        (lo_c, hi_c) = (0 if c0 == 0 else m, C//16 - (0 if c0 + C == W else m))
+        assert torch.equal(y_big[:, r0//16 + lo_r:r0//16 + hi_r, c0//16 + lo_c:c0//16 + hi_c], y_crop[:, lo_r:hi_r, lo_c:hi_c]), (r0, c0)
+        # the synthesis transform on the crop's slice of the big image's quantised latents
+        piece = shifted_big[:, r0//16:(r0 + C)//16, c0//16:(c0 + C)//16].contiguous()
+        (_, rec_crop, _) = decoder(piece, reference_uint8=crop)
+        (plo_r, phi_r, plo_c, phi_c) = (16*lo_r + (16 if lo_r else 0), 16*hi_r - (16 if hi_r != C//16 else 0),
+                                        16*lo_c + (16 if lo_c else 0), 16*hi_c - (16 if hi_c != C//16 else 0))
+        assert torch.equal(rec_big[:, r0 + plo_r:r0 + phi_r, c0 + plo_c:c0 + phi_c], rec_crop[:, plo_r:phi_r, plo_c:phi_c]), (r0, c0)
+    # the crop itself against the oracle: every value
+    crop = x[:, H - C:, W - C:]
+    from oracle import transforms as T
+    y_ref = T.encoder(crop.astype(numpy.float32)[..., None], v, False)
+    assert numpy.array_equal(encoder(torch.from_numpy(numpy.ascontiguousarray(crop)).cuda()).cpu().numpy(), y_ref)
+    # one size up is refused, loudly
+    with pytest.raises(dev.HipError):
+        encoder(torch.zeros((1, 8192, 8192), dtype=torch.uint8, device='cuda'))

@@ -165,3 +165,35 @@ def test_the_largest_image_the_kernels_accept_equals_its_crops():
     # one size up is refused, loudly
     with pytest.raises(dev.HipError):
         encoder(torch.zeros((1, 8192, 8192), dtype=torch.uint8, device='cuda'))
+
+
+def test_the_fused_path_on_the_largest_image():
+    """codec.BatchCodec at 1 x 8192 x 8176 (maps of 261,632 symbols, streams of megabits): the squared error it reports is that of the
+    reconstruction it returns, its coder bits are those of the separate kernels' path, and three maps agree with the bit-serial
+    oracle coder."""
+    import torch
+    from oracle import coder as oc
+    from autoencoder_based_image_compression_amd import codec, device as dev, pipeline
+    from autoencoder_based_image_compression_amd.kodak.lossless import compression
+    (H, W) = (8192, 8176)
+    v = _model()
+    rng = numpy.random.RandomState(23)
+    x = rng.randint(16, 236, size=(1, H, W), dtype=numpy.uint8)
+    x = ((x.astype(numpy.uint16) + numpy.roll(x, 1, 1) + numpy.roll(x, 1, 2) + numpy.roll(x, -1, 2))//4).astype(numpy.uint8)
+    bw = numpy.ones(128, dtype=numpy.float32)
+    mean = numpy.zeros(128, dtype=numpy.float32)
+    probabilities = numpy.clip(rng.rand(128, 10), 0.05, 0.95)
+    xd = torch.from_numpy(x).cuda()
+    with codec.BatchCodec(v, False, bw, mean, probabilities, 67, 1, H, W, nb_in_flight=1, keep_reconstruction=True) as c:
+        ticket = c.submit(xd)
+        values = ticket.result()
+        rec = ticket.reconstruction_uint8.cpu().numpy()
+    assert int(values['sse'][0]) == int(((x.astype(numpy.int64) - rec.astype(numpy.int64))**2).sum())
+    y = pipeline.DeviceEncoder(v, False)(xd)
+    symbols = dev.quantize_maps(y, torch.from_numpy(bw).cuda(), torch.from_numpy(mean).cuda(), want_symbols=True)['symbols'].cpu().numpy()
+    (rec_sym, nb_bits) = compression.code_planar_symbols(symbols, probabilities, 67)
+    assert numpy.array_equal(rec_sym, symbols)
+    assert int(values['coder_bits'][0]) == int(nb_bits.astype(numpy.int64).sum())
+    lib = oc.CoderLib('oracle')
+    for ch in (0, 66, 127):
+        assert lib.compress_lossless(symbols[0, ch], probabilities[ch])[1] == int(nb_bits[0, ch])

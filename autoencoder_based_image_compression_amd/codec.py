@@ -174,6 +174,18 @@ def default_nb_in_flight(h_in, w_in):
     return int(min(8, 3 + map_size//768))
 
 
+PRODUCT_TRANSFORM_STREAMS = 3      # 2 / 3 / 4 / 5 streams: 3,020 / 3,075 / 3,060 / 3,030 Mpx/s for 24 Kodak images per step, 2,550 / 2,770 / 2,740
+#                                    for 64 images of 256x256 (profiles/r03_transform_streams2.txt)
+
+
+def product_mode(h_in, w_in):
+    """The keyword arguments of the mode a deployment (and `bench.py`'s headline) runs `BatchCodec` in: consecutive batches go
+    round three private transform streams, the step is replayed as three hipGraphs, the number of coder batches in flight follows
+    the map size. `BatchCodec(..., **codec.product_mode(h, w))`; the constructor's own defaults are the conservative ones (every
+    launch on the caller's stream, kernel by kernel: what the per-launch hooks and the roofline leg need)."""
+    return {'nb_in_flight': default_nb_in_flight(h_in, w_in), 'nb_transform_streams': PRODUCT_TRANSFORM_STREAMS, 'use_graphs': True}
+
+
 class BatchCodec(object):
     """Encode -> quantise -> entropy-code (with round trip) -> decode -> squared error for batches of a fixed shape."""
 

@@ -54,8 +54,8 @@ def parse_args(argv=None):
                         help='batches whose entropy coding may be in flight at once (each on its own HIP stream). 0 (default): '
                              'decided from the shape (`auto_coder_streams`: a map is one serial chain, so large maps need more '
                              'batches in flight for the transforms to cover it)')
-    parser.add_argument('--transform-streams', type=int, default=int(os.environ.get('EAE_TRANSFORM_STREAMS', '3')),
-                        help='3 (default, the product mode): consecutive batches go round three private streams, so the tail of '
+    parser.add_argument('--transform-streams', type=int, default=int(os.environ.get('EAE_TRANSFORM_STREAMS', '0')),
+                        help='0 (default): codec.PRODUCT_TRANSFORM_STREAMS = 3, the product mode: consecutive batches go round three private streams, so the tail of '
                              'one batch\'s kernel is filled by the next batches\' (2 / 3 / 4 / 5 streams: 3,020 / 3,075 / 3,060 / '
                              '3,030 Mpx/s at the default shape, 2,550 / 2,770 / 2,740 for 64 x 256x256: profiles/r03_transform_streams2.txt). '
                              '1: the transforms of consecutive batches back to back on one stream (what the `roofline` leg always '
@@ -391,6 +391,8 @@ def launch_rooflines(run_events, pixels_per_step, fuse_latent, map_symbols):
 
 def main(args):
     (h_in, w_in) = (args.height, args.width)
+    if args.transform_streams <= 0:
+        args.transform_streams = codec.PRODUCT_TRANSFORM_STREAMS
 
     # two Python threads share the GIL (kernel launches; the codec's result worker): hand it over quickly
     sys.setswitchinterval(1e-4)

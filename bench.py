@@ -215,7 +215,7 @@ class Context(object):
 
 
 def run_pipeline(ctx, batch, steps, warmup, variables, h, w, coder='device', coder_streams=3, transform_streams=1, use_graphs=False,
-                 min_seconds=0., max_blocks=1, record=False, coder_events=False, pcie=False):
+                 min_seconds=0., max_blocks=1, record=False, coder_events=False, pcie=False, serial=False):
     """Builds the resident state for `batch` images of h x w per step (codec.BatchCodec: weights, tables, per-slot buffers),
     runs `warmup` untimed steps, then BLOCKS of exactly `steps` timed steps -- each block bracketed by barrier + synchronize
     on both sides, its wall time the MAX over ranks -- until `min_seconds` have been timed (at most `max_blocks` blocks; the
@@ -224,7 +224,8 @@ def run_pipeline(ctx, batch, steps, warmup, variables, h, w, coder='device', cod
     record: HIP events around every named launch of the step (launch-by-launch path, one transform stream: a launch then has
     the GPU to itself apart from the coder's side streams). pcie: the images of every step come from pinned host memory (uint8,
     one async copy on a copy stream) and the uint8 reconstructions go back to pinned host memory (the feed / fetch of the
-    reference's `sess.run`, eae/batching.py:95-99, 49-53)."""
+    reference's `sess.run`, eae/batching.py:95-99, 49-53). serial: every step is waited for before the next is submitted (the
+    latency of one step on an otherwise idle GPU instead of the throughput of the pipeline)."""
     args = ctx.args
     (device, world, rank) = (ctx.device, ctx.world, ctx.rank)
     images_host = torch.from_numpy(synthetic_images(1000 + rank + args.seed_offset, batch, h, w))
@@ -282,7 +283,11 @@ def run_pipeline(ctx, batch, steps, warmup, variables, h, w, coder='device', cod
                 ctx.barrier()
                 t0 = time.perf_counter()
                 c0 = time.process_time()
-                tickets = [submit() for _ in range(steps)]
+                tickets = []
+                for _ in range(steps):
+                    tickets.append(submit())
+                    if serial:
+                        tickets[-1].result()
                 the_codec.drain()
                 results = [t.result() for t in tickets]          # raises here if any map of any batch failed
                 if pcie and any(t.reconstruction_host is None for t in tickets):
@@ -509,8 +514,12 @@ def main(args):
     if side and args.batch != 1 and (h_in, w_in) == (512, 768):
         # BASELINE.json configs[1] is ONE Kodak image: the same path with one image per step (launch-bound, not the headline)
         one = run_pipeline(ctx, 1, 300, 30, variables, h_in, w_in, coder_streams=8, transform_streams=6, use_graphs=True)
+        alone = run_pipeline(ctx, 1, 100, 10, variables, h_in, w_in, coder_streams=1, transform_streams=1, use_graphs=True, serial=True)
         line['single_image'] = {'ms_per_image': round(one['elapsed']/300*1e3, 4),
                                 'mpixels_per_s': round(300*h_in*w_in/one['elapsed']/1e6, 2), 'steps': 300, 'warmup': 30,
+                                'latency_ms': round(alone['elapsed']/100*1e3, 4),
+                                'latency_note': 'one image at a time, each waited for before the next is submitted (submit -> result '
+                                                'on the host, 100 images): what BASELINE.json configs[1] takes end to end',
                                 'note': 'one 512x768 image per step; a step is a chain of short latency-bound kernels, so steps '
                                         'are pipelined: 6 transform streams, 8 coder streams, three hipGraph launches per step'}
     if side and (h_in, w_in, args.batch) == (512, 768, 24):

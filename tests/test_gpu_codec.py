@@ -115,7 +115,7 @@ def test_batch_codec_on_tiny_images(tmp_path, shape):
     c.close()
 
 
-@pytest.mark.parametrize('streams', [1, 2])
+@pytest.mark.parametrize('streams', [1, 2, 3])
 @pytest.mark.parametrize('learned', [False, True])
 def test_batch_codec_graph_replay_equals_the_launch_by_launch_path(learned, streams):
     """use_graphs: a step captured into one hipGraph per slot and replayed (with the coder as a forked branch) gives the same
@@ -367,3 +367,29 @@ def test_host_reconstructions_one_at_a_time_are_all_right():
             t = c.submit(b)
             t.result()
             assert numpy.array_equal(t.reconstruction_host, t.reconstruction_uint8.cpu().numpy()), k
+
+
+def test_the_product_mode_at_kodak_size_equals_the_conservative_one():
+    """`codec.product_mode(h, w)` (three transform streams, hipGraph replay, five coder batches in flight at this size: what
+    bench.py's headline runs) against the constructor's defaults (every launch on the caller's stream), 24 images of 512 x 768,
+    twelve steps through the seven slots: same bits, errors, dead maps."""
+    from autoencoder_based_image_compression_amd import codec
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    with numpy.load(GOLD) as g:
+        probabilities = g['real_probabilities_1']
+    mode = codec.product_mode(512, 768)
+    assert mode == {'nb_in_flight': 5, 'nb_transform_streams': 3, 'use_graphs': True}
+    rng = numpy.random.RandomState(37)
+    v = var.random_variables(1., False, seed=8, bias_std=0.01)
+    v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
+    batches = [torch.from_numpy(rng.randint(16, 236, size=(24, 512, 768), dtype=numpy.uint8)).cuda() for _ in range(3)]
+    bin_widths = numpy.ones(128, dtype=numpy.float32)
+    map_mean = numpy.zeros(128, dtype=numpy.float32)
+    with codec.BatchCodec(v, False, bin_widths, map_mean, probabilities, 67, 24, 512, 768) as plain:
+        want = [plain.submit(b).result() for b in batches]
+    with codec.BatchCodec(v, False, bin_widths, map_mean, probabilities, 67, 24, 512, 768, **mode) as c:
+        tickets = [c.submit(batches[k % 3]) for k in range(12)]
+        for (k, t) in enumerate(tickets):
+            r = t.result()
+            for key in ('nb_bits', 'sse', 'nb_deads'):
+                assert numpy.array_equal(r[key], want[k % 3][key]), (k, key)

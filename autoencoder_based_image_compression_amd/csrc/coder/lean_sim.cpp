@@ -63,7 +63,9 @@ int eae_lean_sim_encode(uint32_t size, const int16_t* in, uint32_t L, const doub
     return 0;
 }
 
-// One map: arithmetic-coded stream -> the truncated-unary prefix (0..L) of every symbol.
+// One map: arithmetic-coded stream -> the truncated-unary prefix (0..L) of every symbol. Returns 0, an error code of the core, or
+// eae_lean_sim_outside if the code register ever left the interval -- which no stream, however damaged, can cause (lean_step.h).
+enum { eae_lean_sim_outside = -100 };
 int eae_lean_sim_decode_prefixes(uint32_t size, uint32_t L, const double* probabilities, const uint8_t* bac_bytes,
                                  uint32_t bac_bits, uint8_t* prefixes) {
     // the stream as an array of bits with the reference's end-of-stream rule applied per step
@@ -86,6 +88,7 @@ int eae_lean_sim_decode_prefixes(uint32_t size, uint32_t L, const double* probab
         for (;;) {
             const double p = probabilities[unary];
             if (!(p > 0. && p < 1.)) return eae_core::PROBABILITY;
+            if (!code_inside(s, code32)) return eae_lean_sim_outside;       // cannot happen (lean_step.h: code_inside); checked on every step
             const DecodeStep d = decode_step(s, code32, scaled[unary]);
             code32 = shift_code(code32, d, take(d.take));
             if (!d.one) break;

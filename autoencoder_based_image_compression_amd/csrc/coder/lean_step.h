@@ -119,6 +119,14 @@ struct DecodeStep {
     uint32_t take;     // n + k: stream bits this decision consumes
     uint32_t flip;     // k != 0: the code register's top bit is flipped after the shift
 };
+// The reference's decode_bit (BinaryArithmeticCoder.cpp:254-273) narrows the interval only when low <= code <= high and otherwise
+// leaves interval and decision as they were; this step always narrows. The two agree on EVERY input, damaged streams included,
+// because the code register cannot leave the interval: it starts inside (any 16 bits lie in [0, 0xFFFF]); a decision keeps the
+// half that holds it; E1/E2 shift out a bit that low, code and high share and E3 subtracts the same quarter from all three; and
+// the bit that enters at the bottom (0 for low, 1 for high, the stream's or the repeated last one for the code) cannot break
+// low <= code <= high. `code_inside` states the invariant; the CPU model checks it on every step of every damaged stream the
+// tests feed it (tests/test_lean_coder.py), and the GPU test decodes such streams against the host library (tests/test_coder_device.py).
+EAE_HD bool code_inside(const Interval& s, uint32_t code32) { return code32 >= s.lo && code32 <= ~s.hc; }   // ~hc = (high << 16) | 0xFFFF
 EAE_HD DecodeStep decode_step(Interval& s, uint32_t code32, double p_scaled) {
     const uint32_t mid = middle32(s, p_scaled);
     DecodeStep d;

@@ -12,6 +12,19 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define EAE_C 128  // channels of every hidden layer (eae/graph/constants.py:42-44)
 
+// Kernel-form overrides (experiments and the parity tests of every form): read from the environment ONCE, when the library is
+// loaded, never on the launch path; tests that switch forms inside one process call eae_hip_debug_reload_launch_options(). The
+// hand-off fault injection is not reachable from the environment at all (eae_hip_debug_set_split_mute). misc.hip owns the object.
+struct EaeLaunchOptions {
+    char gemm;          // EAE_HIP_GEMM: 0 (by shape) | 's' cut forced | 'u' whole tiles | 'w' one-tile-per-wave kernel | 'l' LDS slabs
+    int split_waves;    // EAE_HIP_SPLIT_WAVES: 1..3 (with 's'), default 3
+    int force_tile;     // EAE_HIP_FORCE_TILE: 0 (by shape) | 32 | 64 | 128
+    int force_nt;       // EAE_HIP_FORCE_NT: 0 (by shape) | 1 | 2 | 4
+    char latent;        // EAE_HIP_LATENT: 'q' (default) | 'w' | 'l'
+    int split_mute;     // test hook, debug entry point only: heads of cut tiles never publish, tails give up after ~1 ms
+};
+extern EaeLaunchOptions g_eae_launch_options;
+
 #define EAE_HIP_CHECK_LAUNCH()                         \
     do {                                               \
         hipError_t e__ = hipGetLastError();            \

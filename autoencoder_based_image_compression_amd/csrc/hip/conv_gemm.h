@@ -38,7 +38,7 @@ struct ConvGemmParams {
     int split;                          // conv_gemm_split.hip: 1 = the last tiles of each XCD's share are cut in two
     int split_resident_waves_per_xcd;   // conv_gemm_split.hip: how many tiles get cut (the waves an XCD holds at once)
     int split_spin_limit;               // conv_gemm_split.hip: polls of a tail for its head before it gives up (error word)
-    int split_mute_heads;               // conv_gemm_split.hip: TEST HOOK (EAE_HIP_TEST_SPLIT_MUTE): heads never publish
+    int split_mute_heads;               // conv_gemm_split.hip: TEST HOOK (eae_hip_debug_set_split_mute): heads never publish
     // conv_gemm_split.hip, norm == NORM_LATENT / NORM_LATENT_PLAIN: the latent stage behind conv_3 (latent_body.h)
     const float* map_mean;              // [128] or nullptr
     const float* bin_widths;            // [128]

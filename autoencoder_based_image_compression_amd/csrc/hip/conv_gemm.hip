@@ -419,15 +419,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
 
 // conv_gemm_split.hip when EAE_HIP_GEMM asks for it or the layer has at least one 32-position tile per SIMD; 1 = not taken
 int try_split(ConvGemmParams& p, hipStream_t stream) {
-    const char* form = std::getenv("EAE_HIP_GEMM");
-    const char f = form ? form[0] : 0;
+    const char f = g_eae_launch_options.gemm;
     if (!(f == 's' || f == 'u' || f == 0)) return 1;
     int cut = f == 'u' ? 0 : -1;
-    if (f == 's') {
-        const char* e = std::getenv("EAE_HIP_SPLIT_WAVES");
-        cut = e ? std::atoi(e) : 3;
-        if (cut < 1 || cut > 3) cut = 3;
-    }
+    if (f == 's') cut = g_eae_launch_options.split_waves;
     const long tiles32 = ((long)p.n * ((p.hp + 3) / 4) * ((p.wp + 7) / 8)) * p.n_phases;
     if (f == 0 && tiles32 < 1024) return 1;
     return launch_split(p, stream, cut);
@@ -439,8 +434,8 @@ int launch(ConvGemmParams& p, hipStream_t stream) {
     //          workspace) for layers with at least one 32-position tile per SIMD, the small-layer forms below otherwise;
     //   's'    conv_gemm_split.hip with the cut forced, sized for EAE_HIP_SPLIT_WAVES (1..3, default 3) waves per SIMD;
     //   'u'    conv_gemm_split.hip, whole tiles only;   'w'  conv_gemm_wave_kernel;   'l'  block-cooperative LDS slabs.
-    const char* form = std::getenv("EAE_HIP_GEMM");
-    const char f = form ? form[0] : 0;
+    const char f = g_eae_launch_options.gemm;
+    const int force_tile = g_eae_launch_options.force_tile, force_nt = g_eae_launch_options.force_nt;
     const int variant = f == 'l' ? 0 : 1;
     p.stamps = g_stamp_buffer;
     {
@@ -450,7 +445,7 @@ int launch(ConvGemmParams& p, hipStream_t stream) {
     const long positions = (long)p.n * p.hp * p.wp;
     if (variant == 0) {          // block-cooperative LDS slabs (one barrier per K-step); phase is the fastest index
         bool big = positions * p.n_phases >= 128L * 512 && p.wp >= 16;
-        if (const char* force = std::getenv("EAE_HIP_FORCE_TILE")) big = std::atoi(force) == 128;
+        if (force_tile) big = force_tile == 128;
         const int tile_w = big ? 16 : 8;
         p.tiles_r = (p.hp + TILE_H - 1) / TILE_H;
         p.tiles_c = (p.wp + tile_w - 1) / tile_w;
@@ -473,7 +468,7 @@ int launch(ConvGemmParams& p, hipStream_t stream) {
     // channels go to two blocks each below (measured on 64 images of 256x256: conv_2 0.62 -> 0.50 ms)
     const bool small_conv = p.n_phases == 1 && positions < 3L * 1024 * 32;
     if (small_conv) waves = 1;
-    if (const char* force = std::getenv("EAE_HIP_FORCE_TILE")) waves = std::atoi(force) == 128 ? 4 : (std::atoi(force) == 64 ? 2 : 1);
+    if (force_tile) waves = force_tile == 128 ? 4 : (force_tile == 64 ? 2 : 1);
     const int tile_w = waves * 32 / TILE_H;
     p.tiles_r = (p.hp + TILE_H - 1) / TILE_H;
     p.tiles_c = (p.wp + tile_w - 1) / tile_w;
@@ -495,7 +490,7 @@ int launch(ConvGemmParams& p, hipStream_t stream) {
         // between half a wave and one wave per SIMD, a layer with a normalisation keeps whole tiles (conv_2 of four Kodak
         // images, 768 items: 0.223 ms whole, 0.252 as half tiles + the normalisation pass)
     }
-    if (const char* force = std::getenv("EAE_HIP_FORCE_NT")) nt = std::atoi(force) == 1 ? 1 : (std::atoi(force) == 2 ? 2 : 4);
+    if (force_nt) nt = force_nt == 1 ? 1 : (force_nt == 2 ? 2 : 4);
     if (nt != 4 && waves == 1) {
         grid *= 4 / nt;
         if (nt == 2) hipLaunchKernelGGL((conv_gemm_wave_kernel<1, EAE_NORM_NONE, 2>), dim3(grid), dim3(64), 0, stream, p);

@@ -355,9 +355,8 @@ int eae_conv_gemm::launch_split(ConvGemmParams& p, hipStream_t stream, int cut) 
     p.split_spin_limit = SPIN_LIMIT;
     p.split_mute_heads = 0;
     if (split) {
-        // test hook (tests/test_gpu_conv_split.py): heads that never publish, and tails that give up after ~1 ms
-        const char* mute = std::getenv("EAE_HIP_TEST_SPLIT_MUTE");
-        if (mute && mute[0] == '1') { p.split_mute_heads = 1; p.split_spin_limit = 1 << 12; }
+        // test hook (eae_hip_debug_set_split_mute, tests/test_gpu_conv_split.py): heads that never publish, tails that give up after ~1 ms
+        if (g_eae_launch_options.split_mute) { p.split_mute_heads = 1; p.split_spin_limit = 1 << 12; }
     }
     p.split_resident_waves_per_xcd = (cus / 8) * 4 * (int)k;
     // one wave per item, blocks of 4 items, the 8 shares interleaved: the largest share decides the grid

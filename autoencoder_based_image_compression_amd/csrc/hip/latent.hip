@@ -360,11 +360,9 @@ extern "C" int eae_hip_latent_stage(const float* x, const float* gamma_in_packed
     if ((gamma_out_packed == nullptr) != (beta_out == nullptr) || (gamma_out_packed && !t_out)) return EAE_HIP_BAD_ARGUMENT;
     const long rows = (long)n * hw;
     hipStream_t s = (hipStream_t)stream;
-    // EAE_HIP_LATENT = q (four waves per tile, the default) | w (one wave per tile) | l (block-cooperative LDS form); read per
-    // launch: the parity tests run all three. EAE_HIP_LATENT_LDS (round 1) still selects the LDS form.
-    const char* form_env = std::getenv("EAE_HIP_LATENT");
-    char form = form_env && (form_env[0] == 'w' || form_env[0] == 'l' || form_env[0] == 'q') ? form_env[0] : 'q';
-    if (std::getenv("EAE_HIP_LATENT_LDS") != nullptr) form = 'l';
+    // EAE_HIP_LATENT = q (four waves per tile, the default) | w (one wave per tile) | l (block-cooperative LDS form); read when the
+    // library is loaded (misc.hip): the parity tests run all three.
+    char form = g_eae_launch_options.latent;
     if (form == 'q' && hw > (1 << 21)) form = 'w';          // 32-bit symbol offsets inside two images
     if (form != 'l') {
         const unsigned wgrid = (unsigned)((rows + 31) / 32);

@@ -1,7 +1,39 @@
 // misc.hip -- library identity and device probing.
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
+
+// ---- kernel-form overrides: the environment is read here, once per library load (and on a test's explicit request) ----
+static EaeLaunchOptions read_launch_options() {
+    EaeLaunchOptions o{};
+    const char* e = std::getenv("EAE_HIP_GEMM");
+    o.gemm = e && (e[0] == 's' || e[0] == 'u' || e[0] == 'w' || e[0] == 'l') ? e[0] : 0;
+    e = std::getenv("EAE_HIP_SPLIT_WAVES");
+    o.split_waves = e ? std::atoi(e) : 3;
+    if (o.split_waves < 1 || o.split_waves > 3) o.split_waves = 3;
+    e = std::getenv("EAE_HIP_FORCE_TILE");
+    o.force_tile = e ? std::atoi(e) : 0;
+    e = std::getenv("EAE_HIP_FORCE_NT");
+    o.force_nt = e ? std::atoi(e) : 0;
+    e = std::getenv("EAE_HIP_LATENT");
+    o.latent = e && (e[0] == 'w' || e[0] == 'l' || e[0] == 'q') ? e[0] : 'q';
+    if (std::getenv("EAE_HIP_LATENT_LDS") != nullptr) o.latent = 'l';      // round 1's name for the LDS form
+    o.split_mute = 0;                                                      // never from the environment
+    return o;
+}
+EaeLaunchOptions g_eae_launch_options = read_launch_options();
+
+extern "C" int eae_hip_debug_reload_launch_options(void) {
+    const int mute = g_eae_launch_options.split_mute;
+    g_eae_launch_options = read_launch_options();
+    g_eae_launch_options.split_mute = mute;
+    return EAE_HIP_OK;
+}
+extern "C" int eae_hip_debug_set_split_mute(int on) {
+    g_eae_launch_options.split_mute = on ? 1 : 0;
+    return EAE_HIP_OK;
+}
 
 extern "C" const char* eae_hip_version(void) { return "eae_hip 1.0 (gfx950, f32 MFMA, bit-exact vs oracle/transforms_oracle.c)"; }
 

@@ -67,6 +67,9 @@ def parse_args(argv=None):
                         help='(default) replay three captured hipGraphs per step instead of launching kernel by kernel')
     parser.add_argument('--no-graphs', dest='graphs', action='store_false')
     parser.add_argument('--seed-offset', type=int, default=0, help='rank r codes the images of seed 1000 + r + this (tests)')
+    parser.add_argument('--force-nccl', action='store_true',
+                        help='join an RCCL process group even as a single rank, so that the barriers and the one statistics '
+                             'all-reduce of the N-GPU run go through librccl on a one-GPU box (tests/test_bench_launcher.py)')
     parser.add_argument('--dry-launch', action='store_true',
                         help='rendezvous check only (no GPU): every rank joins a gloo group, one all-reduce, rank 0 prints n_gpus')
     args = parser.parse_args(argv)
@@ -77,13 +80,17 @@ def parse_args(argv=None):
     return args
 
 
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with no launcher around it: start N FRESH rank processes (one per GPU; RANK, LOCAL_RANK,
     WORLD_SIZE, MASTER_ADDR, MASTER_PORT in their environment), wait for all of them and return the first non-zero exit
     code. This process has not touched the GPU (torch is not even imported yet) and never does; nothing is re-exec'ed."""
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
+    port = free_port()
     children = []
     for rank in range(args.gpus):
         env = dict(os.environ)
@@ -192,9 +199,12 @@ class Context(object):
 
     def __init__(self, args, device, world, rank, cores):
         (self.args, self.device, self.world, self.rank, self.cores) = (args, device, world, rank, cores)
+        self.grouped = world > 1 or bool(getattr(args, 'force_nccl', False))      # a process group exists
+        self.collectives = 0                                                       # barriers + all-reduces that went through it
 
     def barrier(self):
-        if self.world > 1:
+        if self.grouped:
+            self.collectives += 1
             import torch.distributed as dist
             if dist.get_backend() == 'nccl':
                 dist.barrier(device_ids=[self.device.index])      # RCCL: name the device, no guess from the rank
@@ -203,7 +213,8 @@ class Context(object):
         torch.cuda.synchronize()
 
     def all_reduce(self, tensor, op):
-        if self.world > 1:
+        if self.grouped:
+            self.collectives += 1
             import torch.distributed as dist
             if dist.get_backend() != 'nccl':      # gloo (the shared-GPU test hook) reduces host tensors
                 host = tensor.cpu()
@@ -429,10 +440,15 @@ def main(args):
     elif local_rank >= torch.cuda.device_count():
         raise SystemExit('bench.py: rank {0} has no GPU (this node shows {1}); one process per GPU.'.format(local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_nccl:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='gloo' if share_gpu else 'nccl', rank=rank, world_size=world)
+        if world == 1:
+            os.environ.setdefault('MASTER_PORT', str(free_port()))
+            # what launch_ranks gives its children (the pool's host driver only supports dmabuf IPC); a caller's setting wins
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group(backend='gloo' if share_gpu else 'nccl', rank=rank, world_size=world,
+                                device_id=None if share_gpu else torch.device('cuda', local_rank))
     device = torch.device('cuda', local_rank)
     cores = usable_cpus()
     os.environ.setdefault('OMP_NUM_THREADS', str(cores))      # the oracle's OpenMP transforms (cpu_baseline only)
@@ -472,7 +488,8 @@ def main(args):
     blocks = run['block_seconds']
     roof_ms = roof['elapsed']/min(args.steps, 30)*1e3
     line = {
-        'metric': 'Mpixels/s encode+decode (Kodak 768x512 luma), bitstream bit-exact',
+        'metric': 'Mpixels/s encode+decode ({0} {1}x{2} luma), bitstream bit-exact'.format(
+            'Kodak' if (h_in, w_in) == (512, 768) else 'synthetic', w_in, h_in),
         'value': round(value, 3), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed/args.steps*1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
@@ -509,6 +526,12 @@ def main(args):
                      'algorithmic_flop_per_launch': {k: flops[k]*pixels_per_step for k in GEMM_LAUNCHES},
                      'per_kernel': per_kernel, 'peak_hbm_tbytes_per_s': PEAK_HBM_TBS},
     }
+    if ctx.grouped:
+        import torch.distributed as dist
+        # the collectives of this run (barriers around every timed block, the MAX of the block times, the one statistics
+        # all-reduce) went through this backend; with --force-nccl also as a single rank
+        line['process_group'] = {'backend': dist.get_backend(), 'world_size': world, 'collectives': ctx.collectives,
+                                 'forced_single_rank': bool(world == 1)}
     del run, roof
     side = rank == 0 and world == 1 and not args.no_single_image
     if side and args.batch != 1 and (h_in, w_in) == (512, 768):
@@ -579,7 +602,7 @@ def main(args):
             line['cpu_baseline'] = cpu_baseline(variables, probabilities, map_mean_host, cores, h_in, w_in)
         print(json.dumps(line))
         sys.stdout.flush()
-    if world > 1:
+    if ctx.grouped:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -343,6 +343,17 @@ int eae_hip_dequantize_maps(const int16_t* symbols_planar, const float* bin_widt
  * records s_memtime stamps per wave (start, loop start, loop end, GDN end, end, K-steps, XCC id, HW id). NULL disables. */
 int eae_hip_debug_set_stamp_buffer(uint64_t* device_buffer);
 
+/* Kernel-form overrides (EAE_HIP_GEMM, EAE_HIP_SPLIT_WAVES, EAE_HIP_FORCE_TILE, EAE_HIP_FORCE_NT, EAE_HIP_LATENT: README.md) are
+ * read from the environment ONCE, when the library is loaded -- no launch reads the environment, and a hipGraph captures what
+ * every later launch would have done anyway. The parity tests of every kernel form change the environment inside one process and
+ * then call this to have it read again. Not part of the path. */
+int eae_hip_debug_reload_launch_options(void);
+/* Fault injection for the cut-tile hand-off of the conv launches (tests/test_gpu_conv_split.py, tests/test_gpu_codec.py): with
+ * on != 0 the heads of cut tiles never publish and the tails give up after ~1 ms, so the launch reports the hand-off failure
+ * (eae_hip_conv_workspace_collect, eae_hip_transform_status). Reachable through this entry point only -- no environment variable
+ * can make a deployment drop tiles. */
+int eae_hip_debug_set_split_mute(int on);
+
 /* tls.cast_bt601 (tools.py:61-93) on its own: u8 = uint8(round_half_even(clip(x, 16, 235))). */
 int eae_hip_cast_bt601(const float* x, uint8_t* out, int64_t count, void* stream);
 

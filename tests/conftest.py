@@ -27,3 +27,42 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+class _LaunchOptions(object):
+    """Kernel-form overrides for the parity tests of every form: the library reads EAE_HIP_* once at load (csrc/hip/misc.hip), so a
+    test that changes them inside the process has the library read them again (eae_hip_debug_reload_launch_options); the
+    hand-off fault injection has no environment variable at all (eae_hip_debug_set_split_mute)."""
+    NAMES = ('EAE_HIP_GEMM', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_FORCE_TILE', 'EAE_HIP_FORCE_NT', 'EAE_HIP_LATENT', 'EAE_HIP_LATENT_LDS')
+
+    def __init__(self, monkeypatch):
+        from autoencoder_based_image_compression_amd import _native
+        self._mp = monkeypatch
+        self._lib = _native.hip()
+
+    def setenv(self, name, value):
+        assert name in self.NAMES, name
+        self._mp.setenv(name, value)
+        assert self._lib.eae_hip_debug_reload_launch_options() == 0
+
+    def delenv(self, name, raising=False):
+        assert name in self.NAMES, name
+        self._mp.delenv(name, raising=raising)
+        assert self._lib.eae_hip_debug_reload_launch_options() == 0
+
+    def clear(self):
+        for name in self.NAMES:
+            self._mp.delenv(name, raising=False)
+        assert self._lib.eae_hip_debug_reload_launch_options() == 0
+
+    def split_mute(self, on):
+        assert self._lib.eae_hip_debug_set_split_mute(1 if on else 0) == 0
+
+
+@pytest.fixture
+def launch_options(monkeypatch):
+    options = _LaunchOptions(monkeypatch)
+    options.clear()
+    yield options
+    options.split_mute(False)
+    options.clear()

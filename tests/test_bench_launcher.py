@@ -105,3 +105,22 @@ def test_four_ranks_share_the_gpu_and_the_host_cpu_budget_is_reported():
     assert four['n_gpus'] == 4 and four['totals']['images'] == 4*3*2
     assert len(four['host_cpu_ms_per_step']) == 4 and all(v > 0. for v in four['host_cpu_ms_per_step'])
     assert four['usable_cpus'] >= 1 and 'one_stream_leg' in four and four['roofline']['per_kernel']['conv1_gdn1']['avg_ms'] > 0.
+
+
+@pytest.mark.gpu
+def test_one_rank_through_rccl():
+    """`--force-nccl`: the process group of the N-GPU run (backend 'nccl' = RCCL on ROCm), joined by ONE rank on this box's one GPU:
+    librccl loads, `init_process_group` succeeds with HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment (what `launch_ranks` gives its
+    children), the barriers of the timed blocks (`dist.barrier(device_ids=...)`) and the statistics all-reduce run on the device,
+    and the integer totals equal those of the same run without a process group."""
+    common = ['--gpus', '1', '--steps', '3', '--warmup', '1', '--batch', '4', '--no-cpu-baseline', '--no-single-image', '--min-seconds', '0']
+    (proc, lines) = run_bench(common + ['--force-nccl'])
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert len(lines) == 1
+    grouped = lines[0]
+    assert grouped['process_group']['backend'] == 'nccl' and grouped['process_group']['world_size'] == 1
+    assert grouped['process_group']['collectives'] >= 4          # barriers on both sides of a timed block, MAX of the times, the totals
+    (proc, lines) = run_bench(common)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert 'process_group' not in lines[0]
+    assert grouped['totals'] == lines[0]['totals'] and grouped['n_gpus'] == 1

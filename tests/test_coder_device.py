@@ -3,6 +3,8 @@ host C-ABI coder (itself pinned to the reference's C++ coder by tests/test_coder
 streams produced by the real reference build: bit counts, stream BYTES, decoded symbols, error codes and stages are
 identical."""
 import os
+import re
+import sys
 
 import numpy
 import pytest
@@ -442,3 +444,145 @@ def test_batch_coder_next_to_mfma_kernels(dev, bin_width):
     torch.cuda.synchronize()
     coded = rows_host >= 0
     assert numpy.array_equal(decoded.cpu().numpy()[coded], planar[coded])
+
+
+def host_decode_maps(streams, bac, byp, probs, prob_row, size):
+    """eae_coder_decode_maps on the host over the given bytes: (symbols [n, size], status, stage)."""
+    lib = _native.coder()
+    n = streams.shape[0]
+    out = numpy.zeros((n, size), dtype=numpy.int16)
+    (status, stage) = (numpy.zeros(n, dtype=numpy.int32), numpy.zeros(n, dtype=numpy.int32))
+    pp = numpy.ascontiguousarray(probs, dtype=numpy.float64)
+    rows = numpy.ascontiguousarray(prob_row, dtype=numpy.int32)
+    streams = numpy.ascontiguousarray(streams)
+    (bac, byp) = (numpy.ascontiguousarray(bac, dtype=numpy.uint32), numpy.ascontiguousarray(byp, dtype=numpy.uint32))
+    lib.eae_coder_decode_maps(n, size, _native.ptr(out, _native.c_i16p), probs.shape[1], _native.ptr(pp, _native.c_f64p),
+                              _native.ptr(rows, _native.c_i32p), _native.ptr(streams, _native.c_u8p), streams.shape[1],
+                              _native.ptr(bac, _native.c_u32p), _native.ptr(byp, _native.c_u32p),
+                              _native.ptr(status, _native.c_i32p), _native.ptr(stage, _native.c_i32p), 4)
+    return out, status, stage
+
+
+@pytest.mark.parametrize('scale', [0.5, 3.])
+def test_batch_decoder_on_streams_it_did_not_write_equals_the_host_decoder(gold, dev, scale):
+    """Corrupted, truncated and foreign streams: flipped bits at the head, in the middle and at the end of the
+    arithmetic-coded bytes, bit counts cut short or stretched, streams swapped between maps. A pure decode by the
+    64-maps-per-wavefront kernels must return, map for map, the symbols, status and stage of the host library (which follows the
+    reference's decode_bit, including its "leave the interval alone when the code is outside it" -- which no stream can bring about:
+    coder/lean_step.h: code_inside)."""
+    rng = numpy.random.RandomState(int(scale*100) + 1)
+    probs = gold['real_probabilities_1']
+    n = 2*128
+    size = 384
+    planar = numpy.clip(numpy.round(rng.laplace(size=(n, size))*rng.uniform(0.2, 1., size=(n, 1))*scale), -32768, 32767).astype(numpy.int16)
+    prob_row = (numpy.arange(n) % 128).astype(numpy.int32)
+    prob_row[67::128] = -1
+    (streams, sym, p, rows) = batch_code(dev, planar, probs, prob_row)
+    assert not streams.status.cpu().numpy().any()
+    raw = streams.streams.cpu().numpy().copy()
+    bac = streams.bac_bits.cpu().numpy().astype(numpy.uint32).copy()
+    byp = streams.bypass_bits.cpu().numpy().astype(numpy.uint32).copy()
+    coded = numpy.flatnonzero((prob_row >= 0) & (bac >= 48))
+    kinds = ('head', 'middle', 'end', 'burst', 'short', 'long', 'swap')
+    for (j, m) in enumerate(coded[:14*len(kinds)]):
+        kind = kinds[j % len(kinds)]
+        nbytes = int(bac[m] + 7)//8
+        if kind == 'head':
+            raw[m, rng.randint(0, 2)] ^= 1 << rng.randint(0, 8)
+        elif kind == 'middle':
+            raw[m, nbytes//2] ^= 1 << rng.randint(0, 8)
+        elif kind == 'end':
+            raw[m, nbytes - 1] ^= 1 << rng.randint(0, 8)
+        elif kind == 'burst':
+            raw[m, 2:2 + min(6, nbytes - 2)] = rng.randint(0, 256, size=min(6, nbytes - 2)).astype(numpy.uint8)
+        elif kind == 'short':
+            bac[m] = bac[m]//2
+        elif kind == 'long':
+            bac[m] = bac[m] + 40                 # bytes behind the stream: whatever an earlier encode left there (zeros here)
+        else:
+            other = coded[(j + 5) % coded.size]
+            raw[m, :nbytes + 8] = raw[other, :nbytes + 8]
+    (h_sym, h_status, h_stage) = host_decode_maps(raw, bac, byp, probs, prob_row, size)
+    streams.streams.copy_(torch.from_numpy(raw).cuda())
+    streams.bac_bits.copy_(torch.from_numpy(bac.astype(numpy.int32)).cuda())
+    ws = dev.coder_workspace(n, size, probs.shape[1], 'cuda')
+    out = dev.coder_decode_batch(streams, p, rows, workspace=ws).cpu().numpy()
+    torch.cuda.synchronize()
+    status = streams.status.cpu().numpy()
+    assert numpy.array_equal(status, h_status), numpy.flatnonzero(status != h_status)[:8]
+    assert numpy.array_equal(streams.stage.cpu().numpy()[status != 0], h_stage[status != 0])
+    keep = (prob_row >= 0) & (status == 0)
+    differing = numpy.flatnonzero((out != h_sym).any(axis=1) & keep)
+    assert differing.size == 0, differing[:8]
+    # the streams WERE damaged: most of the touched maps decode to other symbols than the encoder's, a few end in an error
+    touched = coded[:14*len(kinds)]
+    assert ((out[touched] != planar[touched]).any(axis=1) | (status[touched] != 0)).sum() > touched.size//2
+
+
+def _private_library(tmp_path, flags):
+    """libeae_hip.so with coder_simd.hip rebuilt with extra flags (never the shipped library): the other objects are the build's."""
+    import glob
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, 'autoencoder_based_image_compression_amd', 'csrc')
+    objects = [o for o in glob.glob(os.path.join(root, 'build', 'hip', '*.o')) if not o.endswith('/coder_simd.o')]
+    hipcc = '/opt/rocm/bin/hipcc'
+    if not os.path.isfile(hipcc) or len(objects) < 10:
+        pytest.skip('needs hipcc and the objects of the build (build/hip/*.o)')
+    obj = str(tmp_path / 'coder_simd.o')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt',
+                    '-fno-fast-math', '-I' + os.path.join(root, 'include'), '-I' + os.path.join(csrc, 'hip')] + flags +
+                   ['-c', '-o', obj, os.path.join(csrc, 'hip', 'coder_simd.hip')], check=True)
+    lib = str(tmp_path / 'libeae_hip.so')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objects + [obj], check=True)
+    return lib
+
+
+def test_the_guard_test_is_red_on_the_first_decoder_core(tmp_path):
+    """Sensitivity of `test_batch_coder_next_to_mfma_kernels`, re-demonstrated on whatever toolchain builds this tree: round 3's first
+    decoder core (-DEAE_DECODE_TOPUP_ZEROS: 40 of 40 VGPRs, its 64-bit window shift fed from v39, the last register of the
+    allocation -- csrc/isa_guard.py rule 2) in a PRIVATE library, at the priority of its neighbours, must fail
+    that test at every rate; and the ISA guard must name the instruction. If the compiler ever stops producing the pattern from
+    this source, the guard stays the judge: the test then only checks that guard and run agree."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'autoencoder_based_image_compression_amd', 'csrc'))
+    import isa_guard
+    lib = _private_library(tmp_path, ['-DEAE_DECODE_TOPUP_ZEROS', '-DEAE_SIMD_PRIO=0'])
+    findings = isa_guard.check([lib])
+    env = dict(os.environ, EAE_HIP_LIB=lib)
+    run = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-k', 'test_batch_coder_next_to_mfma_kernels',
+                          '-p', 'no:cacheprovider'], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
+    if findings:
+        assert all('bac_decode_core_kernel' in f and 'rule 2' in f for f in findings), findings
+        assert run.returncode != 0 and 'test_batch_coder_next_to_mfma_kernels' in run.stdout, run.stdout[-2000:]
+    else:
+        assert run.returncode == 0, run.stdout[-2000:]
+
+
+def test_the_64_bit_shift_hazard_itself(tmp_path):
+    """The fault in its minimal form (scratch/r04/probe_shift64.hip, generated by gen_probe_shift.py): `v_lshlrev_b64 v[18:19], vK,
+    v[16:17]` in a wave whose allocation is N registers, against the same shift done with 32-bit instructions. Asserted: alone on the
+    GPU every result is right for every (N, K); next to other waves every result is right when K + 1 < N. Reported, not asserted
+    (a later firmware may cure it, and then rule 2 of the guard can go): the wrong results with K = N - 1 next to other waves."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    source = os.path.join(root, 'scratch', 'r04', 'probe_shift64.hip')
+    hipcc = '/opt/rocm/bin/hipcc'
+    if not os.path.isfile(hipcc) or not os.path.isfile(source):
+        pytest.skip('needs hipcc and scratch/r04/probe_shift64.hip')
+    exe = str(tmp_path / 'probe_shift64')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O2', '-o', exe, source], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = subprocess.run([exe, '48', '20000', '2'], check=True, stdout=subprocess.PIPE, universal_newlines=True, timeout=600).stdout
+    rows = re.findall(r'^(alone|VALU neighbours|MFMA neighbours)\s+N = +(\d+), K = +(\d+).*?wrong results (\d+) of', out, flags=re.M)
+    assert len(rows) == 27, out
+    hazard = 0
+    for (where, n, k, wrong) in rows:
+        (n, k, wrong) = (int(n), int(k), int(wrong))
+        if where == 'alone' or k + 1 < n:
+            assert wrong == 0, (where, n, k, wrong)
+        else:
+            hazard += wrong
+    print('64-bit shifts fed from the last register of the allocation, next to other waves: {0} wrong results'.format(hazard))
+    if hazard == 0:
+        pytest.skip('the hazard did not reproduce on this box: rule 2 of csrc/isa_guard.py may have become unnecessary')

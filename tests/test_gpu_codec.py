@@ -251,14 +251,13 @@ def test_fused_latent_stage_gives_the_same_results(learned, shape):
     assert numpy.array_equal(results[0][1], results[1][1])
 
 
-def test_a_failed_hand_off_raises_from_the_ticket_and_the_next_batches_are_right(monkeypatch):
-    """The cut-tile hand-off of the conv launches forced to fail (csrc/hip/conv_gemm_split.hip, EAE_HIP_TEST_SPLIT_MUTE):
+def test_a_failed_hand_off_raises_from_the_ticket_and_the_next_batches_are_right(launch_options):
+    """The cut-tile hand-off of the conv launches forced to fail (csrc/hip/conv_gemm_split.hip, eae_hip_debug_set_split_mute):
     `Ticket.result()` raises for exactly those batches; with the hook off again the same codec -- every slot, hence every
     workspace, used once more -- returns what a fresh codec returns."""
     from autoencoder_based_image_compression_amd import codec, device as dev
     from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
-    for name in ('EAE_HIP_GEMM', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_TEST_SPLIT_MUTE'):
-        monkeypatch.delenv(name, raising=False)
+    launch_options.clear()
     with numpy.load(GOLD) as g:
         probabilities = g['real_probabilities_1']
     v = var.random_variables(1., False, seed=8, bias_std=0.01)
@@ -267,17 +266,17 @@ def test_a_failed_hand_off_raises_from_the_ticket_and_the_next_batches_are_right
     ones = numpy.ones(128, dtype=numpy.float32)
     with codec.BatchCodec(v, False, ones, 0*ones, probabilities, 67, 3, 64, 96) as fresh:
         expected = fresh.submit(images).result()
-    monkeypatch.setenv('EAE_HIP_GEMM', 's')                  # cut every conv launch, small as they are
+    launch_options.setenv('EAE_HIP_GEMM', 's')                  # cut every conv launch, small as they are
     with codec.BatchCodec(v, False, ones, 0*ones, probabilities, 67, 3, 64, 96) as c:
         first = c.submit(images).result()
         for key in expected:
             assert numpy.array_equal(first[key], expected[key]), key
-        monkeypatch.setenv('EAE_HIP_TEST_SPLIT_MUTE', '1')
+        launch_options.split_mute(True)
         failed = [c.submit(images) for _ in range(2)]
         for ticket in failed:
             with pytest.raises(dev.SplitHandOffTimeout):
                 ticket.result()
-        monkeypatch.delenv('EAE_HIP_TEST_SPLIT_MUTE')
+        launch_options.split_mute(False)
         for _ in range(c.nb_slots + 1):
             r = c.submit(images).result()
             for key in expected:

@@ -9,7 +9,6 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-ENV = ('EAE_HIP_GEMM', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_FORCE_TILE', 'EAE_HIP_FORCE_NT', 'EAE_HIP_TEST_SPLIT_MUTE')
 
 
 def _vars(seed):
@@ -21,25 +20,23 @@ def _workspace_is_clean(ws):
     return int(torch.count_nonzero(ws).item()) == 0
 
 
-def _forms(monkeypatch, call, ws, reference):
+def _forms(launch_options, call, ws, reference):
     """The same launch in every other form: bits equal `reference`, workspace left zeroed."""
     for (form, waves) in (('u', None), ('w', None), ('s', '1'), ('s', '2'), ('s', '3')):
-        monkeypatch.setenv('EAE_HIP_GEMM', form)
+        launch_options.setenv('EAE_HIP_GEMM', form)
         if waves:
-            monkeypatch.setenv('EAE_HIP_SPLIT_WAVES', waves)
+            launch_options.setenv('EAE_HIP_SPLIT_WAVES', waves)
         assert torch.equal(call(ws), reference), (form, waves)
         assert _workspace_is_clean(ws)
-    for name in ENV:
-        monkeypatch.delenv(name, raising=False)
+    launch_options.clear()
 
 
 @pytest.mark.parametrize('norm', [0, 1])
-def test_conv_against_the_oracle(norm, monkeypatch):
+def test_conv_against_the_oracle(norm, launch_options):
     """6 x 128x192 inputs = 1152 tiles of 32 positions on 1024 SIMDs: the launch cuts its last tiles by itself."""
     from autoencoder_based_image_compression_amd import device as dev
     from oracle import transforms as orc
-    for name in ENV:
-        monkeypatch.delenv(name, raising=False)
+    launch_options.clear()
     v = _vars(31)
     x = numpy.random.RandomState(32).standard_normal(size=(6, 128, 192, 128)).astype(numpy.float32)
     ref = orc.conv2d_same(x, v['encoder/weights_2'], 2, v['encoder/biases_2'])
@@ -53,16 +50,15 @@ def test_conv_against_the_oracle(norm, monkeypatch):
     assert numpy.array_equal(got.cpu().numpy(), ref)
     assert _workspace_is_clean(ws)
     assert torch.equal(dev.conv5x5s2(*args, workspace=False), got)          # no workspace: whole tiles
-    _forms(monkeypatch, lambda w: dev.conv5x5s2(*args, workspace=w), ws, got)
+    _forms(launch_options, lambda w: dev.conv5x5s2(*args, workspace=w), ws, got)
 
 
 @pytest.mark.parametrize('norm', [0, 2])
-def test_tconv_against_the_oracle(norm, monkeypatch):
+def test_tconv_against_the_oracle(norm, launch_options):
     """3 x 48x72 sites x 4 output phases = 1296 tiles of four lengths (36 / 24 / 24 / 16 K-steps)."""
     from autoencoder_based_image_compression_amd import device as dev
     from oracle import transforms as orc
-    for name in ENV:
-        monkeypatch.delenv(name, raising=False)
+    launch_options.clear()
     v = _vars(33)
     x = numpy.random.RandomState(34).standard_normal(size=(3, 48, 72, 128)).astype(numpy.float32)
     ref = orc.conv2d_transpose_same(x, v['decoder/weights_4'], 2, v['decoder/biases_4'])
@@ -76,16 +72,15 @@ def test_tconv_against_the_oracle(norm, monkeypatch):
     assert numpy.array_equal(got.cpu().numpy(), ref)
     assert _workspace_is_clean(ws)
     assert torch.equal(dev.tconv5x5s2(*args, workspace=False), got)
-    _forms(monkeypatch, lambda w: dev.tconv5x5s2(*args, workspace=w), ws, got)
+    _forms(launch_options, lambda w: dev.tconv5x5s2(*args, workspace=w), ws, got)
 
 
-def test_kodak_batch_layers_in_every_form(monkeypatch):
+def test_kodak_batch_layers_in_every_form(launch_options):
     """The four launches of the benchmark's step (24 x 512x768), GPU against GPU: ragged shares (4608 tiles / 8 XCDs), one
     workspace reused by all four launches, then the same again on two streams at once with a workspace each."""
     import bench
     from autoencoder_based_image_compression_amd import device as dev, pipeline
-    for name in ENV:
-        monkeypatch.delenv(name, raising=False)
+    launch_options.clear()
     variables = bench.synthetic_model(1.)
     enc = pipeline.DeviceEncoder(variables, False)
     dec = pipeline.DeviceDecoder(variables, False)
@@ -100,19 +95,19 @@ def test_kodak_batch_layers_in_every_form(monkeypatch):
         t2 = dev.tconv5x5s2(t1, dec.w5, d['decoder/biases_5'], dev.NORM_IGDN, dec.g[6], d['decoder/beta_6'], workspace=workspace)
         return (gdn_2, conv_3, t1, t2)
 
-    monkeypatch.setenv('EAE_HIP_GEMM', 'w')
+    launch_options.setenv('EAE_HIP_GEMM', 'w')
     plain = chain(False)                         # conv_gemm_wave_kernel, pinned to the oracle at this size by test_gpu_full_size
-    monkeypatch.delenv('EAE_HIP_GEMM')
+    launch_options.delenv('EAE_HIP_GEMM')
     ws = dev.conv_workspace('cuda')
     for _ in range(3):
         for (a, b) in zip(plain, chain(ws)):
             assert torch.equal(a, b)
         assert _workspace_is_clean(ws)
-    monkeypatch.setenv('EAE_HIP_GEMM', 's')      # every layer cut, the transposed convolutions too
+    launch_options.setenv('EAE_HIP_GEMM', 's')      # every layer cut, the transposed convolutions too
     for (a, b) in zip(plain, chain(ws)):
         assert torch.equal(a, b)
     assert _workspace_is_clean(ws)
-    monkeypatch.delenv('EAE_HIP_GEMM')
+    launch_options.delenv('EAE_HIP_GEMM')
     # two chains at once: their waves compete for the SIMDs, every tile is still one uninterrupted-equivalent chain
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     spaces = [dev.conv_workspace('cuda') for _ in streams]
@@ -128,7 +123,7 @@ def test_kodak_batch_layers_in_every_form(monkeypatch):
     assert all(_workspace_is_clean(space) for space in spaces)
 
 
-def test_workspace_entry_points_check_their_arguments(monkeypatch):
+def test_workspace_entry_points_check_their_arguments(launch_options):
     from autoencoder_based_image_compression_amd import _native
     lib = _native.hip()
     assert int(lib.eae_hip_conv_workspace_bytes()) >= 4*(256 + 8*128)
@@ -140,7 +135,7 @@ def test_workspace_entry_points_check_their_arguments(monkeypatch):
     ws = torch.zeros(int(lib.eae_hip_conv_workspace_bytes())//4, dtype=torch.int32, device='cuda')
     assert lib.eae_hip_conv5x5s2_ws(x.data_ptr(), w.data_ptr(), None, 1, None, None, out.data_ptr(), 1, 4, 4, ws.data_ptr(), None) == -1
     assert lib.eae_hip_conv5x5s2_ws(x.data_ptr(), w.data_ptr(), None, 0, None, None, out.data_ptr(), 1, 3, 4, ws.data_ptr(), None) == -2
-    monkeypatch.setenv('EAE_HIP_GEMM', 's')      # a forced cut needs the workspace
+    launch_options.setenv('EAE_HIP_GEMM', 's')      # a forced cut needs the workspace
     assert lib.eae_hip_conv5x5s2(x.data_ptr(), w.data_ptr(), None, 0, None, None, out.data_ptr(), 1, 4, 4, None) == -1
 
 
@@ -151,14 +146,13 @@ def _collect(dev, ws):
 
 
 @pytest.mark.parametrize('forced', [False, True])
-def test_a_hand_off_that_never_happens_is_loud_and_leaves_no_trace(forced, monkeypatch):
-    """EAE_HIP_TEST_SPLIT_MUTE=1 (build-independent test hook, read per launch): the heads of the cut tiles park their
+def test_a_hand_off_that_never_happens_is_loud_and_leaves_no_trace(forced, launch_options):
+    """eae_hip_debug_set_split_mute(1) (fault injection, a debug entry point: no environment variable reaches it): the heads of the cut tiles park their
     accumulators but never publish. Every tail must give up (after ~1 ms with the hook), write NOTHING into its tile, and be
     counted in the workspace's error word; eae_hip_conv_workspace_collect hands the count over and zeroes the workspace, so
     that the next launch -- hook off -- gives the oracle's bits with the same workspace."""
     from autoencoder_based_image_compression_amd import device as dev
-    for name in ENV:
-        monkeypatch.delenv(name, raising=False)
+    launch_options.clear()
     v = _vars(41)
     x = torch.from_numpy(numpy.random.RandomState(42).standard_normal(size=(6, 128, 192, 128)).astype(numpy.float32)).cuda()
     args = (x, dev.pack_conv_weights(torch.from_numpy(v['encoder/weights_2']).cuda()), torch.from_numpy(v['encoder/biases_2']).cuda(),
@@ -166,8 +160,8 @@ def test_a_hand_off_that_never_happens_is_loud_and_leaves_no_trace(forced, monke
     good = dev.conv5x5s2(*args, workspace=False)
     ws = dev.conv_workspace('cuda')
     if forced:
-        monkeypatch.setenv('EAE_HIP_GEMM', 's')      # every XCD share cut as deep as it goes
-    monkeypatch.setenv('EAE_HIP_TEST_SPLIT_MUTE', '1')
+        launch_options.setenv('EAE_HIP_GEMM', 's')      # every XCD share cut as deep as it goes
+    launch_options.split_mute(True)
     sentinel = torch.full_like(good, 12345.0)
     out = dev.conv5x5s2(*args, out=sentinel.clone(), workspace=ws)
     torch.cuda.synchronize()
@@ -178,26 +172,25 @@ def test_a_hand_off_that_never_happens_is_loud_and_leaves_no_trace(forced, monke
     # least `unfinished` tiles of 32 positions differ, and no abandoned tile carries a finished result
     differs = (out != good).any(dim=-1)
     assert int(differs.sum().item()) > 0
-    monkeypatch.delenv('EAE_HIP_TEST_SPLIT_MUTE')
+    launch_options.split_mute(False)
     again = dev.conv5x5s2(*args, workspace=ws)       # the same workspace, no memset by the caller
     assert torch.equal(again, good)
     assert _collect(dev, ws) == 0 and _workspace_is_clean(ws)
 
 
-def test_the_whole_path_entry_points_report_the_failure(monkeypatch):
+def test_the_whole_path_entry_points_report_the_failure(launch_options):
     """eae_hip_encode with the hook on: eae_hip_transform_status (C ABI) and device.Model.check() (what the reference-shaped
     `sess.run` nodes call after their copy to the host) both report it; the next call on the same model is clean."""
     import ctypes
     from autoencoder_based_image_compression_amd import _native, device as dev, pipeline
-    for name in ENV:
-        monkeypatch.delenv(name, raising=False)
+    launch_options.clear()
     v = _vars(43)
     images = torch.from_numpy(numpy.random.RandomState(44).randint(16, 236, size=(2, 128, 192)).astype(numpy.uint8)).cuda()
     enc = pipeline.DeviceEncoder(v, False)
     good = enc(images)
     enc.check()
-    monkeypatch.setenv('EAE_HIP_GEMM', 's')
-    monkeypatch.setenv('EAE_HIP_TEST_SPLIT_MUTE', '1')
+    launch_options.setenv('EAE_HIP_GEMM', 's')
+    launch_options.split_mute(True)
     enc(images)
     with pytest.raises(dev.SplitHandOffTimeout):
         enc.check()
@@ -209,7 +202,7 @@ def test_the_whole_path_entry_points_report_the_failure(monkeypatch):
     assert lib.eae_hip_encode(enc.model._handle, images.data_ptr(), 2, 128, 192, latents.data_ptr(), scratch.data_ptr(), nbytes, None) == 0
     count = ctypes.c_uint32(0)
     assert lib.eae_hip_transform_status(scratch.data_ptr(), ctypes.byref(count), None) == 0 and count.value > 0
-    monkeypatch.delenv('EAE_HIP_TEST_SPLIT_MUTE')
+    launch_options.split_mute(False)
     assert lib.eae_hip_encode(enc.model._handle, images.data_ptr(), 2, 128, 192, latents.data_ptr(), scratch.data_ptr(), nbytes, None) == 0
     assert lib.eae_hip_transform_status(scratch.data_ptr(), ctypes.byref(count), None) == 0 and count.value == 0
     assert torch.equal(latents, good)

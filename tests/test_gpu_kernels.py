@@ -58,25 +58,24 @@ def test_conv1_gdn1(T, dev, orc, shape, with_gdn):
     assert numpy.array_equal(got, ref)
 
 
-def _select_form(monkeypatch, form, tile):
+def _select_form(launch_options, form, tile):
     """Every form of the conv GEMM must give the same bits (EAE_HIP_GEMM, csrc/hip/conv_gemm.hip: launch):
     'wave' = conv_gemm_wave_kernel, one tile per wave (32 / 64 / 128-position blocks); 'nt1' / 'nt2' = the same with a
     wave's output channels spread over 4 / 2 blocks (small layers); 'lds' = the block-cooperative LDS form (64- or
     128-position blocks); 'whole' = conv_gemm_split_kernel with whole tiles; 'cut1..3' = conv_gemm_split_kernel with the cut
     forced onto these small shapes (every tile is then cut in two and the tails wait for their heads)."""
-    for name in ('EAE_HIP_GEMM', 'EAE_HIP_FORCE_NT', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_FORCE_TILE'):
-        monkeypatch.delenv(name, raising=False)
+    launch_options.clear()
     if form.startswith('cut'):
-        monkeypatch.setenv('EAE_HIP_GEMM', 's')
-        monkeypatch.setenv('EAE_HIP_SPLIT_WAVES', form[3:])
+        launch_options.setenv('EAE_HIP_GEMM', 's')
+        launch_options.setenv('EAE_HIP_SPLIT_WAVES', form[3:])
         return
     if form == 'whole':
-        monkeypatch.setenv('EAE_HIP_GEMM', 'u')
+        launch_options.setenv('EAE_HIP_GEMM', 'u')
         return
-    monkeypatch.setenv('EAE_HIP_GEMM', 'l' if form == 'lds' else 'w')
-    monkeypatch.setenv('EAE_HIP_FORCE_TILE', tile)
+    launch_options.setenv('EAE_HIP_GEMM', 'l' if form == 'lds' else 'w')
+    launch_options.setenv('EAE_HIP_FORCE_TILE', tile)
     if form.startswith('nt'):
-        monkeypatch.setenv('EAE_HIP_FORCE_NT', form[2:])
+        launch_options.setenv('EAE_HIP_FORCE_NT', form[2:])
 
 
 def _assert_handed_over(T, dev, ws):
@@ -113,8 +112,8 @@ def test_conv1_reads_words(T, dev, orc):
 @pytest.mark.parametrize('form,tile', FORMS)
 @pytest.mark.parametrize('shape', [(2, 16, 24), (1, 32, 64), (1, 6, 10), (2, 2, 2), (1, 20, 36)])
 @pytest.mark.parametrize('norm', [0, 1])
-def test_conv5x5s2(T, dev, orc, shape, norm, form, tile, monkeypatch):
-    _select_form(monkeypatch, form, tile)
+def test_conv5x5s2(T, dev, orc, shape, norm, form, tile, launch_options):
+    _select_form(launch_options, form, tile)
     v = _vars(3)
     rng = numpy.random.RandomState(4)
     x = rng.standard_normal(size=shape + (128,)).astype(numpy.float32)
@@ -136,8 +135,8 @@ def test_conv5x5s2(T, dev, orc, shape, norm, form, tile, monkeypatch):
 @pytest.mark.parametrize('form,tile', FORMS)
 @pytest.mark.parametrize('shape', [(2, 8, 12), (1, 16, 32), (1, 3, 5), (2, 1, 1), (1, 10, 18)])
 @pytest.mark.parametrize('norm', [0, 2])
-def test_tconv5x5s2(T, dev, orc, shape, norm, form, tile, monkeypatch):
-    _select_form(monkeypatch, form, tile)
+def test_tconv5x5s2(T, dev, orc, shape, norm, form, tile, launch_options):
+    _select_form(launch_options, form, tile)
     v = _vars(5)
     rng = numpy.random.RandomState(6)
     x = rng.standard_normal(size=shape + (128,)).astype(numpy.float32)

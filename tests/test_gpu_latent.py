@@ -10,12 +10,12 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(2, 32, 48), (3, 5, 7), (1, 1, 1), (5, 16, 16), (40, 1, 2)])
 @pytest.mark.parametrize('learned', [False, True])
 @pytest.mark.parametrize('form', ['quarter', 'wave', 'lds'])
-def test_latent_stage_equals_the_separate_kernels(shape, learned, form, monkeypatch):
+def test_latent_stage_equals_the_separate_kernels(shape, learned, form, launch_options):
     """form (EAE_HIP_LATENT, csrc/hip/latent.hip): four waves per 32-position tile, one 32-channel tile each (the default);
     one register-resident wave per tile; the block-cooperative LDS kernel. (3, 5, 7): tiles that straddle images."""
     from autoencoder_based_image_compression_amd import device as dev
-    monkeypatch.delenv('EAE_HIP_LATENT_LDS', raising=False)
-    monkeypatch.setenv('EAE_HIP_LATENT', form[0])
+    launch_options.delenv('EAE_HIP_LATENT_LDS', raising=False)
+    launch_options.setenv('EAE_HIP_LATENT', form[0])
     rng = numpy.random.RandomState(shape[1]*7 + int(learned))
     (n, h, w) = shape
     x = torch.from_numpy((rng.laplace(size=(n, h, w, 128))*rng.uniform(0.1, 6., size=128)).astype(numpy.float32)).cuda()
@@ -62,14 +62,13 @@ def test_latent_stage_argument_checks():
 @pytest.mark.parametrize('learned', [False, True])
 @pytest.mark.parametrize('shape,form', [((2, 16, 24), ''), ((1, 6, 10), ''), ((2, 16, 24), 'u'), ((2, 16, 24), 's'), ((1, 6, 10), 's'),
                                         ((6, 128, 192), ''), ((6, 128, 192), 'u'), ((24, 64, 96), '')])
-def test_conv3_with_the_latent_stage_as_its_epilogue(shape, form, learned, monkeypatch):
+def test_conv3_with_the_latent_stage_as_its_epilogue(shape, form, learned, launch_options):
     """eae_hip_conv5x5s2_latent == eae_hip_conv5x5s2 (no normalisation) followed by eae_hip_latent_stage, every output, bit for
     bit: small layers (two launches inside the entry point), the fused kernel with whole tiles ('u'), with every tile cut
     ('s') and as the launch decides ('' : 6 x 128x192 = 1152 tiles is cut, 24 x 64x96 = Kodak batch)."""
     from autoencoder_based_image_compression_amd import device as dev
     from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
-    for name in ('EAE_HIP_GEMM', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_FORCE_TILE', 'EAE_HIP_FORCE_NT', 'EAE_HIP_LATENT_LDS', 'EAE_HIP_LATENT'):
-        monkeypatch.delenv(name, raising=False)
+    launch_options.clear()
     v = var.random_variables(1., learned, seed=61, bias_std=0.01)
     rng = numpy.random.RandomState(62 + shape[1])
     x = torch.from_numpy(rng.standard_normal(size=shape + (128,)).astype(numpy.float32)).cuda()
@@ -82,23 +81,23 @@ def test_conv3_with_the_latent_stage_as_its_epilogue(shape, form, learned, monke
         gdn_in = (dev.pack_gamma(torch.from_numpy(v['encoder/gamma_3']).cuda()), torch.from_numpy(v['encoder/beta_3']).cuda())
         igdn_out = (dev.pack_gamma(torch.from_numpy(v['decoder/gamma_4']).cuda()), torch.from_numpy(v['decoder/beta_4']).cuda())
     # the two separate launches (the convolution in its one-tile-per-wave form)
-    monkeypatch.setenv('EAE_HIP_GEMM', 'w')
+    launch_options.setenv('EAE_HIP_GEMM', 'w')
     raw = dev.conv5x5s2(x, w3, b3, dev.NORM_NONE, workspace=False)
-    monkeypatch.delenv('EAE_HIP_GEMM')
+    launch_options.delenv('EAE_HIP_GEMM')
     ref = dev.latent_stage(raw, bw, mean, gdn_in=gdn_in, igdn_out=igdn_out, want_y=True, want_shifted=True, want_flags=True)
     if form:
-        monkeypatch.setenv('EAE_HIP_GEMM', form)
+        launch_options.setenv('EAE_HIP_GEMM', form)
     ws = dev.conv_workspace('cuda')
     # small layers run the stage IN PLACE on the convolution's output inside the entry point: every form of the stage kernel
     # ('' = four waves per tile, 'w' = one wave per tile, 'l' = block-cooperative LDS form) must cope with x == its output
     for stage_form in ('', 'w', 'l') if shape[1] <= 16 else ('',):
         if stage_form:
-            monkeypatch.setenv('EAE_HIP_LATENT', stage_form)
+            launch_options.setenv('EAE_HIP_LATENT', stage_form)
         for _ in range(2):
             got = dev.conv5x5s2_latent(x, w3, b3, bw, mean, gdn_in=gdn_in, igdn_out=igdn_out, want_y=True, want_shifted=True,
                                        want_flags=True, workspace=ws)
             for key in ('y', 'shifted', 'symbols', 'nonzero_flags', 'checks') + (() if learned else ('t',)):
                 assert torch.equal(got[key].reshape(ref[key].shape), ref[key]), (key, stage_form)
             assert int(torch.count_nonzero(ws).item()) == 0
-        monkeypatch.delenv('EAE_HIP_LATENT', raising=False)
+        launch_options.delenv('EAE_HIP_LATENT', raising=False)
     assert int(ref['symbols'].abs().max().item()) > 2            # the quantiser is exercised, not a field of zeros

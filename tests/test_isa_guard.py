@@ -60,3 +60,79 @@ def test_the_shipped_library_is_clean():
     # the scan sees the stores it is about: the cut tiles' parked accumulators ARE 16-byte stores with a register soffset
     text = ''.join(isa_guard.disassemble(b) for b in blobs)
     assert 'buffer_store_dwordx4' in text
+
+
+# ---- rule 2: a 64-bit shift whose shift amount is the LAST register of the wave's VGPR allocation (round 4)
+SHIFT_BAD = """
+_Z6kernelv:
+	v_min_u32_e32 v39, v38, v19
+	v_lshlrev_b64 v[12:13], v39, v[12:13]
+	v_lshrrev_b64 v[14:15], v39, v[14:15]
+	v_ashrrev_i64 v[16:17], v39, v[14:15]
+	s_endpgm
+	.amdhsa_kernel _Z6kernelv
+		.amdhsa_next_free_vgpr 40
+		.amdhsa_accum_offset 40
+	.end_amdhsa_kernel
+"""
+SHIFT_FINE = """
+_Z6kernelv:
+	v_lshlrev_b64 v[12:13], v38, v[12:13]
+	v_lshlrev_b64 v[38:39], v35, v[8:9]
+	v_lshlrev_b64 v[12:13], 3, v[38:39]
+	v_lshlrev_b32_e32 v12, v39, v12
+	v_mul_f64 v[14:15], v[14:15], v[38:39]
+	s_endpgm
+_Z7kernel2v:
+	v_lshlrev_b64 v[12:13], v39, v[12:13]
+	s_endpgm
+	.amdhsa_kernel _Z6kernelv
+		.amdhsa_next_free_vgpr 40
+	.end_amdhsa_kernel
+	.amdhsa_kernel _Z7kernel2v
+		.amdhsa_next_free_vgpr 42
+	.end_amdhsa_kernel
+"""
+
+
+def test_a_64_bit_shift_fed_from_the_last_register_of_the_allocation_is_found():
+    import isa_guard
+    found = isa_guard.scan(SHIFT_BAD, 'bad')
+    assert len(found) == 3 and all('rule 2' in f and 'v39' in f for f in found)
+    # the data pair may end at the last register, a 32-bit shift may use it, and v39 is harmless in an allocation of 48
+    assert isa_guard.scan(SHIFT_FINE, 'fine') == []
+
+
+def test_allocations_from_the_shipped_metadata():
+    import isa_guard
+    lib = os.path.join(ROOT, 'autoencoder_based_image_compression_amd', 'lib', 'libeae_hip.so')
+    if not os.path.isfile(lib):
+        pytest.skip('libeae_hip.so not built')
+    alloc = {}
+    for blob in isa_guard.code_objects(lib):
+        alloc.update(isa_guard.allocations(blob))
+    decode = [v for (k, v) in alloc.items() if 'bac_decode_core_kernel' in k]
+    assert decode == [64]                         # 46 registers + the reserved v63 (EAE_KEEP_LAST_VGPR_FREE, coder_simd.hip)
+    assert all(v % 8 == 0 and 8 <= v <= 512 for v in alloc.values()) and len(alloc) > 50
+    assert not any('latent_wave_kernelILb1ELb1' in k for k in alloc)       # kernels with AccVGPRs are left out: their top registers are accumulators
+
+
+def test_the_first_decoder_core_is_rejected():
+    """Round 3's first form of the decoder core (-DEAE_DECODE_TOPUP_ZEROS, kept buildable) used 40 of 40 registers and shifted its
+    stream window by v39: the guard must reject exactly that build, and pass the shipped form of the same file."""
+    import subprocess
+    import tempfile
+    import isa_guard
+    hipcc = '/opt/rocm/bin/hipcc'
+    if not os.path.isfile(hipcc):
+        pytest.skip('no hipcc')
+    csrc = os.path.join(ROOT, 'autoencoder_based_image_compression_amd', 'csrc')
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt', '-fno-fast-math',
+             '-I' + os.path.join(ROOT, 'include'), '-I' + os.path.join(csrc, 'hip'), '--cuda-device-only', '-S']
+    with tempfile.TemporaryDirectory() as tmp:
+        for (extra, expected) in ((['-DEAE_DECODE_TOPUP_ZEROS'], 8), ([], 0)):
+            out = os.path.join(tmp, 'coder_simd.s')
+            subprocess.run([hipcc] + flags + extra + ['-o', out, os.path.join(csrc, 'hip', 'coder_simd.hip')], check=True)
+            found = isa_guard.check([out])
+            assert len(found) == expected, found
+            assert all('bac_decode_core_kernel' in f and 'v_lshlrev_b64 v[12:13], v39, v[12:13]' in f for f in found)

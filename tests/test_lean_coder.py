@@ -168,3 +168,49 @@ def test_the_e3_closed_form_in_the_top_aligned_representation():
         high = int(rng.randint(low, 0x10000))
         assert closed(low, high) == loop(low, high), (low, high)
     assert count > 10**6
+
+
+def test_damaged_streams_decode_like_the_host_decoder_and_the_code_never_leaves_its_interval(sim):
+    """the reference's decode_bit leaves interval and decision alone when the code register is outside [low, high]
+    (BinaryArithmeticCoder.cpp:254-273); the lean step always narrows. They can only differ if the code register ever IS outside --
+    and it cannot be, whatever the stream holds (csrc/coder/lean_step.h: code_inside). Checked here on damaged streams (flipped
+    bits, random bytes, bit counts cut short): the model tests the invariant on every step (-100 if it broke) and its prefixes
+    equal those of the symbols the host decoder returns for the same bytes."""
+    from autoencoder_based_image_compression_amd import _native
+    lib = _native.coder()
+    rng = numpy.random.RandomState(11)
+    with numpy.load(GOLD) as g:
+        probabilities = numpy.ascontiguousarray(g['real_probabilities_1'][3], dtype=numpy.float64)
+    L = probabilities.size
+    (decoded_alike, differed_from_the_encoder) = (0, 0)
+    for case in range(400):
+        size = int(rng.randint(32, 400))
+        symbols = numpy.clip(numpy.round(rng.laplace(size=size)*rng.uniform(0.3, 4.)), -300, 300).astype(numpy.int16)
+        cap = size*max(32, L)//8 + 32
+        (bac, byp) = (numpy.zeros(cap, dtype=numpy.uint8), numpy.zeros(cap, dtype=numpy.uint8))
+        (bac_bits, byp_bits, stage) = (ctypes.c_uint32(0), ctypes.c_uint32(0), ctypes.c_int(0))
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        assert lib.eae_coder_encode(size, symbols.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)), L, probabilities.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                    bac.ctypes.data_as(u8p), ctypes.byref(bac_bits), byp.ctypes.data_as(u8p), ctypes.byref(byp_bits), ctypes.byref(stage)) == 0
+        nbytes = (bac_bits.value + 7)//8
+        kind = case % 4
+        if kind == 0:
+            bac[rng.randint(0, min(3, nbytes))] ^= 1 << rng.randint(0, 8)
+        elif kind == 1:
+            bac[rng.randint(0, nbytes)] ^= 1 << rng.randint(0, 8)
+        elif kind == 2:
+            bac[:min(nbytes, 8)] = rng.randint(0, 256, size=min(nbytes, 8)).astype(numpy.uint8)
+        else:
+            bac_bits = ctypes.c_uint32(bac_bits.value//2)
+        prefixes = numpy.zeros(size, dtype=numpy.uint8)
+        rc = sim.eae_lean_sim_decode_prefixes(size, L, probabilities.ctypes.data, bac.ctypes.data, bac_bits.value, prefixes.ctypes.data)
+        assert rc == 0, (case, rc)                 # -100: the code register left its interval
+        out = numpy.zeros(size, dtype=numpy.int16)
+        rc_host = lib.eae_coder_decode(size, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int16)), L, probabilities.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                       bac.ctypes.data_as(u8p), bac_bits.value, byp.ctypes.data_as(u8p), byp_bits.value, ctypes.byref(stage))
+        if rc_host != 0:
+            continue            # the bypass stream ran dry / an Exp-Golomb code went wrong: an error of the general coder, reported by it
+        assert numpy.array_equal(prefixes, numpy.minimum(numpy.abs(out.astype(numpy.int32)), L)), case
+        decoded_alike += 1
+        differed_from_the_encoder += int(not numpy.array_equal(out, symbols))
+    assert decoded_alike > 100 and differed_from_the_encoder > 50, (decoded_alike, differed_from_the_encoder)

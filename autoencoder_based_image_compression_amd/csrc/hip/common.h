@@ -142,6 +142,94 @@ __device__ __forceinline__ float gdn_apply(float x, float d, float beta, bool in
     return inverse ? x * s : x / s;
 }
 
+// ---- the same normalisation without the parts of `sqrtf` and `/` that only extreme operands need (round 4) ---------------
+// hipcc's correctly rounded sqrtf is: [a < 2^-96: scale by 2^32] v_sqrt_f32, the two neighbours of the result, two FMA residuals,
+// two selects, [unscale] [class check: +-0 and +inf return themselves] -- 16 vector instructions; its correctly rounded a / b is
+// v_div_scale x2, v_rcp_f32, a Newton step, the quotient with two FMA corrections, v_div_fmas, v_div_fixup -- 11. The bracketed
+// parts do nothing for operands in the middle of the range: `sqrt_mid` and `div_mid` are the SAME instruction sequences without them
+// (9 and 8 instructions), hence the same bits, for
+//     sqrt_mid(a):    a >= 2^-96 (also +inf and NaN: the selects leave v_sqrt_f32's own result alone; NOT negative denormals,
+//                     which v_sqrt_f32 flushes to -0: the guard's minimum keeps every negative a out)
+//     div_mid(x, s):  2^-60 <= |x| <= 2^60 and 2^-20 <= s <= 2^40: v_div_scale_f32 returns its operand unscaled (exponent
+//                     difference below 96, no denormal operand, reciprocal or quotient, numerator exponent above 23), so
+//                     v_div_fmas is a plain FMA and v_div_fixup the identity.
+// Proven on the GPU besides (tests/test_gpu_kernels.py through eae_hip_debug_check_mid_forms): sqrt_mid against sqrtf on EVERY float
+// from 2^-96 up and every NaN, div_mid against `/` on 2^33 operand pairs of the guarded range including its corners. `gdn_tile` checks the range
+// per wavefront (a min / max over the tile: half an instruction per element and bound) and falls back to sqrtf and `/` otherwise.
+__device__ __forceinline__ float sqrt_mid(float a) {
+    float s = __builtin_amdgcn_sqrtf(a);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, a), r_up = __builtin_fmaf(-s_up, s, a);
+    s = 0.f >= r_dn ? s_dn : s;
+    s = 0.f < r_up ? s_up : s;
+    return s;
+}
+__device__ __forceinline__ float div_mid(float x, float s) {
+    float y = __builtin_amdgcn_rcpf(s);
+    y = __builtin_fmaf(__builtin_fmaf(-s, y, 1.f), y, y);
+    float q = x * y;
+    q = __builtin_fmaf(__builtin_fmaf(-s, q, x), y, q);
+    return __builtin_fmaf(__builtin_fmaf(-s, q, x), y, q);
+}
+#define EAE_MID_A_MIN_SQRT 0x1p-96f
+#define EAE_MID_A_MIN 0x1p-40f        // s = sqrt(a) in [2^-20, 2^40]
+#define EAE_MID_A_MAX 0x1p80f
+#define EAE_MID_X_MIN 0x1p-60f
+#define EAE_MID_X_MAX 0x1p60f
+
+// One wavefront's register tile: out(t, g, y) receives, group of four registers by group, y = x / sqrt(a) (GDN) or x * sqrt(a)
+// (IGDN) with a[t][r] = d + beta formed by the caller. The range check runs over the whole tile first (a min / max chain per bound);
+// the groups are then normalised one after the other (a scheduling fence per group keeps the register pressure where it was
+// when the epilogues normalised and stored element by element).
+template <int NT, bool INVERSE, typename Out>
+__device__ __forceinline__ void gdn_tile(const f32x16 (&x)[NT], const f32x16 (&a)[NT], Out out) {
+#ifndef EAE_NO_MID_FORMS
+    float a_min = a[0][0], a_max = a[0][0], x_min = __builtin_fabsf(x[0][0]), x_max = x_min;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = (t == 0 ? 1 : 0); r < 16; ++r) {
+            a_min = __builtin_fminf(a_min, a[t][r]);
+            if (!INVERSE) {
+                a_max = __builtin_fmaxf(a_max, a[t][r]);
+                x_min = __builtin_fminf(x_min, __builtin_fabsf(x[t][r]));
+                x_max = __builtin_fmaxf(x_max, __builtin_fabsf(x[t][r]));
+            }
+        }
+    const bool mid = INVERSE ? a_min >= EAE_MID_A_MIN_SQRT
+                             : (a_min >= EAE_MID_A_MIN && a_max <= EAE_MID_A_MAX && x_min >= EAE_MID_X_MIN && x_max <= EAE_MID_X_MAX);
+    if (__builtin_amdgcn_ballot_w64(!mid) == 0ull) {        // every lane of the wavefront in range: one path for all
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float y[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float s = sqrt_mid(a[t][4 * g + q]);
+                    y[q] = INVERSE ? x[t][4 * g + q] * s : div_mid(x[t][4 * g + q], s);
+                }
+                out(t, g, make_float4(y[0], y[1], y[2], y[3]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        return;
+    }
+#endif
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float y[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float s = sqrtf(a[t][4 * g + q]);
+                y[q] = INVERSE ? x[t][4 * g + q] * s : x[t][4 * g + q] / s;
+            }
+            out(t, g, make_float4(y[0], y[1], y[2], y[3]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
 
 // ---- register-resident epilogue of the TRANSPOSED wave tile (conv_gemm.hip, conv1.hip) --------------------------------
 // acc[t][r] at lane (hi = lane >> 5, lj = lane & 31) holds channel 32 t + (r & 3) + 8 (r >> 2) + 4 hi of position lj
@@ -233,16 +321,19 @@ __device__ __forceinline__ void wave_epilogue(f32x16 (&acc)[4], const float* vec
 #undef EAE_G_LOAD
         EAE_TRACE_MARK(3)
         constexpr bool inverse = NORM == EAE_NORM_IGDN;
+        // `+ beta` after the matmul, then sqrt, then divide / multiply (tfutils.py:396); d becomes d + beta in place
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 bt = *reinterpret_cast<const float4*>(vec_lds + EAE_C + 32 * t + 8 * g + cbase);
-                const float4 y = make_float4(gdn_apply(acc[t][4 * g + 0], d[t][4 * g + 0], bt.x, inverse),
-                                             gdn_apply(acc[t][4 * g + 1], d[t][4 * g + 1], bt.y, inverse),
-                                             gdn_apply(acc[t][4 * g + 2], d[t][4 * g + 2], bt.z, inverse),
-                                             gdn_apply(acc[t][4 * g + 3], d[t][4 * g + 3], bt.w, inverse));
-                if (valid) *reinterpret_cast<float4*>(o + 32 * t + 8 * g) = y;
+                d[t][4 * g + 0] = d[t][4 * g + 0] + bt.x;
+                d[t][4 * g + 1] = d[t][4 * g + 1] + bt.y;
+                d[t][4 * g + 2] = d[t][4 * g + 2] + bt.z;
+                d[t][4 * g + 3] = d[t][4 * g + 3] + bt.w;
             }
+        gdn_tile<4, inverse>(acc, d, [&](int t, int g, float4 y) {
+            if (valid) *reinterpret_cast<float4*>(o + 32 * t + 8 * g) = y;
+        });
     }
 }

@@ -253,15 +253,19 @@ __global__ __launch_bounds__(256) void latent_quarter_kernel(const float* x, con
     }
     if (GDN_IN) {
         EAE_Q_EXCHANGE()
-        const f32x16 d = quarter_denominator<8>(full, gamma_in, w, lane);
+        f32x16 d[1] = {quarter_denominator<8>(full, gamma_in, w, lane)};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 bt = *reinterpret_cast<const float4*>(vec + cw + 8 * g);
-            own[4 * g + 0] = gdn_apply(own[4 * g + 0], d[4 * g + 0], bt.x, false);
-            own[4 * g + 1] = gdn_apply(own[4 * g + 1], d[4 * g + 1], bt.y, false);
-            own[4 * g + 2] = gdn_apply(own[4 * g + 2], d[4 * g + 2], bt.z, false);
-            own[4 * g + 3] = gdn_apply(own[4 * g + 3], d[4 * g + 3], bt.w, false);
+            d[0][4 * g + 0] = d[0][4 * g + 0] + bt.x;
+            d[0][4 * g + 1] = d[0][4 * g + 1] + bt.y;
+            d[0][4 * g + 2] = d[0][4 * g + 2] + bt.z;
+            d[0][4 * g + 3] = d[0][4 * g + 3] + bt.w;
         }
+        const f32x16 xn[1] = {own};
+        gdn_tile<1, false>(xn, d, [&](int, int g, float4 y) {
+            own[4 * g + 0] = y.x; own[4 * g + 1] = y.y; own[4 * g + 2] = y.z; own[4 * g + 3] = y.w;
+        });
     } else {
         __syncthreads();                                     // vec
     }
@@ -327,16 +331,19 @@ __global__ __launch_bounds__(256) void latent_quarter_kernel(const float* x, con
     if (IGDN_OUT) {
         if (GDN_IN) __syncthreads();                         // every wave has read the first exchange
         EAE_Q_EXCHANGE()
-        const f32x16 d = quarter_denominator<8>(full, gamma_out, w, lane);
-        if (valid) {
+        f32x16 d[1] = {quarter_denominator<8>(full, gamma_out, w, lane)};
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 bt = *reinterpret_cast<const float4*>(vec + EAE_C + cw + 8 * g);
-                *reinterpret_cast<float4*>(t_out + obase + 8 * g) =
-                    make_float4(gdn_apply(own[4 * g + 0], d[4 * g + 0], bt.x, true), gdn_apply(own[4 * g + 1], d[4 * g + 1], bt.y, true),
-                                gdn_apply(own[4 * g + 2], d[4 * g + 2], bt.z, true), gdn_apply(own[4 * g + 3], d[4 * g + 3], bt.w, true));
-            }
+        for (int g = 0; g < 4; ++g) {
+            const float4 bt = *reinterpret_cast<const float4*>(vec + EAE_C + cw + 8 * g);
+            d[0][4 * g + 0] = d[0][4 * g + 0] + bt.x;
+            d[0][4 * g + 1] = d[0][4 * g + 1] + bt.y;
+            d[0][4 * g + 2] = d[0][4 * g + 2] + bt.z;
+            d[0][4 * g + 3] = d[0][4 * g + 3] + bt.w;
         }
+        const f32x16 xn[1] = {own};
+        gdn_tile<1, true>(xn, d, [&](int, int g, float4 y) {
+            if (valid) *reinterpret_cast<float4*>(t_out + obase + 8 * g) = y;
+        });
     }
 #ifndef EAE_LATENT_NOCHECKS
     if (checks) {

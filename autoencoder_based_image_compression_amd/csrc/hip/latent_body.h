@@ -66,11 +66,14 @@ __device__ __forceinline__ void wave_gdn_inplace(f32x16 (&x)[4], const float* be
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 bt = *reinterpret_cast<const float4*>(beta_lds + 32 * t + 8 * g + 4 * hi);
-            x[t][4 * g + 0] = gdn_apply(x[t][4 * g + 0], d[t][4 * g + 0], bt.x, INVERSE);
-            x[t][4 * g + 1] = gdn_apply(x[t][4 * g + 1], d[t][4 * g + 1], bt.y, INVERSE);
-            x[t][4 * g + 2] = gdn_apply(x[t][4 * g + 2], d[t][4 * g + 2], bt.z, INVERSE);
-            x[t][4 * g + 3] = gdn_apply(x[t][4 * g + 3], d[t][4 * g + 3], bt.w, INVERSE);
+            d[t][4 * g + 0] = d[t][4 * g + 0] + bt.x;
+            d[t][4 * g + 1] = d[t][4 * g + 1] + bt.y;
+            d[t][4 * g + 2] = d[t][4 * g + 2] + bt.z;
+            d[t][4 * g + 3] = d[t][4 * g + 3] + bt.w;
         }
+    gdn_tile<4, INVERSE>(x, d, [&](int t, int g, float4 y) {
+        x[t][4 * g + 0] = y.x; x[t][4 * g + 1] = y.y; x[t][4 * g + 2] = y.z; x[t][4 * g + 3] = y.w;
+    });
 }
 
 

@@ -600,11 +600,67 @@ def main(args):
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(variables, probabilities, map_mean_host, cores, h_in, w_in)
+            # checker leg, like cpu_baseline: what the summation order of the transforms does to symbols, bits and PSNR, end to end
+            line['order_sensitivity'] = order_sensitivity(device, cores)
         print(json.dumps(line))
         sys.stdout.flush()
     if ctx.grouped:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def order_sensitivity(device, cores, configs=None):
+    """north_star's float clause (symbols bit-exact, reconstruction within 1e-4 dB PSNR) stated end to end with TensorFlow absent: the
+    HIP path's symbols, coded bits and PSNR on BASELINE.json configs[1] (one Kodak-sized image, bin width 1.0) and on a bounded
+    share of configs[2] (Kodak-sized images at bin widths 0.5 / 1.0 / 2.0) against the same graph (i) in float64 and (ii) in float32
+    in oneDNN's summation order (oracle/order_sensitivity.py: checker code, used only here and in tests/test_gpu_order_sensitivity.py).
+    Coded bits: the product's host coder, the same probability tables for every arithmetic."""
+    from oracle import order_sensitivity as checker
+    from autoencoder_based_image_compression_amd.kodak.lossless import compression
+    variables = synthetic_model(1.)
+    encoder = pipeline.DeviceEncoder(variables, False, device)
+    decoder = pipeline.DeviceDecoder(variables, False, device)
+    configs = configs or (('configs[1]', 1, (1.0,)), ('configs[2] (4 of its 24 images)', 4, (0.5, 1.0, 2.0)))
+    out = {'tolerance_psnr_db': 1e-4, 'tolerance_distance_from_a_rounding_boundary': 1e-4,
+           'note': 'HIP path against the same graph in float64 and in float32 in oneDNN order (TensorFlow absent: its order cannot be run)'}
+    t0 = time.perf_counter()
+    for (label, nb_images, multipliers) in configs:
+        images = synthetic_images(2000, nb_images, 512, 768)
+        x = torch.from_numpy(images).to(device)
+        y = encoder(x)
+        map_mean = dev.map_means(y)
+        (y_host, mean_host) = (y.cpu().numpy(), map_mean.cpu().numpy())
+        (product, widths, tables) = ({}, {}, {})
+        for m in multipliers:
+            name = 'bin_width_{0}'.format(m)
+            bw = numpy.full(128, m, dtype=numpy.float32)
+            q = dev.quantize_maps(y, torch.from_numpy(bw).to(device), map_mean, want_shifted=True, want_symbols=True)
+            (_, rec_u8, _) = decoder(q['shifted'], reference_uint8=x)
+            planar = q['symbols'].cpu().numpy()                                             # [N][C][h w]
+            product[name] = {'symbols': numpy.ascontiguousarray(planar.transpose(0, 2, 1)).reshape(y_host.shape),
+                             'reconstruction': rec_u8.cpu().numpy()}
+            widths[name] = bw
+            tables[name] = lossless_stats.compute_binary_probabilities(y_host, bw, mean_host, TRUNCATED_UNARY_LENGTH)
+        rows = {}
+        for name in product:
+            def count_bits(symbols_nhwc, table=tables[name]):
+                n = symbols_nhwc.shape[0]
+                planar = numpy.ascontiguousarray(symbols_nhwc.reshape(n, -1, 128).transpose(0, 2, 1).astype(numpy.int16))
+                (_, nb_bits) = compression.code_planar_symbols(planar, table, IDX_MAP_EXCEPTION, nb_threads=max(1, cores - 1), verify_only=True)
+                return nb_bits.astype(numpy.int64).sum(axis=1)
+            one = checker.compare(images, {name: product[name]}, variables, False, {name: widths[name]}, mean_host, count_bits, threads=cores)
+            for (path, per_width) in one['paths'].items():
+                rows.setdefault(path, {})[name] = per_width[name]
+        out[label] = {'images': nb_images, 'vs': rows}
+    worst = [r for cfg in out.values() if isinstance(cfg, dict) and 'vs' in cfg for per in cfg['vs'].values() for r in per.values()]
+    out['summary'] = {'symbols_compared': int(sum(r['symbols'] for r in worst)), 'symbols_differing': int(sum(r['symbols_differing'] for r in worst)),
+                      'largest_distance_from_a_rounding_boundary': max(r['largest_distance_from_a_rounding_boundary'] for r in worst),
+                      'delta_bits_per_image_max': max(r['delta_bits_per_image_max'] for r in worst),
+                      'delta_psnr_db_per_image_max': max(r['delta_psnr_db_per_image_max'] for r in worst),
+                      'within_tolerance': bool(max(r['delta_psnr_db_per_image_max'] for r in worst) <= 1e-4 and
+                                               max(r['largest_distance_from_a_rounding_boundary'] for r in worst) < 1e-4),
+                      'seconds': round(time.perf_counter() - t0, 1)}
+    return out
 
 
 def cpu_baseline(variables, probabilities, map_mean, cores, h, w):

@@ -353,6 +353,11 @@ int eae_hip_debug_reload_launch_options(void);
  * (eae_hip_conv_workspace_collect, eae_hip_transform_status). Reachable through this entry point only -- no environment variable
  * can make a deployment drop tiles. */
 int eae_hip_debug_set_split_mute(int on);
+/* Proof harness of the normalisations' mid-range forms (csrc/hip/common.h: sqrt_mid, div_mid -- hipcc's correctly rounded sqrtf and
+ * `/` without the scaling and fix-up steps that only extreme operands need). mode 0: every float with bits in [first, first + count)
+ * through sqrt_mid and sqrtf; mode 1: `count` pseudo-random operand pairs of the guarded range (all exponents, random and extreme
+ * mantissas) through div_mid and `/`. out2_device[0] += results whose bits differ, out2_device[1] = one such operand (pair). */
+int eae_hip_debug_check_mid_forms(int mode, uint64_t first, uint64_t count, uint64_t seed, uint64_t* out2_device, void* stream);
 
 /* tls.cast_bt601 (tools.py:61-93) on its own: u8 = uint8(round_half_even(clip(x, 16, 235))). */
 int eae_hip_cast_bt601(const float* x, uint8_t* out, int64_t count, void* stream);

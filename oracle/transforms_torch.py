@@ -29,7 +29,9 @@ def _same_padding(size, k, s):
 class CpuTransforms(object):
     """Weights converted once (NCHW / OIHW, channels_last memory format); `encoder` / `decoder` take and return NHWC numpy."""
 
-    def __init__(self, variables, are_bin_widths_learned, threads=None):
+    def __init__(self, variables, are_bin_widths_learned, threads=None, dtype=numpy.float32):
+        # dtype numpy.float64: the same graph evaluated in double precision (oracle/order_sensitivity.py: the order-free reference)
+        self.dtype = numpy.dtype(dtype)
         if threads:
             torch.set_num_threads(int(threads))
         self.learned = are_bin_widths_learned
@@ -40,19 +42,19 @@ class CpuTransforms(object):
                 if row[1] not in variables:          # an encoder-only or decoder-only set of variables
                     continue
                 if row[0] == 'conv2d':
-                    self.v[row[1]] = torch.from_numpy(numpy.ascontiguousarray(variables[row[1]].transpose(3, 2, 0, 1)))       # HWIO -> OIHW
+                    self.v[row[1]] = torch.from_numpy(numpy.ascontiguousarray(variables[row[1]].transpose(3, 2, 0, 1), dtype=self.dtype))       # HWIO -> OIHW
                 elif row[0] == 'conv2d_transpose':
                     # TF filter [k, k, out, in]; conv_transpose2d wants [in, out, k, k]
-                    self.v[row[1]] = torch.from_numpy(numpy.ascontiguousarray(variables[row[1]].transpose(3, 2, 0, 1)))
+                    self.v[row[1]] = torch.from_numpy(numpy.ascontiguousarray(variables[row[1]].transpose(3, 2, 0, 1), dtype=self.dtype))
                 else:
                     # d[c] = beta[c] + sum_k x[k]^2 Gamma[k, c]: a 1x1 convolution with weight [c, k, 1, 1] = Gamma^T
-                    self.v[row[1]] = torch.from_numpy(numpy.ascontiguousarray(variables[row[1]].T.reshape(128, 128, 1, 1)))
-                    self.v[row[2]] = torch.from_numpy(numpy.ascontiguousarray(variables[row[2]]))
+                    self.v[row[1]] = torch.from_numpy(numpy.ascontiguousarray(variables[row[1]].T.reshape(128, 128, 1, 1), dtype=self.dtype))
+                    self.v[row[2]] = torch.from_numpy(numpy.ascontiguousarray(variables[row[2]], dtype=self.dtype))
                 if row[0] != 'gdn' and row[0] != 'inverse_gdn' and row[3]:
-                    self.v[row[3]] = torch.from_numpy(numpy.ascontiguousarray(variables[row[3]]))
+                    self.v[row[3]] = torch.from_numpy(numpy.ascontiguousarray(variables[row[3]], dtype=self.dtype))
 
     def _run(self, x_nhwc, rows):
-        x = torch.from_numpy(numpy.ascontiguousarray(x_nhwc, dtype=numpy.float32)).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+        x = torch.from_numpy(numpy.ascontiguousarray(x_nhwc, dtype=self.dtype)).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
         with torch.no_grad():
             for row in table.layers_of(rows, self.learned):
                 if row[0] == 'conv2d':

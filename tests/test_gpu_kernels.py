@@ -310,3 +310,67 @@ def test_transforms_equal_the_committed_fixture(learned, size):
         assert numpy.sum(a, dtype=numpy.float64) == crc[name][0], (tag, name)
         if float(zlib.crc32(a.tobytes())) != crc[name][1]:
             assert numpy.count_nonzero(a == 0.) > 0, (tag, name)
+
+
+# ---- the normalisations' mid-range forms (csrc/hip/common.h: sqrt_mid, div_mid, gdn_tile) ------------------
+def _mid_forms(mode, first, count, seed=0):
+    import ctypes
+    from autoencoder_based_image_compression_amd import _native
+    import torch
+    out = torch.zeros(2, dtype=torch.int64, device='cuda')
+    rc = _native.hip().eae_hip_debug_check_mid_forms(mode, first, count, seed, ctypes.c_void_p(out.data_ptr()), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return (int(out[0].item()), int(out[1].item()))
+
+
+def test_sqrt_mid_equals_sqrtf_on_every_float_of_its_range():
+    """v_sqrt_f32 + the two neighbours + two FMA residuals + two selects (hipcc's own correctly rounded sequence without the scaling
+    of tiny inputs and the class check) against sqrtf, EXHAUSTIVELY over everything `gdn_tile`'s guard lets through: every float
+    from 2^-96 to +inf and every NaN (fminf skips NaNs, so they reach the short form): 0 results differ. Below 2^-96 and for
+    negative denormals -- where the guard sends the wavefront to sqrtf -- the short form does go wrong."""
+    two_m96 = 0x0F800000
+    (bad, example) = _mid_forms(0, two_m96, (1 << 31) - two_m96)            # 2^-96 .. +inf, positive NaNs
+    assert bad == 0, hex(example)
+    (bad, example) = _mid_forms(0, 0xFF800001, (1 << 32) - 0xFF800001)      # negative NaNs
+    assert bad == 0, hex(example)
+    (bad_below, _) = _mid_forms(0, 1, two_m96 - 1)
+    (bad_negative, _) = _mid_forms(0, 0x80000001, 0x7F800000)
+    print('sqrt_mid outside its range: {0} of {1} positive floats below 2^-96 and {2} negative floats differ from sqrtf'.format(
+        bad_below, two_m96 - 1, bad_negative))
+    assert bad_below > 0                      # the guard is not decoration
+
+
+def test_div_mid_equals_the_division_on_its_range():
+    """v_rcp_f32 + one Newton step + quotient + two FMA corrections + the final FMA (hipcc's own correctly rounded division without
+    v_div_scale / v_div_fixup) against `/` on 2^33 operand pairs of the guarded range (2^-60 <= |x| <= 2^60, 2^-20 <= s <= 2^40):
+    every exponent pair, random mantissas and the extreme ones (0, all ones, equal), both signs."""
+    for seed in (1, 2):
+        (bad, example) = _mid_forms(1, 0, 1 << 32, seed << 40)
+        assert bad == 0, hex(example)
+
+
+@pytest.mark.parametrize('inverse', [False, True])
+def test_normalisation_outside_the_mid_range_takes_the_general_path(T, dev, orc, inverse):
+    """Tiles whose operands leave the guarded range (tiny beta, tiny, huge and zero activations) are normalised by sqrtf and `/` as
+    before: the conv GEMM epilogue against the oracle on such inputs, next to ordinary ones in the same launch."""
+    rng = numpy.random.RandomState(77)
+    v = _vars(9)
+    x = rng.standard_normal(size=(2, 16, 24, 128)).astype(numpy.float32)
+    x[0, :4] *= numpy.float32(1e-25)                                     # x^2 underflows: d + beta = beta
+    x[1, 4:8] *= numpy.float32(1e22)                                     # beyond 2^60 after the convolution
+    x[1, 8:] = 0.                                                        # exact zeros
+    beta = numpy.full(128, 1e-30, dtype=numpy.float32)                   # below 2^-96
+    beta[::3] = 1.
+    zero_bias = numpy.zeros(128, dtype=numpy.float32)
+    if inverse:
+        ref = orc.gdn(orc.conv2d_transpose_same(x, v['decoder/weights_4'], 2, zero_bias), v['decoder/gamma_5'], beta, inverse=True)
+        got = dev.tconv5x5s2(_cuda(T, x), dev.pack_tconv_weights(_cuda(T, v['decoder/weights_4'])), _cuda(T, zero_bias), 2,
+                             dev.pack_gamma(_cuda(T, v['decoder/gamma_5'])), _cuda(T, beta)).cpu().numpy()
+    else:
+        ref = orc.gdn(orc.conv2d_same(x, v['encoder/weights_2'], 2, zero_bias), v['encoder/gamma_2'], beta)
+        got = dev.conv5x5s2(_cuda(T, x), dev.pack_conv_weights(_cuda(T, v['encoder/weights_2'])), _cuda(T, zero_bias), 1,
+                            dev.pack_gamma(_cuda(T, v['encoder/gamma_2'])), _cuda(T, beta)).cpu().numpy()
+    both_nan = numpy.isnan(got) & numpy.isnan(ref)
+    assert numpy.array_equal(got[~both_nan], ref[~both_nan])
+    assert numpy.isfinite(ref).sum() > ref.size//2

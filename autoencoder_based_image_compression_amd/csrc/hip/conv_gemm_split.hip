@@ -135,11 +135,16 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
         const int tr = b % p.tiles_r;
         const int img = b / p.tiles_r;
 
-        // activation loader: lane -> (position (lane >> 3) + 8 i of this tile, channel quad lane & 7)
+        // activation loader: lane -> (position m_i of this tile, channel quad lane & 7). The eight 8-lane groups of load / staging
+        // store i take the positions 4 (g & 3) + 16 (g >> 2) + i: the rows that one LDS cycle of the 8-byte staging stores touches
+        // (two or four groups) then start 4 rows = 144 floats apart, i.e. 16 banks modulo 32 and modulo 64 -- disjoint bank sets.
+        // (Rounds 1-3: position g + 8 i, adjacent rows per cycle, 36 floats apart: two-way conflicts on every staging store,
+        // SQ_LDS_BANK_CONFLICT 14.05 M per conv_2 launch.)
         int a_pr[4], a_pc[4], a_ok[4];
+        const int a_m0 = 4 * ((lane >> 3) & 3) + 16 * (lane >> 5);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = (lane >> 3) + 8 * i;
+            const int m = a_m0 + i;
             a_pr[i] = tr * QT_H + m / QT_W;
             a_pc[i] = tc * QT_W + m % QT_W;
             a_ok[i] = (a_pr[i] < p.hp) & (a_pc[i] < p.wp);
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
 #define EAE_Q_STAGE_A(buf_)                                                                                          \
         {                                                                                                            \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
-                float* dst_ = wlds + (buf_) * ABUF + ((lane >> 3) + 8 * i) * AS_STRIDE + 2 * a_q;                    \
+                float* dst_ = wlds + (buf_) * ABUF + (a_m0 + i) * AS_STRIDE + 2 * a_q;                              \
                 *reinterpret_cast<float2*>(dst_) = make_float2(a_reg[i].x, a_reg[i].z);                              \
                 *reinterpret_cast<float2*>(dst_ + 16) = make_float2(a_reg[i].y, a_reg[i].w);                         \
             }                                                                                                        \

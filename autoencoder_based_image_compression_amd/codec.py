@@ -41,11 +41,24 @@ _SIDE_STREAMS = {}          # device index -> list of streams
 _POLL_SECONDS = float(os.environ.get('EAE_WORKER_POLL_SECONDS', '0.0002'))
 
 
-def _side_streams(count, device):
+# Stream priorities (experiments: scratch/r04): EAE_TRANSFORM_STREAM_PRIORITY / EAE_CODER_STREAM_PRIORITY, torch's numbering
+# (-1 high, 0 normal); unset = the runtime's default for both.
+_PRIORITY = {'transform': os.environ.get('EAE_TRANSFORM_STREAM_PRIORITY'), 'coder': os.environ.get('EAE_CODER_STREAM_PRIORITY')}
+# Codecs of this process that have not been closed, per device: a graph capture waits until the others are idle (`_capture_all`).
+_LIVE = {}
+_LIVE_LOCK = threading.Lock()
+
+
+def _side_streams(count, device, first=0, kind='coder'):
+    """Streams first .. first + count - 1 of the process-wide list of the device (a codec's first `nb_in_flight` are its coder
+    streams, its transform streams follow)."""
     streams = _SIDE_STREAMS.setdefault(device.index, [])
-    while len(streams) < count:
-        streams.append(torch.cuda.Stream(device=device))
-    return streams[:count]
+    while len(streams) < first + count:
+        if _PRIORITY[kind] is not None:
+            streams.append(torch.cuda.Stream(device=device, priority=int(_PRIORITY[kind])))
+        else:
+            streams.append(torch.cuda.Stream(device=device))
+    return streams[first:first + count]
 
 
 class Ticket(object):
@@ -271,7 +284,9 @@ class BatchCodec(object):
         self.nb_slots = nb_in_flight + 2
         self._streams = _side_streams(nb_in_flight, self.device)
         nb_private = nb_transform_streams if (nb_transform_streams > 1 or use_graphs) else 0      # replays never go to the caller's stream
-        self._transform_streams = _side_streams(nb_in_flight + nb_private, self.device)[nb_in_flight:]
+        self._transform_streams = _side_streams(nb_private, self.device, first=nb_in_flight, kind='transform')
+        with _LIVE_LOCK:
+            _LIVE.setdefault(self.device.index, []).append(self)
         # ... and behind the squared errors one more 64-bit word whose low half is the conv workspace's error word of the step
         self._slot_all = [torch.zeros(nb_words + 2*batch_size + 2, dtype=torch.int32, device=self.device) for _ in range(self.nb_slots)]
         self._slot_out = [t[:nb_words] for t in self._slot_all]
@@ -423,6 +438,14 @@ class BatchCodec(object):
         starts later shares its stream with replays whose events the worker is polling, and on this runtime a query of an
         event recorded on a capturing stream invalidates the capture (seen with one transform stream and 24 Kodak images:
         hipErrorStreamCaptureInvalidated at the first launch of the second slot's capture)."""
+        # Codecs of this process share the device's side streams (and their slices move with `nb_in_flight`): one that is busy would
+        # have its worker polling events on a stream this capture uses. Wait until every other live codec of the device is idle;
+        # a caller that keeps submitting to another codec from another thread during a first submit here is outside the contract
+        # (INTEGRATION.md: bring a device's codecs up one after the other).
+        with _LIVE_LOCK:
+            others = [c for c in _LIVE.get(self.device.index, []) if c is not self]
+        for other in others:
+            other.drain()
         torch.cuda.synchronize(self.device)
         for slot in range(self.nb_slots):
             # any of the codec's streams will do for the capture: a replay runs on the stream it is launched into, which
@@ -588,6 +611,10 @@ class BatchCodec(object):
             self._worker.jobs.put(None)
             self._worker.join()
             self._worker = None
+            with _LIVE_LOCK:
+                live = _LIVE.get(self.device.index, [])
+                if self in live:
+                    live.remove(self)
 
     def __enter__(self):
         return self

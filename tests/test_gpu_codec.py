@@ -157,6 +157,44 @@ def test_batch_codec_graph_replay_equals_the_launch_by_launch_path(learned, stre
         codec.BatchCodec(v, learned, bin_widths, map_mean, probabilities, 67, 2, 64, 96, coder='host', use_graphs=True)
 
 
+def test_a_second_graph_codec_captures_while_the_first_one_is_busy():
+    """codecs of one process share the device's side streams, and their slices move with `nb_in_flight`; a second
+    graph-mode codec whose first submit (= its capture) comes while the first codec has batches in flight must neither invalidate
+    its own capture nor disturb the other's results: `_capture_all` waits until the other live codecs of the device are idle."""
+    from autoencoder_based_image_compression_amd import codec
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    with numpy.load(GOLD) as g:
+        probabilities = g['real_probabilities_1']
+    rng = numpy.random.RandomState(31)
+    v = var.random_variables(1., False, seed=6, bias_std=0.01)
+    v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)
+    images = torch.from_numpy(rng.randint(16, 236, size=(12, 64, 96)).astype(numpy.uint8)).cuda()
+    ones = numpy.ones(128, dtype=numpy.float32)
+    with codec.BatchCodec(v, False, ones, 0*ones, probabilities, 67, 2, 64, 96) as plain:
+        expected = [plain.submit(images[2*k:2*k + 2]).result() for k in range(6)]
+    first = codec.BatchCodec(v, False, ones, 0*ones, probabilities, 67, 2, 64, 96, use_graphs=True, nb_transform_streams=3, nb_in_flight=3)
+    second = codec.BatchCodec(v, False, ones, 0*ones, probabilities, 67, 2, 64, 96, use_graphs=True, nb_transform_streams=2, nb_in_flight=5)
+    try:
+        first.submit(images[0:2]).result()                           # first's graphs exist
+        busy = [first.submit(images[2*(k % 6):2*(k % 6) + 2]) for k in range(8)]      # in flight while the second one captures
+        mine = [second.submit(images[2*k:2*k + 2]) for k in range(6)]
+        for (k, t) in enumerate(busy):
+            r = t.result()
+            for key in ('nb_bits', 'sse', 'nb_deads'):
+                assert numpy.array_equal(r[key], expected[k % 6][key]), ('first', k, key)
+        for (k, t) in enumerate(mine):
+            r = t.result()
+            for key in ('nb_bits', 'sse', 'nb_deads'):
+                assert numpy.array_equal(r[key], expected[k][key]), ('second', k, key)
+        # and interleaved afterwards
+        for k in range(6):
+            (a, b) = (first.submit(images[2*k:2*k + 2]), second.submit(images[2*k:2*k + 2]))
+            assert numpy.array_equal(a.result()['nb_bits'], expected[k]['nb_bits']) and numpy.array_equal(b.result()['nb_bits'], expected[k]['nb_bits'])
+    finally:
+        first.close()
+        second.close()
+
+
 def test_graph_capture_with_one_transform_stream_at_kodak_size():
     """use_graphs with ONE transform stream on a batch whose step takes milliseconds: while slot 0's replay was still running, the
     capture of slot 1 (same stream) used to be invalidated by the result worker's event polls (hipErrorStreamCaptureInvalidated;

@@ -244,7 +244,7 @@ def test_batch_encoder_and_decoder_equal_the_host_coder(gold, dev, scale):
     keep = prob_row >= 0
     assert not streams.status.cpu().numpy().any()
     assert numpy.array_equal(out[keep], planar[keep]) and not out[~keep].any()
-    # the same decode with a workspace: maps sorted into short and long, one launch instead of two passes
+    # the same decode with a workspace: the lean core (ring-fed, one prefix byte per symbol) + the data-parallel pass
     ws = dev.coder_workspace(n, 96, probs.shape[1], 'cuda')
     out = dev.coder_decode_batch(streams, p, rows, workspace=ws).cpu().numpy()
     assert not streams.status.cpu().numpy().any()
@@ -260,8 +260,9 @@ def test_batch_encoder_and_decoder_equal_the_host_coder(gold, dev, scale):
 
 def test_batch_large_maps_long_pending_runs_and_every_window_tier(gold, dev):
     """Maps of 128 x 128 latents (a 2048 x 2048 image): near-dead maps under a very skewed p0 build runs of pending E3 bits far
-    beyond 47, and the stream lengths cover the decoder's window tiers (192 / 48 words first for maps this large, 448 / 96
-    in the second pass, the general kernel beyond). Bytes, bit counts and decoded symbols equal the host coder's."""
+    beyond 47 (emit_kernel's long-queue path and its give-up to the general kernel), and the stream lengths run from a few words
+    (inside the decoder ring's first fill of 32) to thousands (refilled hundreds of times; round 2's decoder had window tiers
+    here, hence the test's name). Bytes, bit counts and decoded symbols equal the host coder's."""
     rng = numpy.random.RandomState(77)
     size = 128*128
     L = 10
@@ -288,12 +289,12 @@ def test_batch_large_maps_long_pending_runs_and_every_window_tier(gold, dev):
     out = dev.coder_decode_batch(streams, p, r).cpu().numpy()
     assert not streams.status.cpu().numpy().any()
     assert numpy.array_equal(out, planar)
-    out = dev.coder_decode_batch(streams, p, r, workspace=dev.coder_workspace(n, size, L, 'cuda')).cpu().numpy()     # sorted form
+    out = dev.coder_decode_batch(streams, p, r, workspace=dev.coder_workspace(n, size, L, 'cuda')).cpu().numpy()     # lean core + debinarise pass
     assert not streams.status.cpu().numpy().any()
     assert numpy.array_equal(out, planar)
     dev.coder_decode_batch(streams, p, r, expected=sym)
     assert not streams.status.cpu().numpy().any()
-    # one corrupted stream per window tier is found, and only those
+    # one corrupted stream per stream-length class (inside the ring's first fill / refilled several times) is found, and only those
     order = [int(m) for m in numpy.argsort(bits) if bits[m] >= 64]      # the flipped bit must be a coded one
     victims = [order[0], order[len(order)//2], order[-1]]
     for m in victims:
@@ -346,7 +347,7 @@ def test_batch_fuzz_against_host_coder_including_errors(gold, dev):
         good = ok & (rows >= 0)
         assert numpy.array_equal(out[good], planar[good]), t
         two_pass_status = streams.status.clone()
-        out = dev.coder_decode_batch(streams, p, r, workspace=dev.coder_workspace(n_maps, size, L, 'cuda')).cpu().numpy()   # sorted form
+        out = dev.coder_decode_batch(streams, p, r, workspace=dev.coder_workspace(n_maps, size, L, 'cuda')).cpu().numpy()   # lean core + debinarise pass
         assert numpy.array_equal(out[good], planar[good]), t
         assert torch.equal(streams.status, two_pass_status) and torch.equal(streams.stage[streams.status != 0], streams.stage[two_pass_status != 0]), t
     assert {0, 1, 4} <= seen

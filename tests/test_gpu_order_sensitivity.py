@@ -22,8 +22,9 @@ def check(report, label):
         for (name, r) in per_width.items():
             where = (label, path, name)
             assert r['symbols'] > 0 and r['psnr_db_mean'] > 0.
-            # symbols: a handful in millions, each a one-step move across a boundary the latent sat on
-            assert r['symbols_differing'] <= max(2, r['symbols']//100000), (where, r)
+            # symbols: a handful in millions (float32 rounding, ~1e-6 of a latent of size 1-4, against the bin width: the share of
+            # latents that close to a boundary is ~2e-6 / bin width), each a one-step move across a boundary the latent sat on
+            assert r['symbols_differing'] <= max(2, r['symbols']//20000), (where, r)
             assert r['largest_symbol_step'] <= 1 and r['largest_distance_from_a_rounding_boundary'] < BOUNDARY_TOLERANCE, (where, r)
             # reconstruction: single grey levels (a few more around a symbol that moved: the synthesis transform spreads one bin over
             # a 16 x 16 neighbourhood), PSNR within north_star's tolerance

@@ -70,6 +70,9 @@ __device__ __forceinline__ int head_steps(int d, int D, int T) {
 template <int NORM>
 __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_split_kernel(const ConvGemmParams p) {
     __shared__ __attribute__((aligned(16))) float lds[4 * 2 * ABUF + vec_floats(NORM)];
+#ifdef EAE_GEMM_PRIO       // scratch/r04: instruction-issue priority of the GEMM waves against the coder's (experiment; no effect measured)
+    __builtin_amdgcn_s_setprio(EAE_GEMM_PRIO);
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* wlds = lds + wave * 2 * ABUF;

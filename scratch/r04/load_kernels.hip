@@ -312,6 +312,68 @@ __global__ __launch_bounds__(64) void lk_vgpr_dirty(float* sink, float seed) {
     if (seed == 12345.678f) sink[0] = seed;
 }
 
+// one-wave blocks, like the coder's kernels: a dependent integer / FP64 chain (the serial cores) ...
+__global__ __launch_bounds__(64) void lk_chain1(float* sink, int iters, float seed) {
+    unsigned int a = threadIdx.x * 2654435761u + blockIdx.x, b = 0x9E3779B9u;
+    double p = 0.3 + 1e-3 * threadIdx.x;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned int t = (unsigned int)(p * (double)(a >> 8));
+            a = (a ^ (t << 3)) + b;
+            b = (b << 1) | (b >> 31);
+            a = __builtin_clz(a | 1u) + (a << 2);
+        }
+    }
+    if (a == 12345u) sink[0] = (float)a;
+}
+// the same chain without any FP64 instruction (integers only) ...
+__global__ __launch_bounds__(64) void lk_chain_int(float* sink, int iters, float seed) {
+    unsigned int a = threadIdx.x * 2654435761u + blockIdx.x, b = 0x9E3779B9u;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned int t = __umulhi(a, b) + (a >> 8);
+            a = (a ^ (t << 3)) + b;
+            b = (b << 1) | (b >> 31);
+            a = __builtin_clz(a | 1u) + (a << 2);
+        }
+    }
+    if (a == 12345u) sink[0] = (float)a;
+}
+// ... with the product formed by 64-bit integer multiply-adds (v_mad_u64_u32) instead of v_mul_f64 ...
+__global__ __launch_bounds__(64) void lk_chain_mad64(float* sink, int iters, float seed) {
+    unsigned int a = threadIdx.x * 2654435761u + blockIdx.x, b = 0x9E3779B9u;
+    const unsigned int m_lo = 0x89ABCDEFu + threadIdx.x, m_hi = 0x00123456u;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned long long lo = (unsigned long long)m_lo * (a >> 16);
+            const unsigned long long hi = (unsigned long long)m_hi * (a >> 16) + (lo >> 32);
+            const unsigned int t = (unsigned int)(hi >> 5);
+            a = (a ^ (t << 3)) + b;
+            b = (b << 1) | (b >> 31);
+            a = __builtin_clz(a | 1u) + (a << 2);
+        }
+    }
+    if (a == 12345u) sink[0] = (float)a;
+}
+// ... and FP64 only (convert, multiply, convert back: the three FP64 instructions of a coder step, nothing else)
+__global__ __launch_bounds__(64) void lk_chain_f64(float* sink, int iters, float seed) {
+    unsigned int a = threadIdx.x * 2654435761u + blockIdx.x;
+    double p = 0.3 + 1e-3 * threadIdx.x;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) a = (unsigned int)(p * (double)(a >> 8)) + 0x9E3779B9u;
+    }
+    if (a == 12345u) sink[0] = (float)a;
+}
+// ... and a streaming pass over the block's own slice of a big buffer (the data-parallel passes: 1-4 bytes per decision)
+__global__ __launch_bounds__(64) void lk_stream1(const float4* __restrict__ src, float4* __restrict__ dst, size_t per_block) {
+    const size_t base = (size_t)blockIdx.x * per_block;
+    for (size_t i = threadIdx.x; i < per_block; i += 64) dst[base + i] = src[base + i];
+}
+
 extern "C" int lk_launch(int kind, int blocks, int iters, void* buf, size_t bytes, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     float* f = (float*)buf;
@@ -322,6 +384,11 @@ extern "C" int lk_launch(int kind, int blocks, int iters, void* buf, size_t byte
     case 3: hipLaunchKernelGGL(lk_mem, dim3(blocks), dim3(256), 0, s, (const float4*)buf, (float4*)((char*)buf + bytes / 2), bytes / 32); break;
     case 4: hipLaunchKernelGGL(lk_lds_dirty, dim3(blocks), dim3(256), 0, s, f, 0xDEADBEEFu); break;
     case 5: hipLaunchKernelGGL(lk_vgpr_dirty, dim3(blocks), dim3(64), 0, s, f, 1.f); break;
+    case 6: hipLaunchKernelGGL(lk_chain1, dim3(blocks), dim3(64), 0, s, f, iters, 1.f); break;
+    case 8: hipLaunchKernelGGL(lk_chain_int, dim3(blocks), dim3(64), 0, s, f, iters, 1.f); break;
+    case 9: hipLaunchKernelGGL(lk_chain_mad64, dim3(blocks), dim3(64), 0, s, f, iters, 1.f); break;
+    case 10: hipLaunchKernelGGL(lk_chain_f64, dim3(blocks), dim3(64), 0, s, f, iters, 1.f); break;
+    case 7: hipLaunchKernelGGL(lk_stream1, dim3(blocks), dim3(64), 0, s, (const float4*)buf, (float4*)((char*)buf + bytes / 2), (size_t)iters); break;
     default: return -1;
     }
     return (int)hipGetLastError();

@@ -55,6 +55,9 @@ CASES = [
     ('96 chain waves', [(6, 96, 60000, 1)]),
     ('256 chain waves', [(6, 256, 60000, 1)]),
     ('1024 chain waves', [(6, 1024, 60000, 1)]),
+    ('48 chain waves in 8 consecutive launches of 1/8 the length (the same work, hopping between SIMDs)', [(6, 48, 7500, 8)]),
+    ('48 chain waves in 32 consecutive launches of 1/32 the length', [(6, 48, 1875, 32)]),
+    ('96 chain waves in 16 launches of 1/16 (two cores)', [(6, 48, 3750, 16), (6, 48, 3750, 16)]),
     ('96 chain waves, integers only', [(8, 96, 60000, 1)]),
     ('96 chain waves, product by v_mad_u64_u32', [(9, 96, 60000, 1)]),
     ('96 chain waves, FP64 only (cvt, mul, cvt)', [(10, 96, 120000, 1)]),

@@ -21,6 +21,7 @@ struct EaeLaunchOptions {
     int force_tile;     // EAE_HIP_FORCE_TILE: 0 (by shape) | 32 | 64 | 128
     int force_nt;       // EAE_HIP_FORCE_NT: 0 (by shape) | 1 | 2 | 4
     char latent;        // EAE_HIP_LATENT: 'q' (default) | 'w' | 'l'
+    int split_wpb;      // EAE_HIP_SPLIT_WPB: 1 = one-wave blocks in the split conv GEMM (default: 4 waves per block)
     int split_mute;     // test hook, debug entry point only: heads of cut tiles never publish, tails give up after ~1 ms
 };
 extern EaeLaunchOptions g_eae_launch_options;

@@ -67,16 +67,17 @@ __device__ __forceinline__ int head_steps(int d, int D, int T) {
 // SIMDs hold one or two waves anyway.
 // Blocks of four waves, each wave on its own (the block is only the unit of dispatch; one-wave blocks measured 1-10 % slower
 // alone and no better next to the coder).
-template <int NORM>
-__global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_split_kernel(const ConvGemmParams p) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * ABUF + vec_floats(NORM)];
+// WPB: waves (= items) per block, the unit of dispatch (4; 1 for conv_2: see the launcher)
+template <int NORM, int WPB>
+__global__ __launch_bounds__(64 * WPB, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_split_kernel(const ConvGemmParams p) {
+    __shared__ __attribute__((aligned(16))) float lds[WPB * 2 * ABUF + vec_floats(NORM)];
 #ifdef EAE_GEMM_PRIO       // scratch/r04: instruction-issue priority of the GEMM waves against the coder's (experiment; no effect measured)
     __builtin_amdgcn_s_setprio(EAE_GEMM_PRIO);
 #endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* wlds = lds + wave * 2 * ABUF;
-    float* vec_lds = lds + 4 * 2 * ABUF;
+    float* vec_lds = lds + WPB * 2 * ABUF;
     {
         const float2 z = make_float2(0.f, 0.f);
         *reinterpret_cast<float2*>(vec_lds + 2 * lane) = p.bias ? *reinterpret_cast<const float2*>(p.bias + 2 * lane) : z;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_sp
     const int a_off = lj * AS_STRIDE + hi * 16;
 
     {
-        const int item = ((int)blockIdx.x >> 3) * 4 + wave;
+        const int item = ((int)blockIdx.x >> 3) * WPB + wave;
         if (item >= n_items) return;
         int d = -1, tau;
         bool is_tail = false;
@@ -370,13 +371,25 @@ int eae_conv_gemm::launch_split(ConvGemmParams& p, hipStream_t stream, int cut) 
     // one wave per item, blocks of 4 items, the 8 shares interleaved: the largest share decides the grid
     const long cnt_max = (nsp + 7) / 8 * p.n_phases;
     const long d_max = split ? (cnt_max < p.split_resident_waves_per_xcd ? cnt_max : p.split_resident_waves_per_xcd) : 0;
-    const int grid = (int)((cnt_max + d_max + 3) / 4) * 8;
-#define EAE_LAUNCH_S(N_) hipLaunchKernelGGL((conv_gemm_split_kernel<N_>), dim3(grid), dim3(256), 0, stream, p)
-    if (p.norm == NORM_LATENT) EAE_LAUNCH_S(NORM_LATENT);
-    else if (p.norm == NORM_LATENT_PLAIN) EAE_LAUNCH_S(NORM_LATENT_PLAIN);
-    else if (p.norm == EAE_NORM_GDN) EAE_LAUNCH_S(EAE_NORM_GDN);
-    else if (p.norm == EAE_NORM_IGDN) EAE_LAUNCH_S(EAE_NORM_IGDN);
-    else EAE_LAUNCH_S(EAE_NORM_NONE);
+    // Blocks of four waves (the unit of dispatch). Next to the coder's long-lived waves a SIMD that hosts one runs its GEMM wave a
+    // third slower, and a four-wave block then holds the slots of the CU's other three SIMDs until its slowest wave is through; with
+    // one-wave blocks (EAE_HIP_SPLIT_WPB=1) only the hosting SIMD falls behind: conv_2 + GDN_2, the layer with the longest tiles, runs
+    // 1.035 -> 0.997 ms in the kernel-by-kernel schedule (conv GEMM 0.778 -> 0.789 of peak), but the product mode -- three transform
+    // streams already fill a launch's tails with the next batches' kernels, and four times as many blocks cost dispatch -- loses 0.6 %
+    // (3,103 -> 3,085 Mpx/s), and conv_3 / the transposed convolutions lose 2-5 % by themselves (profiles/r04_waves_per_block.log).
+    // So four it stays; the one-wave instance is kept behind the override and in the parity tests.
+    const int wpb = g_eae_launch_options.split_wpb == 1 ? 1 : 4;
+    const int grid = (int)((cnt_max + d_max + wpb - 1) / wpb) * 8;
+#define EAE_LAUNCH_S(N_)                                                                                                  \
+    {                                                                                                                     \
+        if (wpb == 1) hipLaunchKernelGGL((conv_gemm_split_kernel<N_, 1>), dim3(grid), dim3(64), 0, stream, p);            \
+        else hipLaunchKernelGGL((conv_gemm_split_kernel<N_, 4>), dim3(grid), dim3(256), 0, stream, p);                    \
+    }
+    if (p.norm == NORM_LATENT) EAE_LAUNCH_S(NORM_LATENT)
+    else if (p.norm == NORM_LATENT_PLAIN) EAE_LAUNCH_S(NORM_LATENT_PLAIN)
+    else if (p.norm == EAE_NORM_GDN) EAE_LAUNCH_S(EAE_NORM_GDN)
+    else if (p.norm == EAE_NORM_IGDN) EAE_LAUNCH_S(EAE_NORM_IGDN)
+    else EAE_LAUNCH_S(EAE_NORM_NONE)
 #undef EAE_LAUNCH_S
     EAE_HIP_CHECK_LAUNCH();
     return EAE_HIP_OK;

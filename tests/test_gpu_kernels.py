@@ -63,8 +63,14 @@ def _select_form(launch_options, form, tile):
     'wave' = conv_gemm_wave_kernel, one tile per wave (32 / 64 / 128-position blocks); 'nt1' / 'nt2' = the same with a
     wave's output channels spread over 4 / 2 blocks (small layers); 'lds' = the block-cooperative LDS form (64- or
     128-position blocks); 'whole' = conv_gemm_split_kernel with whole tiles; 'cut1..3' = conv_gemm_split_kernel with the cut
-    forced onto these small shapes (every tile is then cut in two and the tails wait for their heads)."""
+    forced onto these small shapes (every tile is then cut in two and the tails wait for their heads); 'one2' / 'one3' = the same
+    as blocks of one wave (EAE_HIP_SPLIT_WPB=1)."""
     launch_options.clear()
+    if form.startswith('one'):            # 'one2': the cut forced, one-wave blocks (EAE_HIP_SPLIT_WPB=1)
+        launch_options.setenv('EAE_HIP_GEMM', 's')
+        launch_options.setenv('EAE_HIP_SPLIT_WAVES', form[3:])
+        launch_options.setenv('EAE_HIP_SPLIT_WPB', '1')
+        return
     if form.startswith('cut'):
         launch_options.setenv('EAE_HIP_GEMM', 's')
         launch_options.setenv('EAE_HIP_SPLIT_WAVES', form[3:])
@@ -88,7 +94,7 @@ def _assert_handed_over(T, dev, ws):
 
 
 FORMS = [('wave', '32'), ('wave', '64'), ('wave', '128'), ('lds', '64'), ('lds', '128'), ('nt1', '32'), ('nt2', '32'),
-         ('whole', ''), ('cut1', ''), ('cut2', ''), ('cut3', '')]
+         ('whole', ''), ('cut1', ''), ('cut2', ''), ('cut3', ''), ('one2', ''), ('one3', '')]
 
 
 def test_conv1_reads_words(T, dev, orc):
@@ -125,7 +131,7 @@ def test_conv5x5s2(T, dev, orc, shape, norm, form, tile, launch_options):
     expect_w = numpy.empty((25, 128, 128), dtype=numpy.float32)
     expect_w[:, :, perm] = v['encoder/weights_2'].reshape(25, 128, 128)
     assert numpy.array_equal(wp.cpu().numpy(), expect_w)
-    ws = dev.conv_workspace('cuda') if form.startswith('cut') else None      # a cut launch needs a workspace, and its owner collects
+    ws = dev.conv_workspace('cuda') if form.startswith(('cut', 'one')) else None      # a cut launch needs a workspace, and its owner collects
     got = dev.conv5x5s2(_cuda(T, x), wp, _cuda(T, v['encoder/biases_2']), norm,
                         dev.pack_gamma(_cuda(T, v['encoder/gamma_2'])), _cuda(T, v['encoder/beta_2']), workspace=ws).cpu().numpy()
     assert numpy.array_equal(got, ref)
@@ -148,7 +154,7 @@ def test_tconv5x5s2(T, dev, orc, shape, norm, form, tile, launch_options):
     expect_w = numpy.empty((25, 128, 128), dtype=numpy.float32)
     expect_w[:, :, perm] = v['decoder/weights_4'].transpose(0, 1, 3, 2).reshape(25, 128, 128)
     assert numpy.array_equal(wp.cpu().numpy(), expect_w)
-    ws = dev.conv_workspace('cuda') if form.startswith('cut') else None
+    ws = dev.conv_workspace('cuda') if form.startswith(('cut', 'one')) else None
     got = dev.tconv5x5s2(_cuda(T, x), wp, _cuda(T, v['decoder/biases_4']), norm,
                          dev.pack_gamma(_cuda(T, v['decoder/gamma_5'])), _cuda(T, v['decoder/beta_5']), workspace=ws).cpu().numpy()
     assert numpy.array_equal(got, ref)

@@ -23,7 +23,7 @@ def rows_of(directory):
     return rows
 
 
-# The four launches of a step are instances of conv_gemm_split_kernel<epilogue> (0 none / 1 GDN / 2 IGDN); the two transposed
+# The four launches of a step are instances of conv_gemm_split_kernel<epilogue, waves per block> (0 none / 1 GDN / 2 IGDN; 4); the two transposed
 # convolutions share an instance, so a launch is identified by (instance, grid size in work-items). Grid of a layer
 # (conv_gemm_split.hip: launch_split): 8 x ceil((tiles of the largest XCD share + cut tiles) / 4) blocks of 256 threads.
 def grid_items(batch, positions_per_image, phases, cut, cus=256):
@@ -39,10 +39,10 @@ def grid_items(batch, positions_per_image, phases, cut, cus=256):
 
 def instances(batch):
     px = 512*768
-    return {'conv2_gdn2': ('conv_gemm_split_kernel<1>', grid_items(batch, px//64, 1, True)),
-            'conv3': ('conv_gemm_split_kernel<0>', grid_items(batch, px//256, 1, True)),
-            'tconv1_igdn5': ('conv_gemm_split_kernel<2>', grid_items(batch, px//256, 4, False)),
-            'tconv2_igdn6': ('conv_gemm_split_kernel<2>', grid_items(batch, px//64, 4, False))}
+    return {'conv2_gdn2': ('conv_gemm_split_kernel<1,', grid_items(batch, px//64, 1, True)),
+            'conv3': ('conv_gemm_split_kernel<0,', grid_items(batch, px//256, 1, True)),
+            'tconv1_igdn5': ('conv_gemm_split_kernel<2,', grid_items(batch, px//256, 4, False)),
+            'tconv2_igdn6': ('conv_gemm_split_kernel<2,', grid_items(batch, px//64, 4, False))}
 
 
 INSTANCES = {}

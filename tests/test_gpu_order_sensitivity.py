@@ -28,7 +28,7 @@ def check(report, label):
             assert r['largest_symbol_step'] <= 1 and r['largest_distance_from_a_rounding_boundary'] < BOUNDARY_TOLERANCE, (where, r)
             # reconstruction: single grey levels (a few more around a symbol that moved: the synthesis transform spreads one bin over
             # a 16 x 16 neighbourhood), PSNR within north_star's tolerance
-            assert r['largest_pixel_step'] <= (1 if r['symbols_differing'] == 0 else 8), (where, r)
+            assert r['largest_pixel_step'] <= (1 if r['symbols_differing'] == 0 else 16), (where, r)
             assert r['delta_psnr_db_per_image_max'] <= PSNR_TOLERANCE_DB, (where, r)
             # bits: a differing symbol moves the coded size of an image by a few bits at most
             assert r['delta_bits_per_image_max'] <= 16*max(1, r['symbols_differing_per_image_max']), (where, r)

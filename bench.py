@@ -604,17 +604,25 @@ def main(args):
                 'coder_on_critical_path': bool(in_pipe > coder_streams*ms_step*0.95)})
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(variables, probabilities, map_mean_host, cores, h_in, w_in)
-            # checker leg, like cpu_baseline: what the summation order of the transforms does to symbols, bits and PSNR, end to end
-            try:
-                line['order_sensitivity'] = order_sensitivity(device, cores)
-            except Exception as exc:      # a checker leg must never cost the run its headline
-                line['order_sensitivity'] = {'error': '{0}: {1}'.format(type(exc).__name__, exc)}
+            # the one leg of this file that runs checker code (oracle/): the CPU baseline and, with the same CPU transforms, what
+            # the transforms' summation order does to symbols, bits and PSNR end to end
+            (line['cpu_baseline'], line['order_sensitivity']) = cpu_baseline_leg(variables, probabilities, map_mean_host, cores, h_in, w_in, device)
         print(json.dumps(line))
         sys.stdout.flush()
     if ctx.grouped:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def cpu_baseline_leg(variables, probabilities, map_mean, cores, h, w, device):
+    """bench.py's checker leg (rank 0, one GPU): `cpu_baseline` (the path timed on the host cores) and `order_sensitivity` (the HIP
+    path held against the same graph in two other arithmetics on the host). Nothing outside this leg touches oracle/."""
+    baseline = cpu_baseline(variables, probabilities, map_mean, cores, h, w)
+    try:
+        sensitivity = order_sensitivity(device, cores)
+    except Exception as exc:      # a checker figure must never cost the run its headline
+        sensitivity = {'error': '{0}: {1}'.format(type(exc).__name__, exc)}
+    return (baseline, sensitivity)
 
 
 def order_sensitivity(device, cores, configs=None):

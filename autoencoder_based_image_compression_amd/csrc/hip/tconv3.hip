@@ -40,6 +40,7 @@ constexpr int PATCH_FLOATS = PATCH_R * PATCH_C * PS;   // 38,016 B (4 blocks = 8
 constexpr int Q = HALF_C / 4;                 // float4 per site per pass
 constexpr int LOADS = (PATCH_R * PATCH_C * Q + NT - 1) / NT;   // per thread per pass
 constexpr int STEPS = 4 * 9;                  // (channel block, neighbour)
+constexpr int OT_STRIDE = 68;                 // floats per row of the epilogue's pixel tile in LDS (64 pixels + 4)
 #ifndef EAE_T3_RING
 #define EAE_T3_RING 6
 #endif
@@ -208,13 +209,14 @@ __global__ __launch_bounds__(NT, WAVES_PER_SIMD) void tconv3_kernel(const float*
         __syncthreads();                                   // both waves are done reading the patch
         T3_MARK(5)
         // ---- epilogue: 16 x 64 pixel tile through LDS, then 8 consecutive pixels per thread ------------------------
-        float* ot = patch;                                 // [16][64]
+        float* ot = patch;                                 // [16][OT_STRIDE]: rows 4 floats apart modulo the banks (the four rows a lane quad
+                                                           // group writes at once land in distinct banks; 64 was a four-way conflict)
         {
             const int a = i16 >> 2, bq = i16 & 3;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                ot[(8 * wave + a) * 64 + 4 * (4 * kq + r) + bq] = acc0[r];
-                ot[(8 * wave + 4 + a) * 64 + 4 * (4 * kq + r) + bq] = acc1[r];
+                ot[(8 * wave + a) * OT_STRIDE + 4 * (4 * kq + r) + bq] = acc0[r];
+                ot[(8 * wave + 4 + a) * OT_STRIDE + 4 * (4 * kq + r) + bq] = acc1[r];
             }
         }
         __syncthreads();
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(NT, WAVES_PER_SIMD) void tconv3_kernel(const float*
         for (int half = 0; half < 2; ++half) {
             const int gcc = gc + 4 * half;
             if (gr < ho && gcc < wo) {     // wo is a multiple of 4, so the 4 pixels are inside together
-                const float4 o4 = *reinterpret_cast<const float4*>(ot + prow * 64 + pcol + 4 * half);
+                const float4 o4 = *reinterpret_cast<const float4*>(ot + prow * OT_STRIDE + pcol + 4 * half);
                 const size_t o = ((size_t)cur.img * ho + gr) * wo + gcc;
                 if (out_f32) *reinterpret_cast<float4*>(out_f32 + o) = o4;
                 if (out_u8 || ref) {

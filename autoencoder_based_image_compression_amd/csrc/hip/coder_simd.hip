@@ -48,13 +48,32 @@ int eae_coder_generic_decode(uint32_t n_maps, uint32_t map_size, int16_t* out, u
 
 // gfx950: a 64-bit shift (v_lshlrev_b64 / v_lshrrev_b64 / v_ashrrev_i64) whose shift amount sits in the LAST register of the wave's VGPR
 // allocation gives wrong results whenever other waves share the SIMD (csrc/isa_guard.py rule 2, DESIGN.md section 5: the fault of
-// round 3's first decoder core). These kernels shift 64-bit windows by computed amounts, so each of them names v63 in an empty asm:
-// the allocation becomes 64 registers (still eight waves per SIMD), the allocator's own values stay far below, and the last register
-// is nobody's operand. The guard checks the shipped ISA whatever this does.
+// round 3's first decoder core). These kernels shift 64-bit windows by computed amounts, so each of them names the last register of
+// ITS OWN allocation in an empty asm: the allocator cannot give it to anybody, and the allocation stays what the kernel needs
+// (24 / 40 / 48 registers). Reserving v63 in all of them was the first form of this: the wide passes (one wavefront per map) at 64
+// registers instead of 24-48 took the room of the transforms' waves -- conv_2 +5 %, tconv3 +19 % in the one-stream leg
+// (profiles/r04_tight_alloc.log). A kernel that outgrows its number moves to the next granule with its real last register
+// unreserved: the guard checks the shipped ISA whatever this does (and tests/test_isa_guard.py pins the five allocations).
+#ifndef EAE_RES_BINARISE
+#define EAE_RES_BINARISE 47
+#endif
+#ifndef EAE_RES_ENCODE_CORE
+#define EAE_RES_ENCODE_CORE 39
+#endif
+#ifndef EAE_RES_EMIT
+#define EAE_RES_EMIT 23
+#endif
+#ifndef EAE_RES_DECODE_CORE
+#define EAE_RES_DECODE_CORE 47
+#endif
+#ifndef EAE_RES_DEBINARISE
+#define EAE_RES_DEBINARISE 23
+#endif
 #ifndef EAE_DECODE_TOPUP_ZEROS
-#define EAE_KEEP_LAST_VGPR_FREE() asm volatile("; v63 reserved: the last register of the allocation holds no operand" ::: "v63")
+#define EAE_KEEP_VGPR_FREE_(n) asm volatile("; v" #n " reserved: the last register of the allocation holds no operand" ::: "v" #n)
+#define EAE_KEEP_LAST_VGPR_FREE(n) EAE_KEEP_VGPR_FREE_(n)
 #else      // the first decoder core is kept as it was built (40 of 40 registers): scratch/r04, tests/test_isa_guard.py
-#define EAE_KEEP_LAST_VGPR_FREE()
+#define EAE_KEEP_LAST_VGPR_FREE(n)
 #endif
 
 namespace {
@@ -136,7 +155,7 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // (1) one wavefront per map: symbols -> decisions + bypass stream
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void binarise_kernel(const SimdParams p) {
-    EAE_KEEP_LAST_VGPR_FREE();
+    EAE_KEEP_LAST_VGPR_FREE(EAE_RES_BINARISE);
     __shared__ unsigned long long ybuf[40];            // one tile of bypass bits: carry word + 64 x (33 + 1) bits
     const uint32_t m = blockIdx.x, lane = threadIdx.x;
     const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(64) void binarise_kernel(const SimdParams p) {
 extern __shared__ double lds_dyn[];
 
 __global__ __launch_bounds__(64) void bac_encode_core_kernel(const SimdParams p) {
-    EAE_KEEP_LAST_VGPR_FREE();
+    EAE_KEEP_LAST_VGPR_FREE(EAE_RES_ENCODE_CORE);
     __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
     const uint32_t lane = threadIdx.x;
     const uint32_t m = blockIdx.x * 64u + lane;
@@ -273,7 +292,7 @@ __global__ __launch_bounds__(64) void bac_encode_core_kernel(const SimdParams p)
 // scalings. So P_j = the k's of the records since (and including) the last one that shifted anything out, and the position of
 // record j's bits is the sum of n + P over the records before it: two prefix sums and a running maximum per tile of 64 records.
 __global__ __launch_bounds__(64) void emit_kernel(const SimdParams p) {
-    EAE_KEEP_LAST_VGPR_FREE();
+    EAE_KEEP_LAST_VGPR_FREE(EAE_RES_EMIT);
     __shared__ unsigned long long buf[kEmitWords + 2];
     const uint32_t m = blockIdx.x, lane = threadIdx.x;
     const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
@@ -372,7 +391,7 @@ __device__ unsigned int g_hwid_probe[8];     // [0] waves, [1] waves whose HW_ID
 #endif
 
 __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p) {
-    EAE_KEEP_LAST_VGPR_FREE();
+    EAE_KEEP_LAST_VGPR_FREE(EAE_RES_DECODE_CORE);
     __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
 #ifdef EAE_HWID_PROBE
     const unsigned int probe_hw0 = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);      // HW_REG_HW_ID
@@ -577,7 +596,7 @@ extern "C" int eae_hip_debug_hwid_probe(unsigned int* out8) {
 // (5) one wavefront per map: prefixes + bypass stream -> symbols; compare with the encoder's input
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void debinarise_kernel(const SimdParams p) {
-    EAE_KEEP_LAST_VGPR_FREE();
+    EAE_KEEP_LAST_VGPR_FREE(EAE_RES_DEBINARISE);
     __shared__ uint32_t ytile[80];                     // the bypass words a tile of 64 symbols can touch: 64 x 34 bits + alignment
     const uint32_t m = blockIdx.x, lane = threadIdx.x;
     const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;

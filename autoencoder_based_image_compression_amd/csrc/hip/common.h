@@ -181,10 +181,13 @@ __device__ __forceinline__ float div_mid(float x, float s) {
 // One wavefront's register tile: out(t, g, y) receives, group of four registers by group, y = x / sqrt(a) (GDN) or x * sqrt(a)
 // (IGDN) with a[t][r] = d + beta formed by the caller. The range check runs over the whole tile first (a min / max chain per bound);
 // the groups are then normalised one after the other (a scheduling fence per group keeps the register pressure where it was
-// when the epilogues normalised and stored element by element).
-template <int NT, bool INVERSE, typename Out>
+// when the epilogues normalised and stored element by element). MID = false keeps hipcc's full sequences for a caller the check
+// does not pay for: the latent stage's quarter tiles (16 values per lane: 0.056 ms with the mid forms against 0.051 without,
+// profiles/r04_latent_mid_forms.log -- the two code paths cost it a wave per SIMD).
+template <int NT, bool INVERSE, bool MID = true, typename Out>
 __device__ __forceinline__ void gdn_tile(const f32x16 (&x)[NT], const f32x16 (&a)[NT], Out out) {
 #ifndef EAE_NO_MID_FORMS
+  if constexpr (MID) {
     float a_min = a[0][0], a_max = a[0][0], x_min = __builtin_fabsf(x[0][0]), x_max = x_min;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -215,6 +218,7 @@ __device__ __forceinline__ void gdn_tile(const f32x16 (&x)[NT], const f32x16 (&a
             }
         return;
     }
+  }
 #endif
 #pragma unroll
     for (int t = 0; t < NT; ++t)

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void latent_quarter_kernel(const float* x, con
             d[0][4 * g + 3] = d[0][4 * g + 3] + bt.w;
         }
         const f32x16 xn[1] = {own};
-        gdn_tile<1, false>(xn, d, [&](int, int g, float4 y) {
+        gdn_tile<1, false, false>(xn, d, [&](int, int g, float4 y) {
             own[4 * g + 0] = y.x; own[4 * g + 1] = y.y; own[4 * g + 2] = y.z; own[4 * g + 3] = y.w;
         });
     } else {
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void latent_quarter_kernel(const float* x, con
             d[0][4 * g + 3] = d[0][4 * g + 3] + bt.w;
         }
         const f32x16 xn[1] = {own};
-        gdn_tile<1, true>(xn, d, [&](int, int g, float4 y) {
+        gdn_tile<1, true, false>(xn, d, [&](int, int g, float4 y) {
             if (valid) *reinterpret_cast<float4*>(t_out + obase + 8 * g) = y;
         });
     }

@@ -111,8 +111,13 @@ def test_allocations_from_the_shipped_metadata():
     alloc = {}
     for blob in isa_guard.code_objects(lib):
         alloc.update(isa_guard.allocations(blob))
-    decode = [v for (k, v) in alloc.items() if 'bac_decode_core_kernel' in k]
-    assert decode == [64]                         # 46 registers + the reserved v63 (EAE_KEEP_LAST_VGPR_FREE, coder_simd.hip)
+    # every coder kernel reserves the last register of ITS OWN allocation (EAE_KEEP_LAST_VGPR_FREE(EAE_RES_*), coder_simd.hip, coder_device.hip): a kernel
+    # that outgrows its number lands in the next granule with an unreserved last register -- fix the number, not this test
+    own = {'15binarise_kernel': 48, '22bac_encode_core_kernel': 40, '11emit_kernel': 24, '22bac_decode_core_kernel': 48, '17debinarise_kernel': 24,
+           'coder_maps_kernelILi0ELb0E': 56, 'coder_maps_kernelILi1ELb0E': 56, 'coder_maps_kernelILi1ELb1E': 24, 'coder_maps_kernelILi2ELb0E': 56,
+           'decoder_maps_kernelILb0ELb0E': 48, 'decoder_maps_kernelILb0ELb1E': 24, 'decoder_maps_kernelILb1ELb0E': 56, 'decoder_maps_kernelILb1ELb1E': 32}
+    for (name, want) in own.items():
+        assert [v for (k, v) in alloc.items() if name in k] == [want], name
     assert all(v % 8 == 0 and 8 <= v <= 512 for v in alloc.values()) and len(alloc) > 50
     assert not any('latent_wave_kernelILb1ELb1' in k for k in alloc)       # kernels with AccVGPRs are left out: their top registers are accumulators
 

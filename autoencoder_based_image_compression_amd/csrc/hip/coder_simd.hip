@@ -33,7 +33,6 @@
 // every case; tests/test_coder_device.py compares bytes, bit counts, symbols, statuses and stages.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "../coder/lean_step.h"
 #include "eae_hip.h"
@@ -397,13 +396,6 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
     const unsigned int probe_hw0 = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);      // HW_REG_HW_ID
     const unsigned int probe_xcc0 = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);     // HW_REG_XCC_ID
 #endif
-#ifdef EAE_DECODE_HUNT
-    const unsigned int hunt_hw0 = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);      // HW_REG_HW_ID
-    const unsigned int hunt_gpr = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 5);      // HW_REG_GPR_ALLOC
-    const unsigned int hunt_lds = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 6);      // HW_REG_LDS_ALLOC
-    const unsigned int hunt_xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);      // HW_REG_XCC_ID
-    const unsigned long long hunt_t0 = __builtin_amdgcn_s_memtime();
-#endif
     const uint32_t lane = threadIdx.x;
     const uint32_t m = blockIdx.x * 64u + lane;
     const bool in_range = m < p.n_maps;
@@ -551,26 +543,6 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
         }
     }
     if (live && retry) p.status[m] = RETRY;
-#ifdef EAE_DECODE_HUNT     // scratch/r04: where and when this wavefront ran, into the (otherwise unused) stage words of its first lanes
-    if (p.stage && in_range) {
-        const unsigned int hunt_hw1 = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);
-        const unsigned long long hunt_t1 = __builtin_amdgcn_s_memtime();
-        unsigned int v = 0;
-        switch (lane) {
-        case 0: v = hunt_hw0; break;                                         // HW_ID at the start
-        case 1: v = hunt_hw1; break;                                         // ... and at the end
-        case 2: v = hunt_lds; break;                                         // LDS_ALLOC: base [7:0], size [20:12] (granules)
-        case 3: v = hunt_gpr; break;                                         // GPR_ALLOC: VGPR base [5:0], size [13:8]
-        case 4: v = hunt_xcc; break;
-        case 5: v = (unsigned int)hunt_t0; break;
-        case 6: v = (unsigned int)(hunt_t0 >> 32); break;
-        case 7: v = (unsigned int)hunt_t1; break;
-        case 8: v = (unsigned int)(hunt_t1 >> 32); break;
-        default: v = 0;
-        }
-        if (lane < 9) p.stage[m] = (int32_t)v;
-    }
-#endif
 #ifdef EAE_HWID_PROBE
     {
         const unsigned int hw1 = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);
@@ -783,14 +755,7 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
     // L > 32, the general kernel decodes every map
     const bool fast = fast_applies(L) && map_size && have_ws && !check_simd_layout(map_size, L, streams, stride);
     if (fast) {
-#if defined(EAE_DECODE_HUNT) || defined(EAE_DECODE_HUNT_LDS)      // scratch/r04: the hunt's variants only (never the shipped library): LDS beyond what the kernel uses
-        size_t hunt_lds = decode_lds_bytes(L);
-        if (const char* e = getenv("EAE_HUNT_DECODE_LDS")) hunt_lds = (size_t)atol(e) > hunt_lds ? (size_t)atol(e) : hunt_lds;
-        if (hunt_lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bac_decode_core_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hunt_lds);
-        hipLaunchKernelGGL(bac_decode_core_kernel, dim3((n_maps + 63u) / 64u), dim3(64), hunt_lds, s, p);
-#else
         hipLaunchKernelGGL(bac_decode_core_kernel, dim3((n_maps + 63u) / 64u), dim3(64), decode_lds_bytes(L), s, p);
-#endif
         hipLaunchKernelGGL(debinarise_kernel, dim3(n_maps), dim3(64), 0, s, p);
     } else {
         hipLaunchKernelGGL(mark_kernel, dim3((n_maps + 255u) / 256u), dim3(256), 0, s, p);

@@ -1,7 +1,9 @@
 """r04: the decoder-core fault of DESIGN.md section 5, characterised. The batch decoder (verify mode) on one stream, static inputs
 encoded once without any load, next to ONE kind of neighbour at a time on another stream (or behind a kernel that leaves LDS /
 registers dirty on the same stream):   EAE_HIP_LIB=scratch/r04/libs/<variant>/libeae_hip.so python scratch/r04/decode_hunt.py [bw] [rounds]
-Prints one line per (neighbour, LDS size) with the failing rounds, the failing wavefronts and where in its chain a map first went wrong."""
+Prints one line per (neighbour, LDS size) with the failing rounds, the failing wavefronts and where in its chain a map first went wrong.
+The "LDS 65536 / 163840" rows and EAE_HUNT_PLACEMENT need the probe code that lived in coder_simd.hip during the hunt (-DEAE_DECODE_HUNT,
+-DEAE_DECODE_HUNT_LDS): `git apply scratch/r04/edits/decode_hunt_probes.patch` puts it back."""
 import ctypes, os, sys
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

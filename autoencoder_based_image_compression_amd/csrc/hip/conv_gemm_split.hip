@@ -67,11 +67,12 @@ __device__ __forceinline__ int head_steps(int d, int D, int T) {
 // SIMDs hold one or two waves anyway.
 // Blocks of four waves, each wave on its own (the block is only the unit of dispatch; one-wave blocks measured 1-10 % slower
 // alone and no better next to the coder).
-// WPB: waves (= items) per block, the unit of dispatch (4; 1 for conv_2: see the launcher)
+// WPB: waves (= items) per block, the unit of dispatch (4 is what ships; 1 behind EAE_HIP_SPLIT_WPB and in the parity tests: see the launcher)
 template <int NORM, int WPB>
 __global__ __launch_bounds__(64 * WPB, NORM >= NORM_LATENT ? 2 : 3) void conv_gemm_split_kernel(const ConvGemmParams p) {
     __shared__ __attribute__((aligned(16))) float lds[WPB * 2 * ABUF + vec_floats(NORM)];
-#ifdef EAE_GEMM_PRIO       // scratch/r04: instruction-issue priority of the GEMM waves against the coder's (experiment; no effect measured)
+#ifdef EAE_GEMM_PRIO       // scratch/r04/prio_waves.sh: issue priority of the GEMM waves against the coder's (3: conv_2 1.03 -> 0.96 ms on one
+                           // stream, the coder's chains longer, the product mode -0.4 %: not set in the shipped build)
     __builtin_amdgcn_s_setprio(EAE_GEMM_PRIO);
 #endif
     const int lane = threadIdx.x & 63;

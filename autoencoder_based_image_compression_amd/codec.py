@@ -318,6 +318,7 @@ class BatchCodec(object):
         # host in / host out: a copy stream each way, a pinned buffer per slot for the reconstructions, device staging for the inputs
         self._feed_stream = None
         self._staging = [None]*self.nb_slots
+        self._slot_views = [None]*self.nb_slots      # the views of a slot's pinned result block, made once (graph mode)
         self._fetch_stream = torch.cuda.Stream(device=self.device) if self.fetch_reconstruction else None
         self._pinned_rec = [torch.empty((batch_size, h_in, w_in), dtype=torch.uint8).pin_memory() if self.fetch_reconstruction else None
                             for _ in range(self.nb_slots)]
@@ -400,7 +401,10 @@ class BatchCodec(object):
                 raise RuntimeError('slot {} has no captured graphs (a capture failed earlier)'.format(slot))
             (graphs, static_input, _, reconstruction) = self._graphs[slot]
             fed = []
-            with torch.cuda.stream(stream):
+            # the launch thread's time is what the pipelined small-batch rate is made of: the current stream is switched directly
+            # (`with torch.cuda.stream(...)` costs three device-index resolutions per entry and exit) and restored in the `finally`
+            try:
+                torch.cuda.set_stream(stream)
                 if luminances_uint8.device.type == 'cpu':
                     self._feed(luminances_uint8, static_input, fed)
                 else:
@@ -408,16 +412,18 @@ class BatchCodec(object):
                     static_input.copy_(luminances_uint8, non_blocking=True)
                 graphs[0].replay()
                 quantized = torch.cuda.Event()
-                quantized.record()
-            with torch.cuda.stream(coder_stream):
+                quantized.record(stream)
+                torch.cuda.set_stream(coder_stream)
                 coder_stream.wait_event(quantized)
                 graphs[1].replay()
                 coded = torch.cuda.Event()
-                coded.record()
-            with torch.cuda.stream(stream):
+                coded.record(coder_stream)
+                torch.cuda.set_stream(stream)
                 graphs[2].replay()
                 decoded = torch.cuda.Event()
-                decoded.record()
+                decoded.record(stream)
+            finally:
+                torch.cuda.set_stream(caller)
             if not fed:
                 luminances_uint8.record_stream(stream)
             ticket = Ticket(self.batch_size)
@@ -425,7 +431,9 @@ class BatchCodec(object):
             ticket.fed_event = fed[0] if fed else None
             if self.keep_reconstruction:
                 ticket.reconstruction_uint8 = reconstruction       # valid until this slot is replayed again
-            self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],), None,
+            if self._slot_views[slot] is None:
+                self._slot_views[slot] = self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],)
+            self._worker.jobs.put((ticket, (coded, decoded), self._slot_views[slot], None,
                                    self._slot_free[slot], lambda: self._recount_exception_maps(slot), self._fetch_job(slot, reconstruction)))
             return ticket
         except BaseException:

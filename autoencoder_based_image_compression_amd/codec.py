@@ -24,6 +24,7 @@ import os
 import queue
 import threading
 import time
+import weakref
 
 import numpy
 import torch
@@ -34,8 +35,9 @@ from .kodak.eae.graph import constants as csts
 from .kodak.lossless import compression as lossless_compression
 
 # HIP multiplexes streams onto 4 hardware queues: side streams are shared by every codec of the process so that a coder
-# stream never ends up on the hardware queue of the stream the transforms run on.
-_SIDE_STREAMS = {}          # device index -> list of streams
+# stream never ends up on the hardware queue of the stream the transforms run on. One list per device AND kind: a codec's
+# coder streams are coder streams for every other codec too, whatever their `nb_in_flight`.
+_SIDE_STREAMS = {}          # (device index, kind) -> list of streams
 # The result worker polls its events and sleeps in between: `Event.synchronize()` was measured to spin a whole CPU per
 # process (with blocking events too), and eight ranks share one 16-CPU quota. 0 restores synchronize().
 _POLL_SECONDS = float(os.environ.get('EAE_WORKER_POLL_SECONDS', '0.0002'))
@@ -43,22 +45,33 @@ _POLL_SECONDS = float(os.environ.get('EAE_WORKER_POLL_SECONDS', '0.0002'))
 
 # Stream priorities (experiments: scratch/r04): EAE_TRANSFORM_STREAM_PRIORITY / EAE_CODER_STREAM_PRIORITY, torch's numbering
 # (-1 high, 0 normal); unset = the runtime's default for both.
-_PRIORITY = {'transform': os.environ.get('EAE_TRANSFORM_STREAM_PRIORITY'), 'coder': os.environ.get('EAE_CODER_STREAM_PRIORITY')}
+def _priority(name):
+    """Parsed once at import: a malformed value fails here, not inside some constructor later."""
+    text = os.environ.get(name)
+    if text is None:
+        return None
+    try:
+        return int(text)
+    except ValueError:
+        raise ValueError('{0}={1!r}: expected an integer stream priority (-1 high, 0 normal)'.format(name, text))
+
+
+_PRIORITY = {'transform': _priority('EAE_TRANSFORM_STREAM_PRIORITY'), 'coder': _priority('EAE_CODER_STREAM_PRIORITY')}
 # Codecs of this process that have not been closed, per device: a graph capture waits until the others are idle (`_capture_all`).
-_LIVE = {}
+# Weak references: a codec dropped without close() is still collected (its __del__ closes it).
+_LIVE = {}                  # device index -> weakref.WeakSet of BatchCodec
 _LIVE_LOCK = threading.Lock()
 
 
-def _side_streams(count, device, first=0, kind='coder'):
-    """Streams first .. first + count - 1 of the process-wide list of the device (a codec's first `nb_in_flight` are its coder
-    streams, its transform streams follow)."""
-    streams = _SIDE_STREAMS.setdefault(device.index, [])
-    while len(streams) < first + count:
+def _side_streams(count, device, kind='coder'):
+    """The first `count` streams of the process-wide list of the device for this kind ('coder' / 'transform')."""
+    streams = _SIDE_STREAMS.setdefault((device.index, kind), [])
+    while len(streams) < count:
         if _PRIORITY[kind] is not None:
-            streams.append(torch.cuda.Stream(device=device, priority=int(_PRIORITY[kind])))
+            streams.append(torch.cuda.Stream(device=device, priority=_PRIORITY[kind]))
         else:
             streams.append(torch.cuda.Stream(device=device))
-    return streams[first:first + count]
+    return streams[:count]
 
 
 class Ticket(object):
@@ -284,9 +297,7 @@ class BatchCodec(object):
         self.nb_slots = nb_in_flight + 2
         self._streams = _side_streams(nb_in_flight, self.device)
         nb_private = nb_transform_streams if (nb_transform_streams > 1 or use_graphs) else 0      # replays never go to the caller's stream
-        self._transform_streams = _side_streams(nb_private, self.device, first=nb_in_flight, kind='transform')
-        with _LIVE_LOCK:
-            _LIVE.setdefault(self.device.index, []).append(self)
+        self._transform_streams = _side_streams(nb_private, self.device, kind='transform')
         # ... and behind the squared errors one more 64-bit word whose low half is the conv workspace's error word of the step
         self._slot_all = [torch.zeros(nb_words + 2*batch_size + 2, dtype=torch.int32, device=self.device) for _ in range(self.nb_slots)]
         self._slot_out = [t[:nb_words] for t in self._slot_all]
@@ -323,6 +334,9 @@ class BatchCodec(object):
         self._pinned_rec = [torch.empty((batch_size, h_in, w_in), dtype=torch.uint8).pin_memory() if self.fetch_reconstruction else None
                             for _ in range(self.nb_slots)]
         assert not self.use_graphs or self._transform_streams      # replays never go to the caller's stream
+        # last: a constructor that raised above leaves nothing half-built behind for another codec's `_capture_all` to drain
+        with _LIVE_LOCK:
+            _LIVE.setdefault(self.device.index, weakref.WeakSet()).add(self)
 
     def _views(self, t):
         out = []
@@ -451,7 +465,7 @@ class BatchCodec(object):
         # a caller that keeps submitting to another codec from another thread during a first submit here is outside the contract
         # (bring a device's codecs up one after the other).
         with _LIVE_LOCK:
-            others = [c for c in _LIVE.get(self.device.index, []) if c is not self]
+            others = [c for c in _LIVE.get(self.device.index, ()) if c is not self and getattr(c, '_worker', None) is not None]
         for other in others:
             other.drain()
         torch.cuda.synchronize(self.device)
@@ -611,7 +625,7 @@ class BatchCodec(object):
     def close(self):
         """Waits for the pending batches (whether or not their tickets failed) and joins the result worker: a worker still
         unwinding while the interpreter finalises aborts the process at exit. Idempotent."""
-        if self._worker is None:
+        if getattr(self, '_worker', None) is None:      # closed already, or a constructor that raised before the worker existed
             return
         try:
             self.drain()
@@ -620,9 +634,7 @@ class BatchCodec(object):
             self._worker.join()
             self._worker = None
             with _LIVE_LOCK:
-                live = _LIVE.get(self.device.index, [])
-                if self in live:
-                    live.remove(self)
+                _LIVE.get(self.device.index, weakref.WeakSet()).discard(self)
 
     def __enter__(self):
         return self

@@ -44,6 +44,11 @@ def parse_args(argv=None):
                              'give a low-entropy latent at 1.0; the `realistic_entropy` side figures repeat the run at smaller '
                              'widths (more bits per pixel for the coder)')
     parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--no-dropin-surface', action='store_true',
+                        help='skip the `dropin_surface` leg (the mirror of the reference\'s fix_gamma through the reference\'s own call '
+                             'surface: numpy in, numpy out, batch_size 4)')
+    parser.add_argument('--only-dropin-surface', action='store_true',
+                        help='run the `dropin_surface` leg alone and print it (diagnostic: no headline, no roofline)')
     parser.add_argument('--no-single-image', '--no-side', dest='no_single_image', action='store_true',
                         help='skip the side measurements (one image per step, other shapes, PCIe-inclusive, realistic entropy, host coder)')
     parser.add_argument('--coder', choices=('device', 'host'), default='device',
@@ -458,6 +463,16 @@ def main(args):
     coder_streams = args.coder_streams or auto_coder_streams(h_in, w_in)
 
     variables = synthetic_model(args.bin_width)
+    if args.only_dropin_surface:
+        # diagnostic: the statistics that feed the coder as run_pipeline derives them, then the leg alone
+        encoder = pipeline.DeviceEncoder(variables, False, device)
+        y0 = encoder(torch.from_numpy(synthetic_images(1000 + rank + args.seed_offset, args.batch, h_in, w_in)).to(device))
+        map_mean_host = dev.map_means(y0).cpu().numpy()
+        probabilities = lossless_stats.compute_binary_probabilities(y0.cpu().numpy(), variables[var.BIN_WIDTHS_NAME], map_mean_host, TRUNCATED_UNARY_LENGTH)
+        encoder.check()
+        del y0, encoder
+        print(json.dumps({'dropin_surface': dropin_surface_leg(variables, probabilities, map_mean_host, h_in, w_in)}))
+        return
     # ---- the roofline leg first, while the process has no other streams: the same steps launched kernel by kernel on ONE
     # transform stream (the default stream), HIP events around every launch (on the stream it goes to), so that a duration is
     # that kernel's own next to nothing but the coder's side streams ------------------------------------------------------
@@ -616,16 +631,160 @@ def main(args):
                 # `ms_step` in the product mode: an indication, not an identity -- the step ratio above is the measurement
                 'coder_span_measured_in': 'launch-by-launch schedule, one transform stream',
                 'coder_on_critical_path': bool(in_pipe > coder_streams*ms_step*0.95)})
+    if rank == 0 and world == 1 and not args.no_dropin_surface and (h_in, w_in) == (512, 768):
+        try:
+            line['dropin_surface'] = dropin_surface_leg(variables, probabilities, map_mean_host, h_in, w_in)
+        except Exception as exc:      # a side figure must never cost the run its headline
+            line['dropin_surface'] = {'error': '{0}: {1}'.format(type(exc).__name__, exc)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             # the one leg of this file that runs checker code (oracle/): the CPU baseline and, with the same CPU transforms, what
             # the transforms' summation order does to symbols, bits and PSNR end to end
             (line['cpu_baseline'], line['order_sensitivity']) = cpu_baseline_leg(variables, probabilities, map_mean_host, cores, h_in, w_in, device)
+            surface = line.get('dropin_surface', {})
+            for key in ('code_lossless', 'approx', 'fix_gamma_batched'):
+                if key in surface and line['cpu_baseline'].get('value'):
+                    surface[key]['over_cpu_baseline'] = round(surface[key]['value']/line['cpu_baseline']['value'], 2)
+            if 'code_lossless' in surface:
+                surface['north_star_target'] = {'over_cpu_baseline': 50., 'met': bool(surface['code_lossless'].get('over_cpu_baseline', 0.) >= 50.)}
         print(json.dumps(line))
         sys.stdout.flush()
     if ctx.grouped:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def dropin_surface_leg(variables, probabilities, map_mean, h, w, nb_images=24, batch_size=4, repeats=5):
+    """What a user of the reference's OWN call surface gets: the mirror of `fix_gamma` (reconstructing_eae_kodak.py:31-243) run as
+    the reference's script runs it -- `nb_images` uint8 numpy images in, `batch_size = 4` (:624), one multiplier, numpy in / numpy
+    out at every call, per-image `rescale_compress_lossless_maps` / `rate_3d` / `psnr_2d`, no PNG dumps -- with the modules imported
+    under the reference's names from `dropin/` (the import-shadowing route of INTEGRATION.md section 2). Timed region = BASELINE.md
+    section 3 item 4: the body of `fix_gamma` for one rate point without graph construction / checkpoint restore (the two
+    `initialization` calls and the constructors are timed apart and subtracted). `code_lossless` on and off; `fix_gamma_batched`
+    (the same arrays through codec.BatchCodec) beside it. Median of `repeats` calls after one warm-up call."""
+    import importlib
+    import pickle
+    import shutil
+    import tempfile
+    from autoencoder_based_image_compression_amd.kodak import reconstructing_eae_kodak as mirror
+    dropin = os.path.join(ROOT, 'autoencoder_based_image_compression_amd', 'dropin')
+    sys.path.insert(0, dropin)
+    try:
+        by_reference_name = {name: importlib.import_module(name) for name in (
+            'tensorflow', 'eae.batching', 'eae.graph.EntropyAutoencoder', 'eae.graph.IsolatedDecoder', 'lossless.compression', 'tools.tools')}
+    finally:
+        sys.path.remove(dropin)
+    # the names the reference's script binds (reconstructing_eae_kodak.py:21-29) are the very objects the mirror calls
+    same = (by_reference_name['eae.batching'].encode_mini_batches is mirror.batching.encode_mini_batches and
+            by_reference_name['eae.batching'].decode_mini_batches is mirror.batching.decode_mini_batches and
+            by_reference_name['tools.tools'].quantize_per_map is mirror.tls.quantize_per_map and
+            by_reference_name['tools.tools'].rate_3d is mirror.tls.rate_3d and
+            by_reference_name['tools.tools'].psnr_2d is mirror.tls.psnr_2d and
+            by_reference_name['lossless.compression'].rescale_compress_lossless_maps is mirror.compression.rescale_compress_lossless_maps and
+            by_reference_name['eae.graph.EntropyAutoencoder'].EntropyAutoencoder is mirror.EntropyAutoencoder and
+            by_reference_name['eae.graph.IsolatedDecoder'].IsolatedDecoder is mirror.IsolatedDecoder and
+            by_reference_name['tensorflow'].Session is mirror.tf.Session)
+    if not same:
+        raise RuntimeError('dropin/ does not re-export the objects the mirror harness calls')
+    root = tempfile.mkdtemp(prefix='eae_dropin_surface_')
+    try:
+        suffix = '1_10000'
+        model_dir = os.path.join(root, 'eae/results', suffix)
+        stats_dir = os.path.join(root, 'lossless/results', suffix, 'training_index_10')
+        os.makedirs(model_dir)
+        os.makedirs(stats_dir)
+        var.save_variables(os.path.join(model_dir, 'model_10.npz'), variables)
+        with open(os.path.join(model_dir, 'nb_itvs_per_side_10.pkl'), 'wb') as f:
+            pickle.dump(91, f, protocol=2)
+        numpy.save(os.path.join(stats_dir, 'map_mean.npy'), map_mean)
+        with open(os.path.join(stats_dir, 'idx_map_exception.pkl'), 'wb') as f:
+            pickle.dump(IDX_MAP_EXCEPTION, f, protocol=2)
+        numpy.save(os.path.join(stats_dir, 'binary_probabilities_1.npy'), probabilities)
+        images = synthetic_images(1000, nb_images, h, w)
+        multipliers = numpy.array([1.], dtype=numpy.float32)
+        bin_width_init = float(variables[var.BIN_WIDTHS_NAME][0])
+
+        # wall time spent inside named calls of the surface (cheap wrappers; the two `initialization`s are always wrapped: their
+        # time is what the timed region leaves out)
+        spent = {}
+
+        def timed(name, fn):
+            def wrapper(*a, **k):
+                t0 = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    spent[name] = spent.get(name, 0.) + time.perf_counter() - t0
+            return wrapper
+
+        patches = []
+
+        def patch(owner, attribute, name):
+            original = getattr(owner, attribute)
+            patches.append((owner, attribute, original))
+            setattr(owner, attribute, timed(name, original))
+
+        def unpatch():
+            while patches:
+                (owner, attribute, original) = patches.pop()
+                setattr(owner, attribute, original)
+
+        def call(is_lossless, batched=False):
+            spent.clear()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if batched:
+                out = mirror.fix_gamma_batched(images, bin_width_init, multipliers, 10, 10000., batch_size, False, root=root)
+            else:
+                out = mirror.fix_gamma(images, bin_width_init, multipliers, 10, 10000., batch_size, False, is_lossless, root=root)
+            total = time.perf_counter() - t0
+            return (out, total, dict(spent))
+
+        def measure(is_lossless, batched=False, breakdown=False):
+            patch(mirror.EntropyAutoencoder, 'initialization', 'init')
+            patch(mirror.IsolatedDecoder, 'initialization', 'init')
+            if breakdown:
+                patch(mirror.batching, 'encode_mini_batches', 'encode_mini_batches')
+                patch(mirror.batching, 'decode_mini_batches', 'decode_mini_batches')
+                patch(mirror.tls, 'quantize_per_map', 'quantize_per_map')
+                patch(mirror.tls, 'count_nb_deads', 'count_nb_deads')
+                patch(mirror.tls, 'rate_3d', 'rate_3d')
+                patch(mirror.tls, 'psnr_2d', 'psnr_2d')
+                patch(mirror.compression, 'rescale_compress_lossless_maps', 'rescale_compress_lossless_maps')
+            try:
+                call(is_lossless, batched)                                        # warm-up: module loads, allocator, file cache
+                runs = [call(is_lossless, batched) for _ in range(1 if breakdown else repeats)]
+            finally:
+                unpatch()
+            runs.sort(key=lambda r: r[1] - r[2].get('init', 0.))
+            return runs[(len(runs) - 1)//2]
+
+        pixels = nb_images*h*w
+        out = {'workload': '{0} x {1}x{2} uint8 numpy, batch_size {3}, one multiplier (1.0), no PNG dumps'.format(nb_images, h, w, batch_size),
+               'through': 'dropin/ (tensorflow, eae.batching, eae.graph.*, lossless.compression, tools.tools): the objects the mirror of '
+                          'fix_gamma calls, checked by identity',
+               'timed_region': 'the call of fix_gamma minus its two `initialization` calls (BASELINE.md section 3 item 4); median of {} calls'.format(repeats),
+               'unit': 'Mpixels/s'}
+        reference = {}
+        for (key, is_lossless) in (('code_lossless', True), ('approx', False)):
+            ((rate, psnr), total, sp) = measure(is_lossless)
+            region = total - sp.get('init', 0.)
+            (_, total_b, sp_b) = measure(is_lossless, breakdown=True)
+            named = {k: round(v*1e3, 3) for (k, v) in sorted(sp_b.items()) if k != 'init'}
+            named['harness_own_numpy_and_constructors'] = round((total_b - sum(sp_b.values()))*1e3, 3)
+            out[key] = {'value': round(pixels/region/1e6, 3), 'images_per_s': round(nb_images/region, 2), 'ms_per_image': round(region/nb_images*1e3, 4),
+                        'ms_timed_region': round(region*1e3, 3), 'ms_whole_call': round(total*1e3, 3), 'ms_initialization': round(sp.get('init', 0.)*1e3, 3),
+                        'ms_per_call_of_the_surface': named, 'mean_rate_bpp': round(float(rate.mean()), 5), 'mean_psnr_db': round(float(psnr.mean()), 4)}
+            reference[key] = (rate, psnr)
+        ((rate_b, psnr_b), total, sp) = measure(True, batched=True)
+        out['fix_gamma_batched'] = {'value': round(pixels/total/1e6, 3), 'images_per_s': round(nb_images/total, 2), 'ms_whole_call': round(total*1e3, 3),
+                                    'note': 'same files, same returned arrays through codec.BatchCodec (whole call incl. checkpoint restore, codec '
+                                            'construction and graph capture: it has no separate initialization)',
+                                    'arrays_equal_fix_gamma': bool(numpy.array_equal(rate_b, reference['code_lossless'][0]) and
+                                                                   numpy.array_equal(psnr_b, reference['code_lossless'][1]))}
+        return out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def cpu_baseline_leg(variables, probabilities, map_mean, cores, h, w, device):

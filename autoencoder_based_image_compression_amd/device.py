@@ -125,8 +125,9 @@ class Model(object):
         except Exception:
             pass
 
-    def encode(self, images_u8):
-        """uint8 [N,H,W] (device) -> latents f32 [N,H/16,W/16,128]: `sess.run(node_y)` of eae/batching.py:96-99 in one call."""
+    def encode(self, images_u8, out=None):
+        """uint8 [N,H,W] (device) -> latents f32 [N,H/16,W/16,128]: `sess.run(node_y)` of eae/batching.py:96-99 in one call.
+        out: a contiguous float32 tensor of that shape to write into (e.g. a mini-batch's slice of the whole set's latents)."""
         if images_u8.dtype != torch.uint8:
             raise TypeError('`images_u8.dtype` is not `torch.uint8`.')
         (n, h, wd) = images_u8.shape[:3]
@@ -137,15 +138,18 @@ class Model(object):
             raise HipError('images on {0} but the model lives on {1}'.format(images_u8.device, self.device))
         self.check()
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=images_u8.device)
-        latents = torch.empty((n, h//16, wd//16, NB_MAPS), dtype=torch.float32, device=images_u8.device)
+        latents = out if out is not None else torch.empty((n, h//16, wd//16, NB_MAPS), dtype=torch.float32, device=images_u8.device)
+        if latents.dtype != torch.float32 or tuple(latents.shape) != (n, h//16, wd//16, NB_MAPS):
+            raise HipError('`out` must be float32 of shape (N, H/16, W/16, 128)')
         _check(_native.hip().eae_hip_encode(self._handle, _p(images_u8), n, h, wd, _p(latents), _p(scratch), nbytes, _stream(images_u8)),
                'eae_hip_encode')
         self._track(scratch)
         return latents
 
-    def decode(self, quantized_latents, want_f32=False, want_u8=True, ref_u8=None, sse=None):
+    def decode(self, quantized_latents, want_f32=False, want_u8=True, ref_u8=None, sse=None, out_u8=None):
         """f32 [N,h,w,128] (device) -> (f32 [N,16h,16w] or None, uint8 or None, sse or None): `sess.run(node_reconstruction)` +
-        `tls.cast_bt601` of eae/batching.py:49-53 (+ the squared error of tls.psnr_2d) in one call."""
+        `tls.cast_bt601` of eae/batching.py:49-53 (+ the squared error of tls.psnr_2d) in one call. out_u8: a contiguous uint8
+        tensor of N x 16h x 16w elements to write the reconstruction into."""
         (n, h, wd, c) = quantized_latents.shape
         d = quantized_latents.device
         if d != self.device:
@@ -154,7 +158,10 @@ class Model(object):
         nbytes = int(_native.hip().eae_hip_decode_scratch_bytes(n, h, wd))
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=d)
         out_f32 = torch.empty((n, 16*h, 16*wd), dtype=torch.float32, device=d) if want_f32 else None
-        out_u8 = torch.empty((n, 16*h, 16*wd), dtype=torch.uint8, device=d) if want_u8 else None
+        if out_u8 is not None and (out_u8.dtype != torch.uint8 or out_u8.numel() != n*16*h*16*wd):
+            raise HipError('`out_u8` must hold N x 16h x 16w uint8 elements')
+        if out_u8 is None:
+            out_u8 = torch.empty((n, 16*h, 16*wd), dtype=torch.uint8, device=d) if want_u8 else None
         if ref_u8 is not None and sse is None:
             sse = torch.zeros(n, dtype=torch.int64, device=d)
         _check(_native.hip().eae_hip_decode(self._handle, _p(quantized_latents), n, h, wd, _p(out_f32), _p(out_u8), _p(ref_u8), _p(sse),

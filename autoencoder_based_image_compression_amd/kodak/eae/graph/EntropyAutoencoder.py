@@ -63,6 +63,17 @@ class EntropyAutoencoder(object):
         """Device-resident entry (no host copies): uint8 [N,H,W] tensor -> float32 latents tensor."""
         return self._encoder(luminances_uint8_device)
 
+    def encode_device_into(self, luminances_uint8_device, latents_device):
+        """One mini-batch on the device: uint8 [batch,H,W,1] tensor -> `latents_device` float32 [batch,H/16,W/16,128]
+        (`eae.batching.encode_mini_batches` calls this per mini-batch; what `sess.run(node_y)` computes, eae/batching.py:96-99)."""
+        if self._encoder is None:
+            raise RuntimeError('Attempting to use uninitialized value encoder/weights_1: call `initialization` first.')
+        self._encoder(luminances_uint8_device, out=latents_device)
+
+    def check(self):
+        """Waits for the launches issued so far and raises if one of them left tiles unfinished (device.Model.check)."""
+        self._encoder.check()
+
     def get_bin_widths(self):
         """Quantization bin widths, 1D `numpy.float32` (:398-409)."""
         if self._variables is None:
@@ -81,11 +92,13 @@ class EntropyAutoencoder(object):
         else:
             self._variables = var.random_variables(self.bin_width_init, self.are_bin_widths_learned, seed=seed)
         self._encoder = pipeline.DeviceEncoder(self._variables, self.are_bin_widths_learned, bk.device())
+        self._encoder.model           # `Saver.restore` puts the variables in place here (:454-458), not at the first `sess.run`
 
     def set_variables(self, variables):
         """Installs variables given as a dict keyed by the TF names (used by tests and by drivers holding weights in memory)."""
         self._variables = dict(variables)
         self._encoder = pipeline.DeviceEncoder(self._variables, self.are_bin_widths_learned, bk.device())
+        self._encoder.model
 
     def save(self, sess, path_to_model, path_to_nb_itvs_per_side_save):
         """Saves the variables (`.npz`) and the number of unit intervals (:465-482)."""

@@ -38,6 +38,17 @@ class IsolatedDecoder(object):
                                             reference_uint8=reference_uint8_device, sse=sse)
         return (rec_uint8, sse)
 
+    def decode_device_into(self, quantized_y_device, reconstruction_uint8_device):
+        """One mini-batch on the device: float32 [batch,h,w,128] tensor -> `reconstruction_uint8_device` uint8 [batch,16h,16w,1],
+        clipped to BT.601 and rounded (`sess.run(node_reconstruction)` + `tls.cast_bt601`, eae/batching.py:49-53, in one call)."""
+        if self._decoder is None:
+            raise RuntimeError('Attempting to use uninitialized value decoder/weights_4: call `initialization` first.')
+        self._decoder(quantized_y_device, want_float=False, want_uint8=True, out_uint8=reconstruction_uint8_device)
+
+    def check(self):
+        """Waits for the launches issued so far and raises if one of them left tiles unfinished (device.Model.check)."""
+        self._decoder.check()
+
     def initialization(self, sess, path_to_restore, seed=None):
         """Either initializes all variables or restores a previous model (:109-129)."""
         if path_to_restore:
@@ -45,7 +56,9 @@ class IsolatedDecoder(object):
         else:
             self._variables = var.random_variables(1., self.are_bin_widths_learned, seed=seed)
         self._decoder = pipeline.DeviceDecoder(self._variables, self.are_bin_widths_learned, bk.device())
+        self._decoder.model           # the variables go to the device here, like `Saver.restore` (:123-124)
 
     def set_variables(self, variables):
         self._variables = dict(variables)
         self._decoder = pipeline.DeviceDecoder(self._variables, self.are_bin_widths_learned, bk.device())
+        self._decoder.model

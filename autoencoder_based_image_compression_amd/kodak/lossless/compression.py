@@ -74,10 +74,9 @@ def code_planar_symbols(symbols_planar, binary_probabilities, idx_map_exception=
     return (reconstruction, nb_bits.reshape(nb_images, nb_maps))
 
 
-def code_planar_symbols_device(symbols_planar, binary_probabilities, idx_map_exception=-1, want_reconstruction=False):
-    """`code_planar_symbols` for symbols that are already on the device (torch int16 (nb_images, nb_maps, map_size)):
-    encode, decode and compare without leaving HBM. Returns (reconstruction device tensor or None, nb_bits uint32 numpy
-    (nb_images, nb_maps)); raises exactly like `code_planar_symbols`."""
+def _launch_planar_symbols_device(symbols_planar, binary_probabilities, idx_map_exception, want_reconstruction):
+    """The launches of `code_planar_symbols_device`, nothing waited for: (reconstruction device tensor or None, int32 device
+    tensor [4, nb_images*nb_maps]: arithmetic-coded bits, bypass bits, status, stage of every map)."""
     import torch
     (nb_images, nb_maps, map_size) = symbols_planar.shape
     probabilities = numpy.ascontiguousarray(binary_probabilities, dtype=numpy.float64)
@@ -106,14 +105,60 @@ def code_planar_symbols_device(symbols_planar, binary_probabilities, idx_map_exc
     else:
         dev.coder_decode_batch(streams, probabilities_device, prob_row_device, expected=symbols)
         (final, stage) = (streams.status, streams.stage)
-    host = torch.stack([encode_results[0], encode_results[1], final, stage]).cpu().numpy()      # the one device -> host copy
-    bad = numpy.flatnonzero(host[2])
-    if bad.size and int(host[2, bad[0]]) == 6:
+    return (reconstruction, torch.stack([encode_results[0], encode_results[1], final, stage]))
+
+
+def _raise_for_maps(status, stage):
+    """Raises what the reference raises for the first map (in map order) whose coder status is not 0."""
+    bad = numpy.flatnonzero(status)
+    if bad.size and int(status[bad[0]]) == 6:
         raise AssertionError('\nArrays are not equal\nThe lossless compression has altered the centered quantized data.')
     if bad.size:
-        interface_cython.raise_for_status(int(host[2, bad[0]]), int(host[3, bad[0]]))
+        interface_cython.raise_for_status(int(status[bad[0]]), int(stage[bad[0]]))
+
+
+def code_planar_symbols_device(symbols_planar, binary_probabilities, idx_map_exception=-1, want_reconstruction=False):
+    """`code_planar_symbols` for symbols that are already on the device (torch int16 (nb_images, nb_maps, map_size)):
+    encode, decode and compare without leaving HBM. Returns (reconstruction device tensor or None, nb_bits uint32 numpy
+    (nb_images, nb_maps)); raises exactly like `code_planar_symbols`."""
+    (nb_images, nb_maps, _) = symbols_planar.shape
+    (reconstruction, results) = _launch_planar_symbols_device(symbols_planar, binary_probabilities, idx_map_exception, want_reconstruction)
+    host = results.cpu().numpy()      # the one device -> host copy
+    _raise_for_maps(host[2], host[3])
     nb_bits = (host[0].astype(numpy.int64) + host[1].astype(numpy.int64)).astype(numpy.uint32)
     return (reconstruction, nb_bits.reshape(nb_images, nb_maps))
+
+
+def _resident_lossless_costs(record, bin_widths_test, binary_probabilities, idx_map_exception):
+    """`rescale_compress_lossless_maps` for EVERY image of a published batch of centred-quantised latents, on its device copy,
+    at the first call that is handed one of its images (the reference's harness asks for all of them in turn,
+    reconstructing_eae_kodak.py:212-218): one symbol pass, one coder round trip over all the maps of the batch, one histogram
+    pass over its exception maps, one device -> host copy. Kept with the batch per (bin widths, probabilities, exception index).
+    Returns {'status', 'stage', 'nb_bits' [N, C], 'exception_hist' [N, bins] or None} -- or None when one of the checks that the
+    image-by-image path makes before / after coding would not pass for the batch as a whole: the caller then takes that path,
+    which raises for exactly the image concerned."""
+    import torch
+    key = ('lossless_costs', bin_widths_test.astype(numpy.float32).tobytes(), binary_probabilities.tobytes(), binary_probabilities.shape,
+           int(idx_map_exception))
+    if key not in record.extras:
+        tensor = record.tensor
+        (n, c) = (tensor.shape[0], tensor.shape[3])
+        res = dev.quantize_maps(tensor.view(n, -1, c), bk.to_device(bin_widths_test, numpy.float32), None, want_symbols=True)
+        (_, results) = _launch_planar_symbols_device(res['symbols'], binary_probabilities, idx_map_exception, False)
+        pieces = [res['checks'], results.reshape(-1)]
+        has_exception = 0 <= idx_map_exception < c
+        if has_exception:
+            (hist, overflow) = dev.symbol_histograms(res['symbols'].view(n*c, -1), tls._FIRST_RADIUS, first_map=idx_map_exception, map_step=c)
+            pieces += [overflow, hist.reshape(-1)]
+        host = torch.cat(pieces).cpu().numpy()                                   # the one device -> host copy
+        (checks, results_host) = (host[:3], host[3:3 + 4*n*c].reshape(4, n, c))
+        costs = None
+        if checks[0] == 0 and checks[2] == 0 and not (has_exception and host[3 + 4*n*c:3 + 4*n*c + n].any()):
+            costs = {'status': results_host[2], 'stage': results_host[3],
+                     'nb_bits': (results_host[0].astype(numpy.int64) + results_host[1].astype(numpy.int64)).astype(numpy.uint32),
+                     'exception_hist': host[3 + 4*n*c + n:].reshape(n, -1).astype(numpy.int64) if has_exception else None}
+        record.extras[key] = costs
+    return record.extras[key]
 
 
 def exception_map_nb_bits(hist_row, map_size):
@@ -177,6 +222,17 @@ def rescale_compress_lossless_maps(centered_quantized_data, bin_widths_test, pat
         raise ValueError('`binary_probabilities.ndim` is not equal to 2.')
     if binary_probabilities.shape[0] != nb_maps:
         raise ValueError('`binary_probabilities.shape[0]` is not equal to `ref_int16.shape[2]`.')
+    batch = tls._image_of_published_batch(centered_quantized_data) if centered_quantized_data.dtype == numpy.float32 else None
+    if batch is not None:
+        # image j of a batch `tls.quantize_per_map` returned: the whole batch is coded once, on its device copy
+        costs = _resident_lossless_costs(batch[0], bin_widths_test, binary_probabilities, idx_map_exception)
+        if costs is not None:
+            j = batch[1]
+            _raise_for_maps(costs['status'][j], costs['stage'][j])
+            nb_bits_each_map = costs['nb_bits'][j].copy()
+            if costs['exception_hist'] is not None:
+                nb_bits_each_map[idx_map_exception] = exception_map_nb_bits(costs['exception_hist'][j], height_map*width_map)
+            return numpy.sum(nb_bits_each_map).item()
     # compression.py:142 on the device: int16(round(cq / bw)), map-major; checks[0] is the int16 assertion of
     # tools.py:130-132, checks[2] the final `assert_equal` of compression.py:149-153 (symbol*bw must give cq back).
     res = dev.quantize_maps(bk.to_device(centered_quantized_data[None], numpy.float32), bk.to_device(bin_widths_test, numpy.float32),

@@ -58,8 +58,6 @@ class Session(object):
 
 
 def reset_default_graph():
-    """The reference tears the TF graph down between the encoder and the decoder (:154, :235); nothing to free here
-    beyond letting the caching allocator reuse the previous model's buffers."""
-    import torch
-    if torch.cuda.is_available():
-        torch.cuda.empty_cache()
+    """The reference tears the TF graph down between the encoder and the decoder (:154, :235). There is no graph here and
+    nothing to tear down: a model's buffers go back to torch's caching allocator when its object dies, and the next model
+    reuses them (handing them back to the driver with `empty_cache()` only made the next allocations slow)."""

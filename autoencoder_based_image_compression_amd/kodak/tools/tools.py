@@ -91,7 +91,11 @@ def count_nb_deads(array_4d):
     """Number of dead feature maps (sum of absolute values exactly 0) per first-axis component (tools.py:294-320)."""
     if array_4d.ndim != 4:
         raise ValueError('`array_4d.ndim` is not equal to 4.')
-    flags = bk.to_host(dev.nonzero_flags(bk.to_device(array_4d, numpy.float32)))
+    found = bk.resident(array_4d)
+    if found is not None and found[1] == 0 and 'nonzero_flags' in found[0].extras and array_4d.shape == tuple(found[0].tensor.shape):
+        flags = bk.to_host(found[0].extras['nonzero_flags'])        # the array `quantize_per_map` returned: counted in that pass
+    else:
+        flags = bk.to_host(dev.nonzero_flags(bk.to_device(array_4d, numpy.float32)))
     return numpy.sum(flags == 0, axis=1)
 
 
@@ -186,6 +190,66 @@ def _map_entropies(quantized, bin_widths, planar=False):
     return entropies
 
 
+def _image_of_published_batch(array_3d):
+    """If `array_3d` (h, w, C) is image j of a 4-D array a function of this package returned (`cq[j, :, :, :]` in the reference's
+    harness, reconstructing_eae_kodak.py:214-223): (its `_backend.Resident`, j), else None."""
+    found = bk.resident(array_3d)
+    if found is None:
+        return None
+    (record, first) = found
+    tensor = record.tensor
+    if tensor.dim() != 4 or tuple(tensor.shape[1:]) != array_3d.shape or first % array_3d.size != 0 or tensor.device != bk.device():
+        return None
+    return (record, first//array_3d.size)
+
+
+def _entropies_from_hist_rows(hist_rows):
+    """`_entropy_from_hist` (tools.py:523-537) of every row of `hist_rows` (int64 [C, bins]) -> float64 [C], bit for bit: the
+    element-wise steps (counts / total, f*log2(f)) run once over the non-empty bins of all rows (element-wise results do not
+    depend on where an element sits in its array), the sum of each row's terms is `numpy.sum` over that row's own contiguous run
+    (numpy's pairwise order depends on the length only), and a row whose entropy comes within 1e-9 of a bound goes through the
+    verbatim function so that its two comparisons see the reference's own scalars."""
+    nonzero = hist_rows != 0
+    lengths = nonzero.sum(axis=1)
+    counts = hist_rows[nonzero]                                     # row-major: each row's non-empty bins, ascending
+    frequency = counts.astype(numpy.float64)/numpy.repeat(hist_rows.sum(axis=1), lengths)
+    terms = frequency*numpy.log2(frequency)
+    bounds = numpy.concatenate(([0], numpy.cumsum(lengths))).tolist()
+    entropies = numpy.empty(hist_rows.shape[0])
+    total = numpy.sum
+    for i in range(hist_rows.shape[0]):
+        entropies[i] = -total(terms[bounds[i]:bounds[i + 1]])
+    suspicious = numpy.flatnonzero((entropies < 1.e-9) | (entropies > numpy.log2(lengths) - 1.e-9))
+    for i in suspicious.tolist():
+        entropies[i] = _entropy_from_hist(hist_rows[i, nonzero[i]])
+    return entropies
+
+
+def _resident_symbol_histograms(record, bin_widths):
+    """Symbols and per-map histograms of EVERY image of a published batch of quantised latents, computed on the device copy at
+    the first call that asks for one of its images and kept with it: host int64 [N, C, 2R+1] (R = `_FIRST_RADIUS`), or None
+    when a check of `_quantized_to_symbols` / `_symbol_histograms` would not pass for the batch as a whole -- the caller then
+    takes the image-by-image path, which raises (or widens the histogram) for exactly the image concerned."""
+    key = ('symbol_histograms', numpy.asarray(bin_widths, dtype=numpy.float32).tobytes())
+    if key not in record.extras:
+        tensor = record.tensor
+        (n, c) = (tensor.shape[0], tensor.shape[3])
+        res = dev.quantize_maps(tensor.view(n, -1, c), bk.to_device(numpy.asarray(bin_widths, dtype=numpy.float32)), None, want_symbols=True)
+        (hist, overflow) = dev.symbol_histograms(res['symbols'], _FIRST_RADIUS)
+        state = torch_cat_to_host(res['checks'], overflow)
+        if state[:3].any() or state[3:].any():
+            record.extras[key] = None
+        else:
+            record.extras[key] = bk.to_host(hist).astype(numpy.int64).reshape(n, c, -1)
+    return record.extras[key]
+
+
+def torch_cat_to_host(*tensors):
+    """Several small int32 device tensors -> one host array, one device -> host copy."""
+    import torch
+    return torch.cat([t.reshape(-1) for t in tensors]).cpu().numpy()
+
+
 def float_to_str(float_in):
     """Converts the float into a string, "." -> "dot", "-" -> "minus" (tools.py:570-593)."""
     if float_in.is_integer():
@@ -254,8 +318,11 @@ def quantize_per_map(data, bin_widths):
         raise ValueError('A quantization bin width is not strictly positive.')
     if data.size == 0:
         return numpy.zeros(data.shape, dtype=numpy.float32)
-    res = dev.quantize_maps(bk.to_device(data, numpy.float32), bk.to_device(bin_widths, numpy.float32), None, want_cq=True)
-    return bk.to_host(res['cq'])
+    # one pass: the quantised values and, for `count_nb_deads` on the returned array, which maps have a non-zero value
+    res = dev.quantize_maps(bk.to_device(data, numpy.float32), bk.to_device(bin_widths, numpy.float32), None, want_cq=True, want_flags=True)
+    (quantized, record) = bk.publish(res['cq'])
+    record.extras['nonzero_flags'] = res['nonzero_flags']
+    return quantized
 
 
 def rate_3d(quantized_latent_float32, bin_widths, h_in, w_in):
@@ -265,6 +332,12 @@ def rate_3d(quantized_latent_float32, bin_widths, h_in, w_in):
     (height_map, width_map, nb_maps) = quantized_latent_float32.shape
     if bin_widths.size != nb_maps:
         raise ValueError('`bin_widths.size` is not equal to `quantized_latent_float32.shape[2]`.')
+    batch = _image_of_published_batch(quantized_latent_float32) if quantized_latent_float32.dtype == numpy.float32 else None
+    if batch is not None and not numpy.any(numpy.asarray(bin_widths) <= 0.):
+        # image j of a batch `quantize_per_map` returned: the histograms of the whole batch are taken once, on its device copy
+        histograms = _resident_symbol_histograms(batch[0], bin_widths)
+        if histograms is not None:
+            return rate_from_entropies(_entropies_from_hist_rows(histograms[batch[1]]), height_map, width_map, h_in, w_in)
     entropies = _map_entropies(numpy.ascontiguousarray(quantized_latent_float32, dtype=numpy.float32).reshape(1, -1, nb_maps),
                                numpy.asarray(bin_widths, dtype=numpy.float32))
     return rate_from_entropies(entropies[0], height_map, width_map, h_in, w_in)

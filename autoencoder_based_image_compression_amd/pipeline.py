@@ -50,8 +50,8 @@ class DeviceEncoder(object):
         if self._model is not None:
             self._model.check(wait=True)
 
-    def __call__(self, luminances_uint8):
-        """uint8 [N,H,W] or [N,H,W,1] (device) -> float32 latents [N,H/16,W/16,128] (device)."""
+    def __call__(self, luminances_uint8, out=None):
+        """uint8 [N,H,W] or [N,H,W,1] (device) -> float32 latents [N,H/16,W/16,128] (device); `out`: tensor to write them into."""
         if luminances_uint8.dtype != torch.uint8:
             raise TypeError('`luminances_uint8.dtype` is not equal to `torch.uint8`.')
         (h_in, w_in) = (luminances_uint8.shape[1], luminances_uint8.shape[2])
@@ -61,7 +61,7 @@ class DeviceEncoder(object):
             raise ValueError('The width of the input images is not divisible by the product of the three strides.')
         if luminances_uint8.dim() == 4:
             luminances_uint8 = luminances_uint8[:, :, :, 0]
-        return self.model.encode(luminances_uint8.contiguous())
+        return self.model.encode(luminances_uint8.contiguous(), out=out)
 
 
 class DeviceDecoder(object):
@@ -93,9 +93,10 @@ class DeviceDecoder(object):
         if self._model is not None:
             self._model.check(wait=True)
 
-    def __call__(self, quantized_y, want_float=False, want_uint8=True, reference_uint8=None, sse=None):
+    def __call__(self, quantized_y, want_float=False, want_uint8=True, reference_uint8=None, sse=None, out_uint8=None):
         """float32 [N,h,w,128] (device) -> (float32 [N,16h,16w] or None, uint8 [N,16h,16w] or None, sse or None)."""
-        return self.model.decode(quantized_y.contiguous(), want_f32=want_float, want_u8=want_uint8, ref_u8=reference_uint8, sse=sse)
+        return self.model.decode(quantized_y.contiguous(), want_f32=want_float, want_u8=want_uint8, ref_u8=reference_uint8, sse=sse,
+                                 out_u8=out_uint8)
 
 
 # Algorithmic work per INPUT pixel of each launch (SURVEY.md 8(d), BASELINE.md section 2), fixed-bin-width model.

@@ -417,3 +417,123 @@ def test_create_kodak_ingests_the_png_files(tmp_path, tls, capsys):
     with pytest.raises(IOError):
         kodak.create_kodak('http://127.0.0.1:9/nowhere/', folder, path_to_kodak, path_to_list_rotation)
     assert not os.path.isfile(path_to_kodak)
+
+
+# ---- what one call returned stays resident for the next (kodak/_backend.py): same results, fewer copies ------------------------
+
+def _resident_case(cgold, nb_images=3):
+    rng = numpy.random.RandomState(77)
+    data = (rng.standard_normal((nb_images, 4, 6, 128))*2.).astype(numpy.float32)
+    bw = numpy.linspace(0.5, 1.5, 128).astype(numpy.float32)
+    return (data, bw, cgold['real_probabilities_1'].copy())
+
+
+def test_resident_path_equals_the_image_by_image_path(tmp_path, tls, cgold):
+    """`rate_3d(cq[j])`, `rescale_compress_lossless_maps(cq[j])`, `count_nb_deads(cq)` and `psnr_2d(.., rec[j])` on arrays this
+    package returned take the batch's device copy (counted in `_backend.statistics`); on private copies of the same arrays they
+    upload image by image: identical values, identical exceptions, for the image concerned only."""
+    from autoencoder_based_image_compression_amd.kodak import _backend as bk
+    from autoencoder_based_image_compression_amd.kodak.lossless import compression
+    (data, bw, probabilities) = _resident_case(cgold, 4)
+    data[1, 0, 0, 5] = 40000.*bw[5]          # image 1: a symbol outside int16 (AssertionError in rescale, ValueError in rate_3d)
+    data[2, 1, 1, 9] = 700.*bw[9]            # image 2: a symbol outside the first histogram radius (rate_3d widens it)
+    path = str(tmp_path/'binary_probabilities.npy')
+    numpy.save(path, probabilities)
+    cq = tls.quantize_per_map(data, bw)
+    assert not cq.flags.writeable and bk.resident(cq) is not None
+    private = cq.copy()
+    assert numpy.array_equal(tls.count_nb_deads(cq), tls.count_nb_deads(private))
+    hits = bk.statistics['hits']
+    for j in range(4):
+        for fn in (lambda a: tls.rate_3d(a, bw, 64, 96), lambda a: compression.rescale_compress_lossless_maps(a, bw, path, 67),
+                   lambda a: compression.rescale_compress_lossless_maps(a, bw, path)):
+            try:
+                expected = fn(private[j, :, :, :])
+            except (AssertionError, ValueError) as exc:
+                with pytest.raises(type(exc)) as info:
+                    fn(cq[j, :, :, :])
+                assert str(info.value) == str(exc) and j == 1
+            else:
+                got = fn(cq[j, :, :, :])
+                assert got == expected and type(got) is type(expected)
+    assert bk.statistics['hits'] > hits
+    # a second bin-width vector on the same batch is a different entry of the batch's record, not a stale one
+    assert tls.rate_3d(cq[0], 2.*bw, 64, 96) == tls.rate_3d(private[0], 2.*bw, 64, 96)
+    # PSNR: the reconstruction is resident, the reference is the caller's own array
+    rec = numpy.random.RandomState(3).randint(16, 236, size=(2, 32, 48, 1)).astype(numpy.uint8)
+    import torch
+    (published, _) = bk.publish(torch.from_numpy(rec).cuda())
+    ref = numpy.random.RandomState(4).randint(16, 236, size=(2, 32, 48)).astype(numpy.uint8)
+    for j in range(2):
+        assert tls.psnr_2d(ref[j], numpy.squeeze(published, axis=3)[j, :, :]) == tls.psnr_2d(ref[j], rec[j, :, :, 0].copy())
+
+
+def test_a_returned_array_that_was_written_to_is_uploaded_again(tls, cgold):
+    from autoencoder_based_image_compression_amd.kodak import _backend as bk
+    (data, bw, _) = _resident_case(cgold)
+    cq = tls.quantize_per_map(data, bw)
+    with pytest.raises(ValueError):
+        cq[0] = 0.                              # read-only: the one visible difference from the reference's arrays
+    cq.flags.writeable = True                   # the owner may lift it ...
+    cq[0] = 0.
+    assert bk.resident(cq) is None              # ... and the device copy is never trusted again
+    assert list(tls.count_nb_deads(cq)) == [128] + list(tls.count_nb_deads(cq[1:].copy()))
+    assert tls.rate_3d(cq[0], bw, 64, 96) == 0.
+
+
+def test_surface_without_resident_copies_gives_the_same_arrays(tmp_path, tls, monkeypatch):
+    """EAE_SURFACE_RESIDENT=0 (here: the module switch): plain writable arrays, every call uploads; same harness outputs."""
+    import harness_cases
+    from autoencoder_based_image_compression_amd.kodak import _backend as bk
+    from autoencoder_based_image_compression_amd.kodak import reconstructing_eae_kodak as rk
+    golden = _harness_golden()
+    case = harness_cases.fix_gamma_case(False)
+    _write_model(str(tmp_path), case['suffix'], case['idx_training'], case['variables'], case['map_mean'], case['idx_map_exception'],
+                 case['probabilities'], case['multipliers'], tls, layout='npz')
+    monkeypatch.setattr(bk, 'RESIDENT_ENABLED', False)
+    assert tls.quantize_per_map(numpy.ones((1, 2, 2, 128), dtype=numpy.float32), numpy.ones(128, dtype=numpy.float32)).flags.writeable
+    for is_lossless in (True, False):
+        (rate, psnr, nb_deads) = rk.fix_gamma(case['images'], case['bin_width_init'], case['multipliers'], case['idx_training'],
+                                              case['gamma_scaling'], case['batch_size'], False, is_lossless, root=str(tmp_path),
+                                              return_nb_deads=True)
+        tag = 'fix_gamma_fixed_{}'.format('lossless' if is_lossless else 'approx')
+        assert numpy.array_equal(rate, golden[tag + '_rate']) and numpy.array_equal(psnr, golden[tag + '_psnr'])
+        assert numpy.array_equal(nb_deads, golden[tag + '_nb_deads'])
+
+
+def test_mini_batches_may_be_handed_to_the_device_together(tls, monkeypatch):
+    """The set cut into launches of one mini-batch, of several, or fetched through `sess.run` mini-batch by mini-batch like the
+    reference: the same latents and reconstructions, bit for bit (eae/batching.py: `_launches`)."""
+    import harness_cases
+    from autoencoder_based_image_compression_amd.kodak import tf_shim as tf
+    from autoencoder_based_image_compression_amd.kodak.eae import batching
+    from autoencoder_based_image_compression_amd.kodak.eae.graph.EntropyAutoencoder import EntropyAutoencoder
+    from autoencoder_based_image_compression_amd.kodak.eae.graph.IsolatedDecoder import IsolatedDecoder
+    variables = harness_cases.random_variables(1., False, 5)
+    x = numpy.random.RandomState(6).randint(16, 236, size=(6, 32, 48, 1)).astype(numpy.uint8)
+    ae = EntropyAutoencoder(2, 32, 48, 1., 10000., '', False)
+    dec = IsolatedDecoder(2, 32, 48, False)
+    ae.set_variables(variables)
+    dec.set_variables(variables)
+
+    class OnlyNodes(object):          # what any other object with the two nodes gets: the reference's loop over `sess.run`
+        def __init__(self, model, names):
+            for name in names:
+                setattr(self, name, getattr(model, name))
+    with tf.Session() as sess:
+        together = batching.encode_mini_batches(x, sess, ae, 2)
+        through_session = batching.encode_mini_batches(x, sess, OnlyNodes(ae, ('node_visible_units', 'node_y')), 2)
+        monkeypatch.setattr(batching, '_PIXELS_PER_LAUNCH', 1)
+        one_by_one = batching.encode_mini_batches(x, sess, ae, 2)
+        assert numpy.array_equal(together, through_session) and numpy.array_equal(together, one_by_one)
+        q = tls.quantize_per_map(together, numpy.ones(128, dtype=numpy.float32))
+        rec_one_by_one = batching.decode_mini_batches(q, sess, dec, 2)
+        monkeypatch.undo()
+        rec_together = batching.decode_mini_batches(q, sess, dec, 2)
+        rec_session = batching.decode_mini_batches(q, sess, OnlyNodes(dec, ('node_quantized_y', 'node_reconstruction')), 2)
+        assert rec_together.dtype == numpy.uint8 and rec_together.shape == (6, 32, 48, 1)
+        assert numpy.array_equal(rec_together, rec_one_by_one) and numpy.array_equal(rec_together, rec_session)
+        with pytest.raises(ValueError):
+            batching.decode_mini_batches(q, sess, dec, 4)                      # 6 % 4
+        with pytest.raises(ValueError):
+            batching.decode_mini_batches(q, sess, dec, 3)                      # the placeholder holds mini-batches of 2

@@ -458,7 +458,7 @@ def test_resident_path_equals_the_image_by_image_path(tmp_path, tls, cgold):
                 assert got == expected and type(got) is type(expected)
     assert bk.statistics['hits'] > hits
     # a second bin-width vector on the same batch is a different entry of the batch's record, not a stale one
-    assert tls.rate_3d(cq[0], 2.*bw, 64, 96) == tls.rate_3d(private[0], 2.*bw, 64, 96)
+    assert tls.rate_3d(cq[0], 0.5*bw, 64, 96) == tls.rate_3d(private[0], 0.5*bw, 64, 96)        # (multiples of bw are multiples of bw/2)
     # PSNR: the reconstruction is resident, the reference is the caller's own array
     rec = numpy.random.RandomState(3).randint(16, 236, size=(2, 32, 48, 1)).astype(numpy.uint8)
     import torch

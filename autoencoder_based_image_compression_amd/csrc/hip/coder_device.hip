@@ -15,9 +15,12 @@
 
 // gfx950: a 64-bit shift (v_lshlrev_b64 / v_lshrrev_b64 / v_ashrrev_i64) whose shift amount sits in the LAST register of the wave's VGPR
 // allocation gives wrong results whenever other waves share the SIMD (csrc/isa_guard.py rule 2, DESIGN.md section 5: the fault of
-// round 3's first decoder core). These kernels shift 64-bit windows by computed amounts, so each instantiation names the last register
-// of ITS OWN allocation in an empty asm (see coder_simd.hip for why not v63 everywhere): nobody's operand. The guard checks the
-// shipped ISA whatever this does; tests/test_isa_guard.py pins the allocations.
+// round 3's first decoder core). These kernels shift 64-bit windows by computed amounts, so each instantiation names a register just
+// above what it needs in an empty asm at kernel entry (see coder_simd.hip for why not v63 everywhere). That only PADS the allocation
+// (next_free_vgpr becomes n + 1 and vn is dead across that one point): it does not forbid the allocator to use vn later, and it
+// works because the kernels' pressure stays below n. The ENFORCEMENT is csrc/isa_guard.py rule 2 on the shipped ISA -- run by
+// build() and, whatever build() was told to skip, by tests/test_isa_guard.py::test_the_shipped_library_is_clean on the library that
+// ships; tests/test_isa_guard.py also pins the allocations, so that one more live value shows up as a red test, not as wrong bits.
 #ifndef EAE_DECODE_TOPUP_ZEROS
 #define EAE_KEEP_VGPR_FREE(n) asm volatile("; v" #n " reserved: the last register of the allocation holds no operand" ::: "v" #n)
 #else      // the first decoder core is kept as it was built (40 of 40 registers): scratch/r04, tests/test_isa_guard.py

@@ -429,7 +429,7 @@ int try_split(ConvGemmParams& p, hipStream_t stream) {
 }
 
 int launch(ConvGemmParams& p, hipStream_t stream) {
-    // EAE_HIP_GEMM (read per launch: the parity tests run every form and compare bits):
+    // EAE_HIP_GEMM (read ONCE at library load, misc.hip; the parity tests of every form call eae_hip_debug_reload_launch_options):
     //   unset  conv_gemm_split.hip (one item per wave; the last tiles cut when the shape calls for it and the caller gave a
     //          workspace) for layers with at least one 32-position tile per SIMD, the small-layer forms below otherwise;
     //   's'    conv_gemm_split.hip with the cut forced, sized for EAE_HIP_SPLIT_WAVES (1..3, default 3) waves per SIMD;

@@ -1,14 +1,18 @@
 // misc.hip -- library identity and device probing.
 #include "common.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
 // ---- kernel-form overrides: the environment is read here, once per library load (and on a test's explicit request) ----
+// g_eae_launch_options is a plain global: the two eae_hip_debug_* setters below are TEST HOOKS, to be called from the one thread
+// that launches, with nothing in flight (tests/conftest.py: launch_options); a deployment never calls them, so launches only read.
 static EaeLaunchOptions read_launch_options() {
     EaeLaunchOptions o{};
     const char* e = std::getenv("EAE_HIP_GEMM");
     o.gemm = e && (e[0] == 's' || e[0] == 'u' || e[0] == 'w' || e[0] == 'l') ? e[0] : 0;
+    if (e && e[0] && !o.gemm) std::fprintf(stderr, "libeae_hip: EAE_HIP_GEMM=%s is none of s / u / w / l: ignored (form chosen by shape)\n", e);
     e = std::getenv("EAE_HIP_SPLIT_WAVES");
     o.split_waves = e ? std::atoi(e) : 3;
     if (o.split_waves < 1 || o.split_waves > 3) o.split_waves = 3;

@@ -43,6 +43,19 @@ def parse_args(argv=None):
                         help='quantisation bin width of the headline run (1.0: BASELINE.json configs[1]). Random-init weights '
                              'give a low-entropy latent at 1.0; the `realistic_entropy` side figures repeat the run at smaller '
                              'widths (more bits per pixel for the coder)')
+    parser.add_argument('--kodak-npy', default=None, metavar='PATH',
+                        help='real images instead of synthetic ones: the array `datasets/kodak/kodak.py:66-83` of the reference writes '
+                             '(`kodak.npy`: uint8 (24, 512, 768) luminances; any uint8 (N, H, W) with H, W multiples of 16 is accepted). '
+                             '--batch / --height / --width follow the array')
+    parser.add_argument('--checkpoint', default=None, metavar='PATH',
+                        help='a trained model instead of random-init weights: the ".ckpt" prefix `Saver.restore` takes '
+                             '(eae/graph/EntropyAutoencoder.py:452-458; TensorFlow V1 / V2, read without TensorFlow) or an .npz keyed by '
+                             'the TF variable names. --bin-width then multiplies the checkpoint\'s bin widths (reconstructing_eae_kodak.py:184)')
+    parser.add_argument('--learned-bin-widths', action='store_true', help='--checkpoint is a learned-bin-width model (no GDN3 / IGDN4)')
+    parser.add_argument('--stats-dir', default=None, metavar='PATH',
+                        help='the coder\'s statistics instead of ones computed from the first batch: a directory with `map_mean.npy`, '
+                             '`idx_map_exception.pkl` and `binary_probabilities_<multiplier>.npy` (lossless/stats.py:243-320; e.g. the '
+                             'reference\'s lossless/results/1_10000/training_index_10/)')
     parser.add_argument('--no-cpu-baseline', action='store_true')
     parser.add_argument('--no-dropin-surface', action='store_true',
                         help='skip the `dropin_surface` leg (the mirror of the reference\'s fix_gamma through the reference\'s own call '
@@ -136,6 +149,9 @@ if __name__ == '__main__':
 # one-image-per-step leg keeps 14 streams busy). Must be set before the runtime initialises; an explicit setting of the
 # caller wins.
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+# The pool's host driver only supports dmabuf IPC (RCCL's intra-node transport fails in hipIpcGetMemHandle with the legacy mode).
+# ROCr reads this when it initialises, so it is set here, before torch is imported; launch_ranks gives it to its children too.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import numpy          # noqa: E402
 import torch          # noqa: E402
@@ -199,6 +215,40 @@ def auto_coder_streams(h, w):
     return codec.default_nb_in_flight(h, w)
 
 
+def load_inputs(args):
+    """What --kodak-npy / --checkpoint / --stats-dir name, checked like the reference's loaders check it; None where a flag is absent.
+    Returns {'images', 'variables', 'statistics': (map_mean, probabilities, idx_map_exception) or None, 'data': label for the line}."""
+    import pickle
+    out = {'images': None, 'variables': None, 'statistics': None, 'data': 'synthetic'}
+    labels = []
+    if args.kodak_npy:
+        images = numpy.load(args.kodak_npy)
+        if images.dtype != numpy.uint8 or images.ndim != 3:
+            raise SystemExit('bench.py: --kodak-npy must hold uint8 luminances of shape (N, H, W) (datasets/kodak/kodak.py:66-83), '
+                             'not {0} {1}'.format(images.dtype, images.shape))
+        if images.shape[1] % 16 or images.shape[2] % 16:
+            raise SystemExit('bench.py: --kodak-npy: height and width must be multiples of 16 (EntropyAutoencoder.py:77-80)')
+        out['images'] = numpy.ascontiguousarray(images)
+        labels.append('images: {0} ({1} x {2}x{3})'.format(os.path.basename(args.kodak_npy), *images.shape))
+    if args.checkpoint:
+        variables = var.restore_variables(args.checkpoint, bool(args.learned_bin_widths))
+        variables[var.BIN_WIDTHS_NAME] = (args.bin_width*variables[var.BIN_WIDTHS_NAME]).astype(numpy.float32)
+        out['variables'] = variables
+        labels.append('weights: {}'.format(os.path.basename(args.checkpoint)))
+    if args.stats_dir:
+        map_mean = numpy.load(os.path.join(args.stats_dir, 'map_mean.npy'))
+        with open(os.path.join(args.stats_dir, 'idx_map_exception.pkl'), 'rb') as f:
+            idx_map_exception = int(pickle.load(f))
+        probabilities = numpy.load(os.path.join(args.stats_dir, 'binary_probabilities_{}.npy'.format(tls.float_to_str(float(args.bin_width)))))
+        if map_mean.shape != (128,) or probabilities.ndim != 2 or probabilities.shape[0] != 128:
+            raise SystemExit('bench.py: --stats-dir: map_mean.npy must be (128,) and binary_probabilities_*.npy (128, L)')
+        out['statistics'] = (map_mean.astype(numpy.float32), numpy.ascontiguousarray(probabilities, dtype=numpy.float64), idx_map_exception)
+        labels.append('coder statistics: {}'.format(args.stats_dir))
+    if labels:
+        out['data'] = '; '.join(labels) + ('' if (args.kodak_npy and args.checkpoint) else '; the rest synthetic')
+    return out
+
+
 class Context(object):
     """What every leg of the benchmark shares: the process group, the device, the CPU budget."""
 
@@ -206,6 +256,24 @@ class Context(object):
         (self.args, self.device, self.world, self.rank, self.cores) = (args, device, world, rank, cores)
         self.grouped = world > 1 or bool(getattr(args, 'force_nccl', False))      # a process group exists
         self.collectives = 0                                                       # barriers + all-reduces that went through it
+        self.inputs = {'images': None, 'variables': None, 'statistics': None, 'data': 'synthetic'}
+
+    def images(self, seed, batch, h, w):
+        """uint8 (batch, h, w): the caller's images (--kodak-npy) when they have that size and there are enough of them -- every rank
+        then codes the same images --, else the synthetic ones of `seed`."""
+        mine = self.inputs['images']
+        if mine is not None and mine.shape[1:] == (h, w) and mine.shape[0] >= batch:
+            return mine[:batch]
+        return synthetic_images(seed, batch, h, w)
+
+    def statistics(self, y0, bin_widths, use_given=True):
+        """(map_mean, probabilities, idx_map_exception): --stats-dir, else this build's own a26 / a27 path on the first batch's latents
+        (lossless/stats.py:306, :13-68) and the reference model's exception index."""
+        if use_given and self.inputs['statistics'] is not None:
+            return self.inputs['statistics']
+        map_mean_host = dev.map_means(y0).cpu().numpy()
+        probabilities = lossless_stats.compute_binary_probabilities(y0.cpu().numpy(), bin_widths, map_mean_host, TRUNCATED_UNARY_LENGTH)
+        return (map_mean_host, probabilities, IDX_MAP_EXCEPTION)
 
     def barrier(self):
         if self.grouped:
@@ -231,7 +299,8 @@ class Context(object):
 
 
 def run_pipeline(ctx, batch, steps, warmup, variables, h, w, coder='device', coder_streams=3, transform_streams=1, use_graphs=False,
-                 min_seconds=0., max_blocks=1, record=False, coder_events=False, pcie=False, serial=False):
+                 min_seconds=0., max_blocks=1, record=False, coder_events=False, pcie=False, serial=False, given_statistics=True,
+                 statistics=None):
     """Builds the resident state for `batch` images of h x w per step (codec.BatchCodec: weights, tables, per-slot buffers),
     runs `warmup` untimed steps, then BLOCKS of exactly `steps` timed steps -- each block bracketed by barrier + synchronize
     on both sides, its wall time the MAX over ranks -- until `min_seconds` have been timed (at most `max_blocks` blocks; the
@@ -244,16 +313,20 @@ def run_pipeline(ctx, batch, steps, warmup, variables, h, w, coder='device', cod
     latency of one step on an otherwise idle GPU instead of the throughput of the pipeline)."""
     args = ctx.args
     (device, world, rank) = (ctx.device, ctx.world, ctx.rank)
-    images_host = torch.from_numpy(synthetic_images(1000 + rank + args.seed_offset, batch, h, w))
+    images_host = torch.from_numpy(numpy.ascontiguousarray(ctx.images(1000 + rank + args.seed_offset, batch, h, w)))
     images = images_host.to(device)
     bin_widths = variables[var.BIN_WIDTHS_NAME]
-    # statistics that feed the coder, from this build's own a26/a27 path on the first batch (lossless/stats.py:306, :13-68)
-    encoder = pipeline.DeviceEncoder(variables, False, device)
-    y0 = encoder(images)
-    map_mean_host = dev.map_means(y0).cpu().numpy()
-    probabilities = lossless_stats.compute_binary_probabilities(y0.cpu().numpy(), bin_widths, map_mean_host, TRUNCATED_UNARY_LENGTH)
-    encoder.check()
-    del y0, encoder
+    learned = var.ENCODER_NAMES_FIXED_BW[0] not in variables
+    # statistics that feed the coder: the caller's (--stats-dir; `given_statistics` False for the legs at other bin widths, whose
+    # tables the directory does not hold), `statistics` (a leg's own), else from the first batch
+    if statistics is not None:
+        (map_mean_host, probabilities, idx_map_exception) = statistics
+    else:
+        encoder = pipeline.DeviceEncoder(variables, learned, device)
+        y0 = encoder(images)
+        (map_mean_host, probabilities, idx_map_exception) = ctx.statistics(y0, bin_widths, use_given=given_statistics)
+        encoder.check()
+        del y0, encoder
     events = []            # (start, stop, launch name) around every named launch of the timed region
     recording = [False]
 
@@ -269,7 +342,7 @@ def run_pipeline(ctx, batch, steps, warmup, variables, h, w, coder='device', cod
 
     coder_mode = 'none' if os.environ.get('EAE_BENCH_NO_CODER') else coder      # 'none': diagnostic only
     coder_threads = args.coder_threads if args.coder_threads > 0 else max(1, ctx.cores//max(world, 1) - 2)
-    with codec.BatchCodec(variables, False, bin_widths, map_mean_host, probabilities, IDX_MAP_EXCEPTION, batch, h, w,
+    with codec.BatchCodec(variables, learned, bin_widths, map_mean_host, probabilities, idx_map_exception, batch, h, w,
                           device=device, nb_in_flight=coder_streams, launch_hook=timed_launch if record else None,
                           coder=coder_mode, host_coder_threads=coder_threads, nb_transform_streams=transform_streams,
                           use_graphs=use_graphs, time_coder=coder_events, fuse_latent=args.fuse_latent,
@@ -334,7 +407,7 @@ def run_pipeline(ctx, batch, steps, warmup, variables, h, w, coder='device', cod
     cpu_ms[rank] = block_cpu[mid]/steps*1e3
     ctx.all_reduce(cpu_ms, 'SUM')
     return {'elapsed': block_seconds[mid], 'block_seconds': block_seconds, 'stats': stats, 'events': events,
-            'probabilities': probabilities, 'map_mean_host': map_mean_host, 'host_coder': coder_mode == 'host',
+            'probabilities': probabilities, 'map_mean_host': map_mean_host, 'idx_map_exception': idx_map_exception, 'host_coder': coder_mode == 'host',
             'coder_threads': coder_threads, 'coder_ms': coder_ms, 'host_cpu_ms_per_step': [round(float(v), 4) for v in cpu_ms.tolist()]}
 
 
@@ -413,6 +486,9 @@ def launch_rooflines(run_events, pixels_per_step, fuse_latent, map_symbols):
 
 
 def main(args):
+    inputs = load_inputs(args)
+    if inputs['images'] is not None:
+        (args.batch, args.height, args.width) = inputs['images'].shape
     (h_in, w_in) = (args.height, args.width)
     if args.transform_streams <= 0:
         args.transform_streams = codec.PRODUCT_TRANSFORM_STREAMS
@@ -452,26 +528,32 @@ def main(args):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if world == 1:
             os.environ.setdefault('MASTER_PORT', str(free_port()))
-            # what launch_ranks gives its children (the pool's host driver only supports dmabuf IPC); a caller's setting wins
-            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group(backend='gloo' if share_gpu else 'nccl', rank=rank, world_size=world,
                                 device_id=None if share_gpu else torch.device('cuda', local_rank))
     device = torch.device('cuda', local_rank)
     cores = usable_cpus()
     os.environ.setdefault('OMP_NUM_THREADS', str(cores))      # the oracle's OpenMP transforms (cpu_baseline only)
     ctx = Context(args, device, world, rank, cores)
+    ctx.inputs = inputs
     coder_streams = args.coder_streams or auto_coder_streams(h_in, w_in)
 
-    variables = synthetic_model(args.bin_width)
+    def model_at(width):
+        """The model with its bin widths at `width` times their trained values (random-init: `width` itself)."""
+        if inputs['variables'] is None:
+            return synthetic_model(width)
+        scaled = dict(inputs['variables'])
+        scaled[var.BIN_WIDTHS_NAME] = ((width/args.bin_width)*inputs['variables'][var.BIN_WIDTHS_NAME]).astype(numpy.float32)
+        return scaled
+
+    variables = model_at(args.bin_width)
     if args.only_dropin_surface:
         # diagnostic: the statistics that feed the coder as run_pipeline derives them, then the leg alone
-        encoder = pipeline.DeviceEncoder(variables, False, device)
-        y0 = encoder(torch.from_numpy(synthetic_images(1000 + rank + args.seed_offset, args.batch, h_in, w_in)).to(device))
-        map_mean_host = dev.map_means(y0).cpu().numpy()
-        probabilities = lossless_stats.compute_binary_probabilities(y0.cpu().numpy(), variables[var.BIN_WIDTHS_NAME], map_mean_host, TRUNCATED_UNARY_LENGTH)
+        encoder = pipeline.DeviceEncoder(variables, bool(args.learned_bin_widths), device)
+        y0 = encoder(torch.from_numpy(numpy.ascontiguousarray(ctx.images(1000 + rank + args.seed_offset, args.batch, h_in, w_in))).to(device))
+        (map_mean_host, probabilities, idx_map_exception) = ctx.statistics(y0, variables[var.BIN_WIDTHS_NAME])
         encoder.check()
         del y0, encoder
-        print(json.dumps({'dropin_surface': dropin_surface_leg(variables, probabilities, map_mean_host, h_in, w_in)}))
+        print(json.dumps({'dropin_surface': dropin_surface_leg(ctx, variables, probabilities, map_mean_host, idx_map_exception, h_in, w_in)}))
         return
     # ---- the roofline leg first, while the process has no other streams: the same steps launched kernel by kernel on ONE
     # transform stream (the default stream), HIP events around every launch (on the stream it goes to), so that a duration is
@@ -483,7 +565,7 @@ def main(args):
                        transform_streams=args.transform_streams, use_graphs=args.graphs, min_seconds=args.min_seconds,
                        max_blocks=args.max_blocks)
     (elapsed, stats, probabilities, map_mean_host) = (run['elapsed'], run['stats'], run['probabilities'], run['map_mean_host'])
-    (host_coder, coder_threads) = (run['host_coder'], run['coder_threads'])
+    (host_coder, coder_threads, idx_map_exception) = (run['host_coder'], run['coder_threads'], run['idx_map_exception'])
     # ---- derived figures (outside the timed region) ------------------------------------------------------------------
     pixels_per_step = args.batch*h_in*w_in
     value = pixels_per_step*args.steps*world/elapsed/1e6
@@ -509,12 +591,13 @@ def main(args):
             'Kodak' if (h_in, w_in) == (512, 768) else 'synthetic', w_in, h_in),
         'value': round(value, 3), 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed/args.steps*1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': 'f32', 'data': inputs['data'],
         'config': {'workload': '{0}_{1}x{2}_luma_batch{3}_per_gpu_bin_width_{4}_lossless_roundtrip'.format(
                        'kodak' if (h_in, w_in) == (512, 768) else 'synthetic', h_in, w_in, args.batch, args.bin_width),
                    'images_per_gpu_per_step': args.batch, 'height': h_in, 'width': w_in, 'bin_width_multiplier': args.bin_width,
-                   'truncated_unary_length': TRUNCATED_UNARY_LENGTH, 'idx_map_exception': IDX_MAP_EXCEPTION,
-                   'weights': 'random-init fixed-bin-width architecture (trained checkpoints absent from the reference)',
+                   'truncated_unary_length': int(probabilities.shape[1]), 'idx_map_exception': idx_map_exception,
+                   'weights': ('random-init fixed-bin-width architecture (trained checkpoints absent from the reference)' if inputs['variables'] is None
+                               else '{0} ({1}-bin-width architecture)'.format(args.checkpoint, 'learned' if args.learned_bin_widths else 'fixed')),
                    'parallelism': 'image shards, one process per GPU' if world > 1 else 'single GPU',
                    'mode': '{0} transform stream(s), {1} batches of coder work in flight, {2}'.format(
                        args.transform_streams, coder_streams, 'three hipGraph launches per step' if args.graphs else 'launched kernel by kernel'),
@@ -587,6 +670,19 @@ def main(args):
                                  'per_kernel': {k: {'avg_ms': v['avg_ms'], 'frac': v.get('frac'), 'bound': v['bound']} for (k, v) in pk2.items()}}
             del roof2
             line['other_shapes'].append(entry)
+    golden = os.path.join(ROOT, 'tests', 'golden', 'coder_golden.npz')
+    if side and args.coder == 'device' and inputs['statistics'] is None and os.path.isfile(golden):
+        # the coder exercised on the AUTHORS' statistics (the tables of lossless/results/1_10000/training_index_10/ of the reference,
+        # held as data in tests/golden/): their map means, exception map and binary probabilities over this run's latents. The tables
+        # were not made from these latents, so the rate is what a mismatched table costs; every map still round-trips.
+        with numpy.load(golden) as g:
+            authors = (g['real_map_mean'].astype(numpy.float32), g['real_probabilities_1'].copy(), int(g['real_idx_map_exception']))
+        leg = run_pipeline(ctx, args.batch, 30, 5, variables, h_in, w_in, coder_streams=coder_streams, transform_streams=args.transform_streams,
+                           use_graphs=args.graphs, min_seconds=0.4, max_blocks=5, statistics=authors)
+        line['authors_statistics'] = {'value': round(30*pixels_per_step/leg['elapsed']/1e6, 3), 'unit': 'Mpixels/s', 'ms_per_step': round(leg['elapsed']/30*1e3, 4),
+                                      'steps': 30, 'rate_bpp': round(rate_and_psnr(leg['stats'], h_in, w_in)[0], 5), 'idx_map_exception': authors[2],
+                                      'tables': 'map_mean.npy, idx_map_exception.pkl, binary_probabilities_1.npy of the reference model 1_10000 / training_index_10 '
+                                                '(tests/golden/coder_golden.npz); --stats-dir PATH runs the headline itself on a directory of such files'}
     if side and args.coder == 'device':
         # the feed / fetch of the reference's sess.run (uint8 images from pinned host memory in, uint8 reconstructions out)
         feed = run_pipeline(ctx, args.batch, 60, 10, variables, h_in, w_in, coder_streams=coder_streams, transform_streams=args.transform_streams,
@@ -612,11 +708,13 @@ def main(args):
         del os.environ['EAE_BENCH_NO_CODER']
         ms_bare = bare['elapsed']/30*1e3
         for width in (args.bin_width,) + tuple(wd for wd in REALISTIC_BIN_WIDTHS if wd < args.bin_width):
-            v_w = synthetic_model(width)
+            v_w = model_at(width)
+            given = width == args.bin_width          # a --stats-dir table belongs to one multiplier
             leg = run_pipeline(ctx, args.batch, 30, 5, v_w, h_in, w_in, coder_streams=coder_streams, transform_streams=args.transform_streams,
-                               use_graphs=args.graphs, min_seconds=0.5, max_blocks=5)
+                               use_graphs=args.graphs, min_seconds=0.5, max_blocks=5, given_statistics=given)
             # the coder's span in the pipeline needs events on its stream: the launch-by-launch path, one transform stream
-            span = run_pipeline(ctx, args.batch, 20, 5, v_w, h_in, w_in, coder_streams=coder_streams, min_seconds=0., max_blocks=1, coder_events=True)
+            span = run_pipeline(ctx, args.batch, 20, 5, v_w, h_in, w_in, coder_streams=coder_streams, min_seconds=0., max_blocks=1, coder_events=True,
+                                given_statistics=given)
             (enc_ms, dec_ms) = coder_alone_ms(ctx, args.batch, v_w, h_in, w_in)
             (leg_bpp, leg_psnr) = rate_and_psnr(leg['stats'], h_in, w_in)
             ms_step = leg['elapsed']/30*1e3
@@ -633,7 +731,7 @@ def main(args):
                 'coder_on_critical_path': bool(in_pipe > coder_streams*ms_step*0.95)})
     if rank == 0 and world == 1 and not args.no_dropin_surface and (h_in, w_in) == (512, 768):
         try:
-            line['dropin_surface'] = dropin_surface_leg(variables, probabilities, map_mean_host, h_in, w_in)
+            line['dropin_surface'] = dropin_surface_leg(ctx, variables, probabilities, map_mean_host, idx_map_exception, h_in, w_in)
         except Exception as exc:      # a side figure must never cost the run its headline
             line['dropin_surface'] = {'error': '{0}: {1}'.format(type(exc).__name__, exc)}
     if rank == 0:
@@ -654,7 +752,7 @@ def main(args):
         dist.destroy_process_group()
 
 
-def dropin_surface_leg(variables, probabilities, map_mean, h, w, nb_images=24, batch_size=4, repeats=5):
+def dropin_surface_leg(ctx, variables, probabilities, map_mean, idx_map_exception, h, w, nb_images=24, batch_size=4, repeats=5):
     """What a user of the reference's OWN call surface gets: the mirror of `fix_gamma` (reconstructing_eae_kodak.py:31-243) run as
     the reference's script runs it -- `nb_images` uint8 numpy images in, `batch_size = 4` (:624), one multiplier, numpy in / numpy
     out at every call, per-image `rescale_compress_lossless_maps` / `rate_3d` / `psnr_2d`, no PNG dumps -- with the modules imported
@@ -688,7 +786,9 @@ def dropin_surface_leg(variables, probabilities, map_mean, h, w, nb_images=24, b
         raise RuntimeError('dropin/ does not re-export the objects the mirror harness calls')
     root = tempfile.mkdtemp(prefix='eae_dropin_surface_')
     try:
-        suffix = '1_10000'
+        learned = var.ENCODER_NAMES_FIXED_BW[0] not in variables
+        bin_width_init = float(variables[var.BIN_WIDTHS_NAME][0])      # only names the directories (reconstructing_eae_kodak.py:88-93)
+        suffix = '{0}{1}_10000'.format('learning_bw_' if learned else '', tls.float_to_str(bin_width_init))
         model_dir = os.path.join(root, 'eae/results', suffix)
         stats_dir = os.path.join(root, 'lossless/results', suffix, 'training_index_10')
         os.makedirs(model_dir)
@@ -698,11 +798,10 @@ def dropin_surface_leg(variables, probabilities, map_mean, h, w, nb_images=24, b
             pickle.dump(91, f, protocol=2)
         numpy.save(os.path.join(stats_dir, 'map_mean.npy'), map_mean)
         with open(os.path.join(stats_dir, 'idx_map_exception.pkl'), 'wb') as f:
-            pickle.dump(IDX_MAP_EXCEPTION, f, protocol=2)
+            pickle.dump(idx_map_exception, f, protocol=2)
         numpy.save(os.path.join(stats_dir, 'binary_probabilities_1.npy'), probabilities)
-        images = synthetic_images(1000, nb_images, h, w)
+        images = numpy.ascontiguousarray(ctx.images(1000, nb_images, h, w))
         multipliers = numpy.array([1.], dtype=numpy.float32)
-        bin_width_init = float(variables[var.BIN_WIDTHS_NAME][0])
 
         # wall time spent inside named calls of the surface (cheap wrappers; the two `initialization`s are always wrapped: their
         # time is what the timed region leaves out)
@@ -734,9 +833,9 @@ def dropin_surface_leg(variables, probabilities, map_mean, h, w, nb_images=24, b
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             if batched:
-                out = mirror.fix_gamma_batched(images, bin_width_init, multipliers, 10, 10000., batch_size, False, root=root)
+                out = mirror.fix_gamma_batched(images, bin_width_init, multipliers, 10, 10000., batch_size, learned, root=root)
             else:
-                out = mirror.fix_gamma(images, bin_width_init, multipliers, 10, 10000., batch_size, False, is_lossless, root=root)
+                out = mirror.fix_gamma(images, bin_width_init, multipliers, 10, 10000., batch_size, learned, is_lossless, root=root)
             total = time.perf_counter() - t0
             return (out, total, dict(spent))
 

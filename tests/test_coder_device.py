@@ -565,7 +565,7 @@ def test_the_guard_test_is_red_on_the_first_decoder_core(tmp_path):
         assert run.returncode == 0, run.stdout[-2000:]
 
 
-def test_the_64_bit_shift_hazard_itself(tmp_path):
+def test_the_64_bit_shift_hazard_itself(tmp_path, capsys):
     """The fault in its minimal form (scratch/r04/probe_shift64.hip, generated by gen_probe_shift.py): `v_lshlrev_b64 v[18:19], vK,
     v[16:17]` in a wave whose allocation is N registers, against the same shift done with 32-bit instructions. Asserted: alone on the
     GPU every result is right for every (N, K); next to other waves every result is right when K + 1 < N. Reported, not asserted
@@ -588,6 +588,20 @@ def test_the_64_bit_shift_hazard_itself(tmp_path):
             assert wrong == 0, (where, n, k, wrong)
         else:
             hazard += wrong
-    print('64-bit shifts fed from the last register of the allocation, next to other waves: {0} wrong results'.format(hazard))
+    # said out loud and kept (gpurun_out/ travels back from the GPU box; a copy goes to profiles/): a green run of this test on
+    # another box then says whether the mechanism was seen there, not only that the guarded cases were right
+    import json
+    summary = {'probe': 'scratch/r04/probe_shift64.hip 48 20000 2', 'reproduced': bool(hazard > 0),
+               'wrong_results_with_the_shift_amount_in_the_last_register_next_to_other_waves': hazard,
+               'cases': [{'where': where, 'N': int(n), 'K': int(k), 'wrong': int(wrong)} for (where, n, k, wrong) in rows]}
+    try:
+        os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(root, 'gpurun_out', 'shift64_hazard_probe.json'), 'w') as f:
+            json.dump(summary, f, indent=1)
+    except OSError:
+        pass
+    with capsys.disabled():
+        print('\n[64-bit shift hazard probe] reproduced: {0} ({1} wrong results with the shift amount in the last register of the '
+              'allocation, next to other waves; 0 in every other case)'.format('true' if hazard > 0 else 'false', hazard))
     if hazard == 0:
         pytest.skip('the hazard did not reproduce on this box: rule 2 of csrc/isa_guard.py may have become unnecessary')

@@ -48,7 +48,7 @@ def cpu_evaluation(images, variables, bwt, map_mean, probabilities, y_cpu):
     return (bits, sse, dead, symbols)
 
 
-def fused_against_cpu(n, h, w, multipliers, seed):
+def fused_against_cpu(n, h, w, multipliers, seed, statistics=None):
     import bench
     from autoencoder_based_image_compression_amd import codec, device as dev, pipeline
     from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
@@ -67,6 +67,8 @@ def fused_against_cpu(n, h, w, multipliers, seed):
     for multiplier in multipliers:
         bwt = (numpy.float32(multiplier)*bin_widths).astype(numpy.float32)
         probabilities = lossless_stats.compute_binary_probabilities(y_gpu, bwt, map_mean, L)
+        if statistics is not None:                # tables that were not made from these latents (any valid table codes any symbols)
+            (map_mean, probabilities) = statistics
         with codec.BatchCodec(variables, False, bwt, map_mean, probabilities, IDX, n, h, w) as fused:
             got = fused.submit(images_device).result()
         (bits, sse, dead, _) = cpu_evaluation(images, variables, bwt, map_mean, probabilities, y_cpu)
@@ -75,6 +77,18 @@ def fused_against_cpu(n, h, w, multipliers, seed):
         assert numpy.array_equal(got['nb_deads'], dead), multiplier
         rates.append(float(bits.mean())/(h*w))
     return rates
+
+
+def test_the_authors_statistics_on_synthetic_latents():
+    """The coder on the AUTHORS' statistics (lossless/results/1_10000/training_index_10/: `map_mean.npy`, `idx_map_exception.pkl` = 67,
+    `binary_probabilities_1.npy`, held as data in tests/golden/coder_golden.npz) over the path's own symbols: bits per image of the
+    fused MI355X path == the CPU coder's (the reference's C++ where its build is present). What `bench.py: authors_statistics` times."""
+    import os
+    with numpy.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'coder_golden.npz')) as g:
+        assert int(g['real_idx_map_exception']) == IDX
+        statistics = (g['real_map_mean'].astype(numpy.float32), g['real_probabilities_1'].copy())
+    rates = fused_against_cpu(3, 128, 192, (1.0,), 31, statistics=statistics)
+    assert rates[0] > 0.
 
 
 def test_config3_kodak_set_at_three_bin_widths():

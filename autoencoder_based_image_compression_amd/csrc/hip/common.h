@@ -23,6 +23,7 @@ struct EaeLaunchOptions {
     char latent;        // EAE_HIP_LATENT: 'q' (default) | 'w' | 'l'
     int split_wpb;      // EAE_HIP_SPLIT_WPB: 1 = one-wave blocks in the split conv GEMM (default: 4 waves per block)
     int split_mute;     // test hook, debug entry point only: heads of cut tiles never publish, tails give up after ~1 ms
+    int assume_partitioned;   // EAE_HIP_ASSUME_PARTITIONED=1: behave as on a device that is not one whole MI355X (tests of the de-tuned path)
 };
 extern EaeLaunchOptions g_eae_launch_options;
 
@@ -86,6 +87,16 @@ inline bool eae_is_gfx950() {
         cached[dev] = (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 2;
     }
     return cached[dev] == 1;
+}
+
+// The tile order of the conv launches (`blockIdx.x & 7` = the XCD, conv_gemm_split.hip) and the sizing of the cut launches (waves
+// an XCD holds at once = CUs / 8 x 4 x k) are built on ONE logical device = one whole MI355X: 8 XCDs x 32 CUs, workgroups handed
+// to the XCDs round-robin (compute partition SPX). In DPX / QPX / CPX a logical device is 4 / 2 / 1 XCDs with 128 / 64 / 32 CUs:
+// blocks b and b + 8 still share an XCD (the XCD count divides 8), so every hand-off stays inside one L2 and the bits are the
+// same, but the per-XCD locality and the cut sizing are off. The CU count of the logical device tells the mode apart; on anything
+// but 256 CUs of gfx950 the launches are never cut of their own accord (eae_hip_partition_info says what was found).
+inline bool eae_is_whole_mi355x() {
+    return eae_is_gfx950() && eae_compute_units() == 256 && !g_eae_launch_options.assume_partitioned;
 }
 
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous chunk of the logical grid so that

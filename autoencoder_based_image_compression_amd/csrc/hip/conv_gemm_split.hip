@@ -334,8 +334,9 @@ int eae_conv_gemm::launch_split(ConvGemmParams& p, hipStream_t stream, int cut) 
     if (k < 1) k = 1;
     // The hand-off between the two halves of a cut tile rests on what was validated on gfx950 only: workgroups dispatched in
     // grid order (a tail only waits for a wave dispatched before it), sc1 stores / loads meeting in the XCD's L2. On any
-    // other device the launch is never cut of its own accord (whole tiles: the same bits).
-    const bool validated = eae_is_gfx950();
+    // other device -- and on a partition of an MI355X (DPX / QPX / CPX: the sizing below assumes 8 XCDs per logical device) -- the
+    // launch is never cut of its own accord (whole tiles: the same bits).
+    const bool validated = eae_is_whole_mi355x();
     bool split = cut > 0;
     if (cut > 0) k = cut > 3 ? 3 : cut;
     if (cut < 0 && validated && p.split_ws && p.n_phases == 1 && tiles >= simds) {

@@ -26,6 +26,8 @@ static EaeLaunchOptions read_launch_options() {
     e = std::getenv("EAE_HIP_SPLIT_WPB");
     o.split_wpb = e && (std::atoi(e) == 1 || std::atoi(e) == 4) ? std::atoi(e) : 0;
     o.split_mute = 0;                                                      // never from the environment
+    e = std::getenv("EAE_HIP_ASSUME_PARTITIONED");
+    o.assume_partitioned = e && e[0] == '1' ? 1 : 0;
     return o;
 }
 EaeLaunchOptions g_eae_launch_options = read_launch_options();
@@ -38,6 +40,21 @@ extern "C" int eae_hip_debug_reload_launch_options(void) {
 }
 extern "C" int eae_hip_debug_set_split_mute(int on) {
     g_eae_launch_options.split_mute = on ? 1 : 0;
+    return EAE_HIP_OK;
+}
+
+extern "C" int eae_hip_partition_info(int* compute_units, int* xcds, int* whole_device) {
+    const int cus = eae_compute_units();
+    if (cus <= 0) return (int)hipErrorNoDevice;
+    if (compute_units) *compute_units = cus;
+    if (xcds) *xcds = eae_is_gfx950() ? (cus + 31) / 32 : 0;
+    if (whole_device) *whole_device = eae_is_whole_mi355x() ? 1 : 0;
+    static bool told = false;
+    if (!told && eae_is_gfx950() && !eae_is_whole_mi355x()) {
+        told = true;
+        std::fprintf(stderr, "libeae_hip: this logical device shows %d compute units, not the 256 of a whole MI355X (compute partition "
+                             "DPX / QPX / CPX?): the conv launches keep whole tiles (same results, the tile order is tuned for SPX)\n", cus);
+    }
     return EAE_HIP_OK;
 }
 

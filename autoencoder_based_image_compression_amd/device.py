@@ -56,6 +56,14 @@ def device_info():
     return {'name': name.value.decode(), 'compute_units': cus.value, 'clock_mhz': mhz.value, 'hbm_bytes': mem.value}
 
 
+def partition_info():
+    """{'compute_units', 'xcds', 'whole_device'} of the current logical device (include/eae_hip.h: eae_hip_partition_info)."""
+    import ctypes
+    (cus, xcds, whole) = (ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0))
+    _check(_native.hip().eae_hip_partition_info(ctypes.byref(cus), ctypes.byref(xcds), ctypes.byref(whole)), 'partition_info')
+    return {'compute_units': cus.value, 'xcds': xcds.value, 'whole_device': bool(whole.value)}
+
+
 class Model(object):
     """eae_hip_model (include/eae_hip.h, whole-path entry points): the variables of one trained entropy autoencoder resident
     on the current device in the kernels' layouts. `variables`: dict of numpy arrays keyed by the TensorFlow variable names

@@ -88,6 +88,10 @@ def parse_args(argv=None):
     parser.add_argument('--force-nccl', action='store_true',
                         help='join an RCCL process group even as a single rank, so that the barriers and the one statistics '
                              'all-reduce of the N-GPU run go through librccl on a one-GPU box (tests/test_bench_launcher.py)')
+    parser.add_argument('--exchange', choices=('all_reduce', 'all_gather'), default='all_reduce',
+                        help='the path\'s one exchange step at the end of every timed block (SURVEY.md 8(e)): all_reduce sums four float64 accumulators '
+                             '(default); all_gather is the exact-parity mode -- every rank receives the per-image (bits, squared error, dead maps) '
+                             'of all ranks in global image order (`sharding.gather_per_image`), so a mean over images is bit-identical to one process\'s')
     parser.add_argument('--dry-launch', action='store_true',
                         help='rendezvous check only (no GPU): every rank joins a gloo group, one all-reduce, rank 0 prints n_gpus')
     args = parser.parse_args(argv)
@@ -285,6 +289,16 @@ class Context(object):
                 dist.barrier()
         torch.cuda.synchronize()
 
+    def gather_per_image(self, local, nb_images_total):
+        """float64 (images of this rank, k) -> (nb_images_total, k) on every rank, global image order (`sharding.gather_per_image`:
+        all_gather through RCCL on the device, through gloo on the host)."""
+        if not self.grouped:
+            return local
+        self.collectives += 1
+        import torch.distributed as dist
+        from autoencoder_based_image_compression_amd import sharding
+        return sharding.gather_per_image(local, nb_images_total, device=self.device if dist.get_backend() == 'nccl' else None)
+
     def all_reduce(self, tensor, op):
         if self.grouped:
             self.collectives += 1
@@ -383,11 +397,17 @@ def run_pipeline(ctx, batch, steps, warmup, variables, h, w, coder='device', cod
                 # submitted again, so all that can be checked once the block is through is that every copy was made)
                 if pcie and any(t.reconstruction_host is None for t in tickets):
                     raise RuntimeError('a reconstruction did not reach the host')
-                # the path's only exchange step: sum the rate / PSNR accumulators over ranks
-                block_stats = torch.tensor([float(sum(int(r['nb_bits'].sum()) for r in results)), float(sum(int(r['sse'].sum()) for r in results)),
-                                            float(sum(int(r['nb_deads'].sum()) for r in results)), float(steps*batch)],
-                                           dtype=torch.float64, device=device)
-                ctx.all_reduce(block_stats, 'SUM')
+                # the path's only exchange step: sum the rate / PSNR accumulators over ranks ...
+                if args.exchange == 'all_reduce':
+                    block_stats = torch.tensor([float(sum(int(r['nb_bits'].sum()) for r in results)), float(sum(int(r['sse'].sum()) for r in results)),
+                                                float(sum(int(r['nb_deads'].sum()) for r in results)), float(steps*batch)],
+                                               dtype=torch.float64, device=device)
+                    ctx.all_reduce(block_stats, 'SUM')
+                else:
+                    # ... or, exact-parity mode, gather the per-image values of every rank in global image order
+                    local = numpy.concatenate([numpy.stack([r['nb_bits'], r['sse'], r['nb_deads']], axis=1) for r in results]).astype(numpy.float64)
+                    everything = ctx.gather_per_image(local, steps*batch*max(world, 1))
+                    block_stats = torch.tensor(list(everything.sum(axis=0)) + [float(everything.shape[0])], dtype=torch.float64, device=device)
                 ctx.barrier()
                 elapsed = time.perf_counter() - t0
                 cpu = time.process_time() - c0
@@ -626,6 +646,11 @@ def main(args):
                      'algorithmic_flop_per_launch': {k: flops[k]*pixels_per_step for k in GEMM_LAUNCHES},
                      'per_kernel': per_kernel, 'peak_hbm_tbytes_per_s': PEAK_HBM_TBS},
     }
+    line['exchange'] = args.exchange
+    # a scaling curve needs one GPU per rank: ranks sharing a GPU (EAE_BENCH_SHARE_GPU) or a single rank measure none
+    line['scaling_measured'] = bool(world > 1 and not share_gpu)
+    partition = dev.partition_info()
+    line['device'] = dict(dev.device_info(), xcds=partition['xcds'], whole_device=partition['whole_device'])
     if ctx.grouped:
         import torch.distributed as dist
         # the collectives of this run (barriers around every timed block, the MAX of the block times, the one statistics

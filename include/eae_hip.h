@@ -39,6 +39,11 @@ enum { EAE_NORM_NONE = 0, EAE_NORM_GDN = 1, EAE_NORM_IGDN = 2 };
 const char* eae_hip_version(void);
 /* Fills name (e.g. "gfx950:sramecc+:xnack-"), CU count; returns 0, or a hipError_t when no device is usable. */
 int eae_hip_device_info(char* name, int name_cap, int* compute_units, int* clock_mhz, int64_t* hbm_bytes);
+/* The compute partition the current logical device is, as far as it matters here: its compute units, the XCDs that makes on
+ * gfx950 (32 CUs each; 0 on another architecture), and whether it is one whole MI355X (256 CUs, mode SPX) -- the shape the
+ * conv launches' XCD-aware tile order and the sizing of their cut tiles are built on. On a partition (DPX / QPX / CPX) every
+ * result is the same, the launches keep whole tiles, and a note goes to stderr once. */
+int eae_hip_partition_info(int* compute_units, int* xcds, int* whole_device);
 
 /* Small results for the host (bit counts, statuses, histograms): a kernel copies `bytes` (multiple of 4) from device
  * memory into PINNED, device-mapped host memory (hipHostMalloc / torch pin_memory) in stream order; the host reads them

@@ -124,3 +124,37 @@ def test_one_rank_through_rccl():
     assert proc.returncode == 0, proc.stderr[-2000:]
     assert 'process_group' not in lines[0]
     assert grouped['totals'] == lines[0]['totals'] and grouped['n_gpus'] == 1
+    assert grouped['scaling_measured'] is False and grouped['device']['whole_device'] is True
+    # the exact-parity exchange (all_gather of the per-image values, `sharding.gather_per_image`) through RCCL as well
+    (proc, lines) = run_bench(common + ['--force-nccl', '--exchange', 'all_gather'])
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert lines[0]['exchange'] == 'all_gather' and lines[0]['process_group']['backend'] == 'nccl'
+    assert lines[0]['totals'] == grouped['totals']
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+def test_eight_ranks_of_configs_3_share_the_gpu():
+    """The 8-GPU run of BASELINE.json configs[3] rehearsed on this box's one GPU (EAE_BENCH_SHARE_GPU: eight rank processes, gloo for
+    the collectives, 64 images of 256x256 per rank and step) under the box's CPU quota: every rank codes its own images (seed offset
+    = rank), the integer totals of the line equal the sums of eight one-rank runs, with either exchange; the summed process CPU of
+    the eight ranks per step is printed. No scaling is measured by this (`scaling_measured` false)."""
+    shape = ['--height', '256', '--width', '256', '--batch', '64', '--steps', '2', '--warmup', '1', '--min-seconds', '0',
+             '--no-cpu-baseline', '--no-side', '--no-dropin-surface']
+    (proc, lines) = run_bench(['--gpus', '8'] + shape, {'EAE_BENCH_SHARE_GPU': '1'}, timeout=1500)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    eight = lines[0]
+    assert eight['n_gpus'] == 8 and eight['scaling_measured'] is False and len(eight['host_cpu_ms_per_step']) == 8
+    (proc, lines) = run_bench(['--gpus', '8', '--exchange', 'all_gather'] + shape, {'EAE_BENCH_SHARE_GPU': '1'}, timeout=1500)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert lines[0]['totals'] == eight['totals']
+    sums = {'bits': 0, 'sse': 0, 'dead_maps': 0, 'images': 0}
+    for rank in range(8):
+        (proc, lines) = run_bench(['--gpus', '1', '--seed-offset', str(rank)] + shape)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        for key in sums:
+            sums[key] += lines[0]['totals'][key]
+    assert sums == eight['totals'], (sums, eight['totals'])
+    print('8 ranks sharing one GPU, 64 x 256x256 per rank and step: process CPU per step and rank (ms) {0}, summed {1:.2f} ms per {2:.2f} ms step '
+          '= {3:.2f} CPUs of the {4} this box allows'.format(eight['host_cpu_ms_per_step'], sum(eight['host_cpu_ms_per_step']), eight['ms_per_step'],
+                                                          sum(eight['host_cpu_ms_per_step'])/eight['ms_per_step'], eight['usable_cpus']))

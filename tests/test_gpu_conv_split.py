@@ -53,6 +53,30 @@ def test_conv_against_the_oracle(norm, launch_options):
     _forms(launch_options, lambda w: dev.conv5x5s2(*args, workspace=w), ws, got)
 
 
+def test_the_cut_launches_are_for_one_whole_mi355x(launch_options):
+    """`blockIdx.x & 7` is the XCD and an XCD holds CUs / 8 x 4 x k waves only when the logical device is one whole MI355X (compute
+    partition SPX: 256 CUs, 8 XCDs). The library reads the CU count of the logical device; on anything else (here: pretended with
+    EAE_HIP_ASSUME_PARTITIONED=1) a launch that would cut its last tiles keeps them whole -- the workspace is never touched -- and
+    gives the same bits."""
+    from autoencoder_based_image_compression_amd import device as dev
+    launch_options.clear()
+    info = dev.partition_info()
+    assert info == {'compute_units': 256, 'xcds': 8, 'whole_device': True}, info      # the GPU boxes of this pool run SPX
+    v = _vars(35)
+    x = torch.from_numpy(numpy.random.RandomState(36).standard_normal(size=(6, 128, 192, 128)).astype(numpy.float32)).cuda()
+    args = (x, dev.pack_conv_weights(torch.from_numpy(v['encoder/weights_2']).cuda()), torch.from_numpy(v['encoder/biases_2']).cuda(), 1,
+            dev.pack_gamma(torch.from_numpy(v['encoder/gamma_2']).cuda()), torch.from_numpy(v['encoder/beta_2']).cuda())
+    ws = dev.conv_workspace('cuda')
+    cut = dev.conv5x5s2(*args, workspace=ws)
+    launch_options.setenv('EAE_HIP_ASSUME_PARTITIONED', '1')
+    assert dev.partition_info() == {'compute_units': 256, 'xcds': 8, 'whole_device': False}
+    poisoned = torch.full_like(ws, 0x5a5a5a5a)          # a cut launch would read flags out of this and time out or go wrong
+    whole = dev.conv5x5s2(*args, workspace=poisoned)
+    assert torch.equal(whole, cut) and bool((poisoned == 0x5a5a5a5a).all())
+    launch_options.clear()
+    assert dev.partition_info()['whole_device']
+
+
 @pytest.mark.parametrize('norm', [0, 2])
 def test_tconv_against_the_oracle(norm, launch_options):
     """3 x 48x72 sites x 4 output phases = 1296 tiles of four lengths (36 / 24 / 24 / 16 K-steps)."""

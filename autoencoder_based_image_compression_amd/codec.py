@@ -200,6 +200,19 @@ def default_nb_in_flight(h_in, w_in):
     return int(min(8, 3 + map_size//768))
 
 
+def default_coder_chunks(n_maps):
+    """Launches the coder's serial chains are cut into (`BatchCodec(coder_chunks=None)`): ONE, i.e. off. For one or two images a
+    step is as long as the coder's chains laid end to end (binarise, encoder core, emit, decoder core, debinarise: 0.65 of the 1.2 ms
+    one Kodak image takes), and cut into chunks on three streams the decoder trails the encoder -- but on this runtime every
+    cross-stream hop costs 60-100 us (launched directly or replayed as a hipGraph), more than a chunk saves at the headline's entropy:
+    one image's round trip 0.65 ms whole, 0.84 / 0.95 / 1.24 ms in 2 / 3 / 4 chunks; at 2 bpp 2.46 ms whole, 2.29 / 2.18 in 4 / 8
+    chunks (profiles/r05_trailing_alone.log). So the chunked form stays an option (`coder_chunks`, EAE_CODER_CHUNKS) for long chains."""
+    forced = os.environ.get('EAE_CODER_CHUNKS')
+    if forced:
+        return max(1, min(16, int(forced)))
+    return 1
+
+
 PRODUCT_TRANSFORM_STREAMS = 3      # 2 / 3 / 4 / 5 streams: 3,020 / 3,075 / 3,060 / 3,030 Mpx/s for 24 Kodak images per step, 2,550 / 2,770 / 2,740
 #                                    for 64 images of 256x256 (profiles/r03_transform_streams2.txt)
 
@@ -218,7 +231,7 @@ class BatchCodec(object):
     def __init__(self, variables, are_bin_widths_learned, bin_widths_test, map_mean, binary_probabilities, idx_map_exception,
                  batch_size, h_in, w_in, device='cuda', nb_in_flight=None, keep_reconstruction=False, launch_hook=None,
                  coder='device', host_coder_threads=0, hist_radius=2047, nb_transform_streams=1, use_graphs=False,
-                 time_coder=False, fuse_latent=False, fetch_reconstruction=False):
+                 time_coder=False, fuse_latent=False, fetch_reconstruction=False, coder_chunks=None):
         """coder: 'device' (the coder kernels on side streams), 'host' (ONE device -> host copy of the symbols per batch, then
         the host C-ABI coder `eae_coder_compress_maps` on `host_coder_threads` threads: the shape BASELINE.json sketches) or
         'none' (transforms only; the bit counts come back as zeros).
@@ -236,6 +249,9 @@ class BatchCodec(object):
         fetch_reconstruction: the uint8 reconstructions are copied to pinned host memory by the result worker (on a stream of its
         own, once the batch is decoded) and `Ticket.reconstruction_host` holds them after `result()`: the fetch of the reference's
         `decode_mini_batches` (eae/batching.py:49-53). The feed is `submit()` with a pinned HOST tensor.
+        coder_chunks: 2..16 cuts the coder's serial chains into that many launches each, so that the emit pass and the decoder run
+        while the encoder core is still at work (`device.coder_roundtrip_trailing`; same results). None: `default_coder_chunks`
+        (off: on this runtime the hops between the three streams cost more than the overlap saves, except for long chains).
         hist_radius: the exception map's entropy is formed from an exact histogram of its symbols over [-hist_radius,
         hist_radius]; when a symbol falls outside, the result worker counts that batch's exception maps again over the whole
         int16 range (like the image-by-image functions of `kodak/`; the reference's histogram has no bound,
@@ -309,8 +325,11 @@ class BatchCodec(object):
                          for _ in range(self.nb_slots)]
         self._coder_streams = [dev.CoderStreams(n_maps, self.map_size, self.truncated_unary_length, self.device,
                                                 results=self._views(self._slot_out[i])[0]) for i in range(self.nb_slots)]
-        self._workspaces = [dev.coder_workspace(n_maps, self.map_size, self.truncated_unary_length, self.device)
-                            for _ in range(self.nb_slots)]
+        self.coder_chunks = int(default_coder_chunks(n_maps) if coder_chunks is None else coder_chunks)
+        if self.coder_chunks > 1 and coder != 'device':
+            self.coder_chunks = 1
+        make_workspace = dev.coder_trailing_workspace if self.coder_chunks > 1 else dev.coder_workspace
+        self._workspaces = [make_workspace(n_maps, self.map_size, self.truncated_unary_length, self.device) for _ in range(self.nb_slots)]
         # scratch that lets the conv GEMM launches cut their last tiles (device.conv_workspace): a slot's launches never overlap each other
         self._conv_ws = [dev.conv_workspace(self.device) for _ in range(self.nb_slots)]
         self._slot_free = [threading.Event() for _ in range(self.nb_slots)]
@@ -588,7 +607,11 @@ class BatchCodec(object):
         slot's result block, on the current stream."""
         hook = hook or self._no_hook
         symbols = self._symbols[slot].view(self._n_maps, self.map_size)
-        if self.coder == 'device':
+        if self.coder == 'device' and self.coder_chunks > 1:
+            hook('coder_roundtrip', lambda: dev.coder_roundtrip_trailing(symbols, self.probabilities, self.prob_row, self.truncated_unary_length,
+                                                                         chunks=self.coder_chunks, out=self._coder_streams[slot],
+                                                                         workspace=self._workspaces[slot]))
+        elif self.coder == 'device':
             hook('coder_encode', lambda: dev.coder_encode_batch(symbols, self.probabilities, self.prob_row, self.truncated_unary_length,
                                                                 out=self._coder_streams[slot], workspace=self._workspaces[slot]))
             hook('coder_decode', lambda: dev.coder_decode_batch(self._coder_streams[slot], self.probabilities, self.prob_row,

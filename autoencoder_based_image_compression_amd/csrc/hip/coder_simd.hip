@@ -68,6 +68,9 @@ int eae_coder_generic_decode(uint32_t n_maps, uint32_t map_size, int16_t* out, u
 #ifndef EAE_RES_DEBINARISE
 #define EAE_RES_DEBINARISE 23
 #endif
+#ifndef EAE_RES_DECODE_CORE_CHUNKED
+#define EAE_RES_DECODE_CORE_CHUNKED 55      // the resumable form of the decoder core (a parked state to load and store)
+#endif
 #ifndef EAE_DECODE_TOPUP_ZEROS
 #define EAE_KEEP_VGPR_FREE_(n) asm volatile("; v" #n " reserved: the last register of the allocation holds no operand" ::: "v" #n)
 #define EAE_KEEP_LAST_VGPR_FREE(n) EAE_KEEP_VGPR_FREE_(n)
@@ -106,8 +109,23 @@ struct SimdParams {
     uint8_t* decisions;                   // [group][j / 8][lane][8]
     uint32_t* ndec;                       // [n_maps]: decisions of a map (encode); 1 = handed to the general kernel (decode)
     uint32_t* records;                    // [n_maps][rcap]
-    uint8_t* prefixes;                    // [n_maps][map_size] (decode; shares the records' memory)
+    uint8_t* prefixes;                    // [n_maps][map_size] (decode; shares the records' memory -- its own in the chunked round trip)
+    // the chunked round trip (eae_hip_coder_roundtrip_trailing): the serial chains cut into `nchunks` launches each, so that the
+    // emit pass and the decoder of chunk c run while the encoder core is on chunk c + 1 (what crosses a launch is below)
+    uint32_t chunk, nchunks;
+    uint32_t* group_steps;                // [groups]: steps of the encoder core of a group of 64 maps, fixed by its first chunk
+    uint2* enc_state;                     // [n_maps]: the interval between two chunks of the encoder core
+    uint4* emit_state;                    // [n_maps]: bits emitted, pending E3 scalings, the partial 64-bit word
+    uint32_t* avail_bits;                 // [n_maps]: stream bits that are in memory (whole 64-bit words) after the last emit chunk
+    uint4* dec_state;                     // [n_maps]: interval, code register, stream bits taken
+    uint2* dec_state2;                    // [n_maps]: unary count, symbol index
 };
+
+// Steps of one chunk of a chain of `steps` steps cut into `nchunks`: a multiple of 64 (whole record tiles, whole 8-step rounds).
+__host__ __device__ inline uint32_t chunk_span(uint32_t steps, uint32_t nchunks) {
+    const uint32_t span = ((steps + nchunks - 1u) / nchunks + 63u) & ~63u;
+    return span ? span : 64u;
+}
 
 // Exclusive prefix sum over the 64 lanes, and the total. Data-parallel primitives, not cross-lane loads: four row_shr steps scan
 // the rows of 16 lanes, row_bcast:15 / :31 carry the row totals on (the sequence LLVM's atomic optimiser emits for gfx9): 6 DPP
@@ -230,6 +248,7 @@ __global__ __launch_bounds__(64) void binarise_kernel(const SimdParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 extern __shared__ double lds_dyn[];
 
+template <bool CHUNKED>
 __global__ __launch_bounds__(64) void bac_encode_core_kernel(const SimdParams p) {
     EAE_KEEP_LAST_VGPR_FREE(EAE_RES_ENCODE_CORE);
     __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
@@ -250,12 +269,23 @@ __global__ __launch_bounds__(64) void bac_encode_core_kernel(const SimdParams p)
             if (!(pk > 0. && pk < 1.)) retry = true;
         }
     const uint32_t nd = live && !retry ? p.ndec[m] : 0u;
-    const uint32_t steps = wave_max(nd);
+    uint32_t steps = wave_max(nd);
     const uint8_t* dec = p.decisions + (size_t)blockIdx.x * 64u * p.dcap + (size_t)lane * 8u;
     uint32_t* rec = p.records + (size_t)(in_range ? m : 0u) * p.rcap;
     Interval s = interval_init();
-    uint2 ahead = steps ? *reinterpret_cast<const uint2*>(dec) : make_uint2(0, 0);
-    for (uint32_t jb = 0; jb < steps; jb += 8) {
+    uint32_t j_first = 0;
+    if (CHUNKED) {
+        // the group's chain length is fixed by the first chunk (a map that drops out later -- its emit pass gave up -- must not
+        // move the chunk boundaries of the others); this chunk's share of it, and the interval where the last chunk left it
+        if (p.chunk == 0u) { if (lane == 0u) p.group_steps[blockIdx.x] = steps; }
+        else steps = p.group_steps[blockIdx.x];
+        const uint32_t span = chunk_span(steps, p.nchunks);
+        j_first = p.chunk * span < steps ? p.chunk * span : steps;
+        steps = j_first + span < steps ? j_first + span : steps;
+        if (p.chunk != 0u && in_range) { const uint2 st = p.enc_state[m]; s.lo = st.x; s.hc = st.y; }
+    }
+    uint2 ahead = j_first < steps ? *reinterpret_cast<const uint2*>(dec + (size_t)(j_first >> 3) * 512u) : make_uint2(0, 0);
+    for (uint32_t jb = j_first; jb < steps; jb += 8) {
         const unsigned long long d8 = (unsigned long long)ahead.x | ((unsigned long long)ahead.y << 32);
         if (jb + 8 < steps) ahead = *reinterpret_cast<const uint2*>(dec + (size_t)((jb >> 3) + 1u) * 512u);
         // the eight probabilities first: they depend on the decisions only, so their LDS latency stays out of the interval's
@@ -279,7 +309,8 @@ __global__ __launch_bounds__(64) void bac_encode_core_kernel(const SimdParams p)
     }
     if (live) {
         if (retry) p.status[m] = RETRY;                 // the general kernel reproduces the exact code and stage
-        else rec[nd] = stop_record(s);                  // BinaryArithmeticCoder.cpp:61-102; emitted by emit_kernel
+        else if (!CHUNKED || p.chunk + 1u == p.nchunks) rec[nd] = stop_record(s);      // BinaryArithmeticCoder.cpp:61-102; emitted by emit_kernel
+        else p.enc_state[m] = make_uint2(s.lo, s.hc);
     }
 }
 
@@ -290,20 +321,37 @@ __global__ __launch_bounds__(64) void bac_encode_core_kernel(const SimdParams p)
 // complement, BinaryArithmeticCoder.cpp:322-337), then the other n_j - 1; afterwards the queue holds the record's own k_j
 // scalings. So P_j = the k's of the records since (and including) the last one that shifted anything out, and the position of
 // record j's bits is the sum of n + P over the records before it: two prefix sums and a running maximum per tile of 64 records.
+template <bool CHUNKED>
 __global__ __launch_bounds__(64) void emit_kernel(const SimdParams p) {
     EAE_KEEP_LAST_VGPR_FREE(EAE_RES_EMIT);
     __shared__ unsigned long long buf[kEmitWords + 2];
     const uint32_t m = blockIdx.x, lane = threadIdx.x;
     const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
     if (row < 0 || p.status[m] != 0) return;
-    const uint32_t nrec = p.ndec[m] + 1u;               // the stop record closes the stream
+    uint32_t nrec = p.ndec[m] + 1u;                     // the stop record closes the stream
     const uint32_t* rec = p.records + (size_t)m * p.rcap;
     unsigned long long* out = reinterpret_cast<unsigned long long*>(p.streams + (uint64_t)m * p.stride);
     const uint32_t size_bits = round_up_to_byte(required_bits(p.map_size, p.L));
     for (uint32_t w = lane; w < kEmitWords + 2u; w += 64u) buf[w] = 0ull;
     uint32_t base = 0, pending = 0;                     // bits emitted so far; the queue in front of the tile
     bool give_up = false;
-    for (uint32_t t = 0; t < nrec; t += 64u) {
+    uint32_t t_first = 0;
+    const bool last_chunk = !CHUNKED || p.chunk + 1u == p.nchunks;
+    if (CHUNKED) {
+        // the records the encoder core's chunk has just left: [chunk * span, (chunk + 1) * span) of this map's decisions; the stop
+        // record goes with the last chunk wherever the map's decisions end
+        const uint32_t span = chunk_span(p.group_steps[m >> 6], p.nchunks);
+        const uint32_t nd = nrec - 1u;
+        t_first = p.chunk * span < nd ? p.chunk * span : nd;
+        if (!last_chunk) nrec = t_first + span < nd ? t_first + span : nd;
+        if (p.chunk != 0u) {
+            const uint4 st = p.emit_state[m];
+            base = st.x;
+            pending = st.y;
+            if (lane == 0) buf[0] = (unsigned long long)st.z | ((unsigned long long)st.w << 32);
+        }
+    }
+    for (uint32_t t = t_first; t < nrec; t += 64u) {
         const uint32_t j = t + lane;
         const uint32_t r = j < nrec ? rec[j] : 0u;
         const uint32_t n = record_n(r), k = record_k(r);
@@ -371,9 +419,13 @@ __global__ __launch_bounds__(64) void emit_kernel(const SimdParams p) {
     if (lane == 0) {
         if (give_up) {
             p.status[m] = RETRY;
-        } else {
+        } else if (last_chunk) {
             if (base & 63u) out[base >> 6] = buf[0];     // Bitstream flush of the partial word (zeros above the last bit)
             p.bac_bits[m] = base;
+        } else {
+            const unsigned long long carry = buf[0];
+            p.emit_state[m] = make_uint4(base, pending, (uint32_t)carry, (uint32_t)(carry >> 32));
+            p.avail_bits[m] = base & ~63u;               // the whole words are in memory: what a trailing decoder may read
         }
     }
 }
@@ -389,8 +441,17 @@ constexpr size_t decode_lds_bytes(uint32_t L) { return ((size_t)L + 1u) * 64u * 
 __device__ unsigned int g_hwid_probe[8];     // [0] waves, [1] waves whose HW_ID[15:0] or XCC_ID changed, [2..5] an example (before, after)
 #endif
 
+// CHUNKED (eae_hip_coder_roundtrip_trailing): the launch decodes as far as the stream has reached memory -- `avail_bits`, left by the
+// emit pass of the encoder's latest chunk -- and parks every lane's state (interval, code register, bits taken, unary count, symbol
+// index); the next launch rebuilds ring and window at that bit position and goes on. A step takes at most 30 bits, and the lane
+// only steps while 46 more bits are known to be there (30 + the 16 the code register looks ahead), so nothing unwritten is ever
+// taken; the last launch runs on the complete stream (`bac_bits`) exactly like the unchunked kernel.
+constexpr uint32_t kNotStarted = 0xFFFFFFFFu;
+constexpr uint32_t kStepMargin = 46u;
+
+template <bool CHUNKED>
 __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p) {
-    EAE_KEEP_LAST_VGPR_FREE(EAE_RES_DECODE_CORE);
+    if (CHUNKED) { EAE_KEEP_LAST_VGPR_FREE(EAE_RES_DECODE_CORE_CHUNKED); } else { EAE_KEEP_LAST_VGPR_FREE(EAE_RES_DECODE_CORE); }
     __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
 #ifdef EAE_HWID_PROBE
     const unsigned int probe_hw0 = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);      // HW_REG_HW_ID
@@ -404,7 +465,8 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
     double* probs = lds_dyn;
     uint32_t* ring = reinterpret_cast<uint32_t*>(lds_dyn + ((size_t)L + 1u) * 64u) + lane;      // row w of this lane: ring[(w & 31) * 64]
     const bool live = in_range && row >= 0 && p.status[m] == 0;
-    const uint32_t nbac = live ? p.bac_bits[m] : 0u;
+    const bool final_chunk = !CHUNKED || p.chunk + 1u == p.nchunks;
+    const uint32_t nbac = live ? (final_chunk ? p.bac_bits[m] : p.avail_bits[m]) : 0u;
     bool retry = false;
     if (live && (nbac > p.stride * 4u || p.bypass_bits[m] > p.stride * 4u)) retry = true;       // beyond the buffer: not a stream of ours
     if (live) {
@@ -418,6 +480,13 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
     const uint32_t size = live && !retry ? p.map_size : 0u;
     const uint4* src = reinterpret_cast<const uint4*>(p.streams + (uint64_t)(in_range ? m : 0u) * p.stride);
     const uint32_t nwords = size ? (nbac + 31u) >> 5 : 0u;          // words that hold stream bits; everything beyond reads as zero
+    // where this launch picks the stream up: bit 0, or where the last chunk parked the lane
+    uint4 parked = make_uint4(0u, 0u, 0u, kNotStarted);
+    uint2 parked2 = make_uint2(0u, 0u);
+    if (CHUNKED && size) { parked = p.dec_state[m]; parked2 = p.dec_state2[m]; }
+    const bool started = CHUNKED && parked.w != kNotStarted;
+    const uint32_t taken0 = started ? parked.w : 0u;      // stream bits taken so far
+    const uint32_t word0 = taken0 >> 5, wbase = word0 & ~3u;
 #ifdef EAE_DECODE_TOPUP_ZEROS
     // The FIRST form of this kernel (commit 377df1b), kept buildable (never shipped: scratch/variant.sh, EAE_HIP_LIB) because it
     // passed every stand-alone test and derailed next to MFMA kernels: words beyond the end of the stream are
@@ -455,23 +524,25 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
         ring[((w0 + 2u) & (kRing - 1u)) * 64u] = __builtin_bitreverse32(v.z);
         ring[((w0 + 3u) & (kRing - 1u)) * 64u] = __builtin_bitreverse32(v.w);
     };
-    // the ring starts full: words 0 .. 31
+    // the ring starts full: words wbase .. wbase + 31
     {
         uint4 first[kRing / 4u];
 #pragma unroll
-        for (uint32_t g = 0; g < kRing / 4u; g++) first[g] = fetch(4u * g);
+        for (uint32_t g = 0; g < kRing / 4u; g++) first[g] = fetch(wbase + 4u * g);
 #pragma unroll
-        for (uint32_t g = 0; g < kRing / 4u; g++) land(4u * g, first[g]);
+        for (uint32_t g = 0; g < kRing / 4u; g++) land(wbase + 4u * g, first[g]);
     }
 #endif
-    uint32_t loaded = kRing;              // words [0, loaded) have been in the ring
+    uint32_t loaded = wbase + kRing;      // words [.., loaded) have been in the ring
     // the window: the next `rcount` stream bits, left-aligned (the next bit in time at bit 63)
-    unsigned long long rwin = ((unsigned long long)ring[0] << 32) | (unsigned long long)ring[64];
-    uint32_t rcount = 64u, rword = 2u;
+    unsigned long long rwin = (((unsigned long long)ring[(word0 & (kRing - 1u)) * 64u] << 32) |
+                               (unsigned long long)ring[((word0 + 1u) & (kRing - 1u)) * 64u]) << (taken0 & 31u);
+    uint32_t rcount = 64u - (taken0 & 31u), rword = word0 + 2u;
+    uint32_t left = nbac > taken0 ? nbac - taken0 : 0u;      // stream bits not yet taken
+    uint32_t code32 = parked.z;
     // Bac::start_decoding (BinaryArithmeticCoder.cpp:104-122): 16 bits, the last one repeated once the stream is exhausted
-    uint32_t left = nbac;                 // stream bits not yet taken
-    uint32_t code32;
-    {
+    bool begun = started;
+    if (!started && (final_chunk || left >= kStepMargin)) {
         const uint32_t k = left < 16u ? left : 16u;
         uint32_t bits = (uint32_t)((rwin >> 1) >> (63u - k));
         const uint32_t sticky = bits & 1u;
@@ -480,11 +551,19 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
         rcount -= k;
         left -= k;
         code32 = bits << 16;
+        begun = true;
     }
     Interval s = interval_init();
     const double p0 = probs[lane];
     double pk = p0;
     uint32_t unary = 0, i = 0;
+    if (started) {
+        s.lo = parked.x;
+        s.hc = parked.y;
+        unary = parked2.x;
+        i = parked2.y;
+        pk = probs[unary * 64u + lane];
+    }
     uint8_t* prefix = p.prefixes + (size_t)(in_range ? m : 0u) * p.map_size;
     const uint32_t steps_left_any = wave_max(size);       // 0: nothing to do in this block
     uint4 fa = make_uint4(0u, 0u, 0u, 0u), fb = fa;        // eight words on their way from memory
@@ -511,7 +590,7 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
             }
 #pragma unroll
             for (uint32_t q = 0; q < 8; q++) {
-                if (i < size) {
+                if (i < size && (!CHUNKED || final_chunk || (begun && left >= kStepMargin))) {
                     // top the window up: 32 more bits once at most 32 are left (the read is unconditional, its use is not)
                     const uint32_t wnext = ring[(rword & (kRing - 1u)) * 64u];
                     const double pspec = probs[(unary + 1u) * 64u + lane];
@@ -539,8 +618,12 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
                     pk = done ? p0 : pspec;
                 }
             }
-            if (!__any(i < size)) break;
+            if (!__any(i < size && (!CHUNKED || final_chunk || (begun && left >= kStepMargin)))) break;
         }
+    }
+    if (CHUNKED && size && !final_chunk) {
+        p.dec_state[m] = make_uint4(s.lo, s.hc, code32, begun ? nbac - left : kNotStarted);
+        p.dec_state2[m] = make_uint2(unary, i);
     }
     if (live && retry) p.status[m] = RETRY;
 #ifdef EAE_HWID_PROBE
@@ -729,8 +812,8 @@ int eae_hip_coder_encode_batch(uint32_t n_maps, uint32_t map_size, const int16_t
     const SimdParams p = make_params(n_maps, map_size, L, symbols, probs, prob_row, streams, stride, bac_bits, bypass_bits,
                                      status, stage, workspace);
     hipLaunchKernelGGL(binarise_kernel, dim3(n_maps), dim3(64), 0, s, p);
-    hipLaunchKernelGGL(bac_encode_core_kernel, dim3((n_maps + 63u) / 64u), dim3(64), (size_t)L * 64u * sizeof(double), s, p);
-    hipLaunchKernelGGL(emit_kernel, dim3(n_maps), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(bac_encode_core_kernel<false>, dim3((n_maps + 63u) / 64u), dim3(64), (size_t)L * 64u * sizeof(double), s, p);
+    hipLaunchKernelGGL(emit_kernel<false>, dim3(n_maps), dim3(64), 0, s, p);
     const int rc = eae_coder_generic_encode(n_maps, map_size, symbols, L, probs, prob_row, streams, stride, bac_bits,
                                             bypass_bits, status, stage, RETRY, s);
     return rc ? rc : (int)hipGetLastError();
@@ -755,7 +838,7 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
     // L > 32, the general kernel decodes every map
     const bool fast = fast_applies(L) && map_size && have_ws && !check_simd_layout(map_size, L, streams, stride);
     if (fast) {
-        hipLaunchKernelGGL(bac_decode_core_kernel, dim3((n_maps + 63u) / 64u), dim3(64), decode_lds_bytes(L), s, p);
+        hipLaunchKernelGGL(bac_decode_core_kernel<false>, dim3((n_maps + 63u) / 64u), dim3(64), decode_lds_bytes(L), s, p);
         hipLaunchKernelGGL(debinarise_kernel, dim3(n_maps), dim3(64), 0, s, p);
     } else {
         hipLaunchKernelGGL(mark_kernel, dim3((n_maps + 255u) / 256u), dim3(256), 0, s, p);
@@ -770,5 +853,126 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
     }
     return (int)hipGetLastError();
 }
+
+#ifndef EAE_DECODE_TOPUP_ZEROS
+// ---- the chunked round trip: decoder and emit pass trailing the encoder core ------------------------------------------------
+// For a batch of one or two images the coder is two to four wavefronts and its time is the LENGTH of its serial chains: binarise
+// -> encoder core -> emit -> decoder core -> debinarise, one after the other (0.72 ms of the 1.2 ms one Kodak image takes, of
+// which the two cores are 0.29 + 0.33). Cut into chunks, the chains overlap: while the encoder core runs chunk c + 1, the emit
+// pass turns the records of chunk c into stream words and the decoder works through the words of chunk c - 1. Three streams,
+// nothing polled: launch order and events carry the dependencies, so the schedule can be captured into a hipGraph like any other.
+uint64_t eae_hip_coder_trailing_workspace_bytes(uint32_t n_maps, uint32_t map_size, uint8_t L) {
+    const uint64_t groups = ((uint64_t)n_maps + 63u) / 64u;
+    return eae_hip_coder_workspace_bytes(n_maps, map_size, L) + round256((uint64_t)n_maps * map_size) + round256(groups * 4u) +
+           round256((uint64_t)n_maps * 8u) + round256((uint64_t)n_maps * 16u) + round256((uint64_t)n_maps * 4u) +
+           round256((uint64_t)n_maps * 16u) + round256((uint64_t)n_maps * 8u) + 256u;
+}
+
+namespace {
+struct TrailingStreams {
+    hipStream_t emit = nullptr, decode = nullptr;
+    hipEvent_t encoded[16] = {}, emitted[16] = {}, start = nullptr, done = nullptr;
+};
+// a few sets, handed out in turn: calls that overlap in time (one per batch in flight) then do not share their side streams
+TrailingStreams* trailing_streams() {
+    static TrailingStreams sets[16][4];
+    static unsigned next[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    TrailingStreams& t = sets[dev][next[dev]++ & 3u];
+    if (!t.emit) {
+        if (hipStreamCreateWithFlags(&t.emit, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithFlags(&t.decode, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (int i = 0; i < 16; i++) {
+            if (hipEventCreateWithFlags(&t.encoded[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&t.emitted[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        if (hipEventCreateWithFlags(&t.start, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &t;
+}
+}  // namespace
+
+int eae_hip_coder_roundtrip_trailing(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, uint8_t L, const double* probs,
+                                     const int32_t* prob_row, uint8_t* streams, uint64_t stride, uint32_t* bac_bits,
+                                     uint32_t* bypass_bits, int32_t* status, int32_t* stage, void* workspace,
+                                     uint64_t workspace_bytes, uint32_t chunks, void* stream) {
+    if (!symbols || !probs || !streams || !bac_bits || !bypass_bits || !status || !workspace) return -1;
+    if (check_simd_layout(map_size, L, streams, stride)) return 1;
+    if (workspace_bytes < eae_hip_coder_trailing_workspace_bytes(n_maps, map_size, L)) return 1;
+    if (n_maps == 0) return 0;
+    if (chunks > 16u) chunks = 16u;
+    if (chunks < 2u || !fast_applies(L) || map_size == 0) {        // nothing to overlap: the two calls one after the other
+        const int rc = eae_hip_coder_encode_batch(n_maps, map_size, symbols, L, probs, prob_row, streams, stride, bac_bits, bypass_bits,
+                                                  status, stage, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        return eae_hip_coder_decode_batch(n_maps, map_size, nullptr, symbols, L, probs, prob_row, streams, stride, bac_bits, bypass_bits,
+                                          status, stage, workspace, workspace_bytes, stream);
+    }
+    TrailingStreams* t = trailing_streams();
+    if (!t) return (int)hipErrorUnknown;
+    hipStream_t s = (hipStream_t)stream;
+    SimdParams p = make_params(n_maps, map_size, L, symbols, probs, prob_row, streams, stride, bac_bits, bypass_bits, status, stage, workspace);
+    {   // the pieces only the chunked form needs, behind the standard ones: prefix bytes of their own (the records are still being
+        // read while the decoder writes them), the group chain lengths, and what crosses the launches
+        uint8_t* at = reinterpret_cast<uint8_t*>(p.records) + piece_b_bytes(n_maps, map_size, L);
+        const uint64_t groups = ((uint64_t)n_maps + 63u) / 64u;
+        p.prefixes = at; at += round256((uint64_t)n_maps * map_size);
+        p.group_steps = reinterpret_cast<uint32_t*>(at); at += round256(groups * 4u);
+        p.enc_state = reinterpret_cast<uint2*>(at); at += round256((uint64_t)n_maps * 8u);
+        p.emit_state = reinterpret_cast<uint4*>(at); at += round256((uint64_t)n_maps * 16u);
+        p.avail_bits = reinterpret_cast<uint32_t*>(at); at += round256((uint64_t)n_maps * 4u);
+        p.dec_state = reinterpret_cast<uint4*>(at); at += round256((uint64_t)n_maps * 16u);
+        p.dec_state2 = reinterpret_cast<uint2*>(at);
+    }
+    const dim3 per_map(n_maps), per_group((n_maps + 63u) / 64u), wave(64);
+    // every lane starts "not started" (0xFF..): a decoder chunk that finds too few bits leaves it so
+    (void)hipMemsetAsync(p.dec_state, 0xFF, (size_t)n_maps * 16u, s);
+    (void)hipMemsetAsync(p.avail_bits, 0, (size_t)n_maps * 4u, s);
+    hipLaunchKernelGGL(binarise_kernel, per_map, wave, 0, s, p);
+    (void)hipEventRecord(t->start, s);
+    (void)hipStreamWaitEvent(t->emit, t->start, 0);
+    (void)hipStreamWaitEvent(t->decode, t->start, 0);
+    p.nchunks = chunks;
+    for (uint32_t c = 0; c < chunks; c++) {
+        p.chunk = c;
+        hipLaunchKernelGGL(bac_encode_core_kernel<true>, per_group, wave, (size_t)L * 64u * sizeof(double), s, p);
+        (void)hipEventRecord(t->encoded[c], s);
+        (void)hipStreamWaitEvent(t->emit, t->encoded[c], 0);
+        hipLaunchKernelGGL(emit_kernel<true>, per_map, wave, 0, t->emit, p);
+        (void)hipEventRecord(t->emitted[c], t->emit);
+        if (c >= 1u && c + 1u < chunks) {
+            // decoder chunk c - 1, on what the emit pass of chunk c has put in memory (the last decoder chunk follows below)
+            SimdParams d = p;
+            d.chunk = c - 1u;
+            d.nchunks = chunks - 1u;
+            (void)hipStreamWaitEvent(t->decode, t->emitted[c], 0);
+            hipLaunchKernelGGL(bac_decode_core_kernel<true>, per_group, wave, decode_lds_bytes(L), t->decode, d);
+        }
+    }
+    // whatever the fast encoder could not finish, recoded by the general kernel (same bytes), then the decoder's last chunk on the
+    // complete streams, the data-parallel rest of the decoder and the comparison: the tail of eae_hip_coder_decode_batch
+    int rc = eae_coder_generic_encode(n_maps, map_size, symbols, L, probs, prob_row, streams, stride, bac_bits, bypass_bits, status, stage,
+                                      RETRY, t->emit);
+    if (rc) return rc;
+    (void)hipEventRecord(t->emitted[chunks - 1u], t->emit);
+    (void)hipStreamWaitEvent(t->decode, t->emitted[chunks - 1u], 0);
+    {
+        SimdParams d = p;
+        d.chunk = chunks - 2u;
+        d.nchunks = chunks - 1u;
+        hipLaunchKernelGGL(bac_decode_core_kernel<true>, per_group, wave, decode_lds_bytes(L), t->decode, d);
+        hipLaunchKernelGGL(debinarise_kernel, per_map, wave, 0, t->decode, d);
+        rc = eae_coder_generic_decode(n_maps, map_size, d.decoded, L, probs, prob_row, streams, stride, bac_bits, bypass_bits, status, stage,
+                                      RETRY, t->decode);
+        if (rc) return rc;
+        hipLaunchKernelGGL(compare_kernel, per_map, wave, 0, t->decode, d);
+    }
+    (void)hipEventRecord(t->done, t->decode);
+    (void)hipStreamWaitEvent(s, t->done, 0);
+    return (int)hipGetLastError();
+}
+#endif
 
 }  // extern "C"

@@ -591,6 +591,31 @@ def coder_decode_batch(streams, probabilities, prob_row, expected=None, workspac
     return out
 
 
+def coder_trailing_workspace(n_maps, map_size, truncated_unary_length, device):
+    """Scratch for coder_roundtrip_trailing (one per batch in flight)."""
+    nbytes = int(_native.hip().eae_hip_coder_trailing_workspace_bytes(n_maps, map_size, truncated_unary_length))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def coder_roundtrip_trailing(symbols_planar, probabilities, prob_row, truncated_unary_length, chunks=4, out=None, workspace=None):
+    """Encode every map, decode it back, compare (coder_encode_batch + coder_decode_batch(expected=symbols)) with the serial
+    chains cut into `chunks` launches so that emit pass and decoder trail the encoder core (include/eae_hip.h: for one or two
+    images). Same streams, bit counts, statuses and stages. Returns the CoderStreams."""
+    map_size = symbols_planar.shape[-1]
+    n_maps = symbols_planar.numel()//map_size
+    if symbols_planar.dtype != torch.int16 or probabilities.dtype != torch.float64:
+        raise TypeError('`symbols_planar` must be int16 and `probabilities` float64.')
+    if out is None:
+        out = CoderStreams(n_maps, map_size, truncated_unary_length, symbols_planar.device)
+    if workspace is None:
+        workspace = coder_trailing_workspace(n_maps, map_size, truncated_unary_length, symbols_planar.device)
+    _check(_native.hip().eae_hip_coder_roundtrip_trailing(n_maps, map_size, _p(symbols_planar), truncated_unary_length, _p(probabilities),
+                                                          _p(prob_row), _p(out.streams), out.stride, _p(out.bac_bits), _p(out.bypass_bits),
+                                                          _p(out.status), _p(out.stage), _p(workspace), workspace.numel(), int(chunks),
+                                                          _stream(symbols_planar)), 'eae_hip_coder_roundtrip_trailing')
+    return out
+
+
 def coder_pack_streams(streams, offsets, payload_bytes):
     """Gathers the valid stream bytes of every map into one uint8 device tensor; `offsets` int64 [n_maps, 2] (device)."""
     payload = torch.zeros(max(int(payload_bytes), 1), dtype=torch.uint8, device=streams.streams.device)

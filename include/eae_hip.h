@@ -330,6 +330,20 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
                                const uint32_t* bypass_bits, int32_t* status, int32_t* stage, void* workspace,
                                uint64_t workspace_bytes, void* stream);
 
+/* The round trip of lossless/c++/source/compression.cpp:27-64 (encode every map, decode it back, compare) for SMALL batches -- one or
+ * two images, two to four wavefronts of maps -- where what it costs is the length of its serial chains one after the other. The
+ * chains are cut into `chunks` launches (2..16; 4 is a good value): while the encoder core runs chunk c + 1 the emit pass assembles
+ * the stream words of chunk c and the decoder works through those of chunk c - 1, on two side streams of the library's own joined
+ * to `stream` by events (nothing is polled: capturable into a hipGraph). Results as eae_hip_coder_encode_batch followed by
+ * eae_hip_coder_decode_batch(expected = symbols): same stream bytes, bit counts, statuses (6 on a difference) and stages, same
+ * fall-back to the general kernel per map. workspace: eae_hip_coder_trailing_workspace_bytes. chunks < 2: the two calls one after
+ * the other. For large batches the transforms of the batches in flight hide the coder anyway and the extra launches only cost. */
+uint64_t eae_hip_coder_trailing_workspace_bytes(uint32_t n_maps, uint32_t map_size, uint8_t truncated_unary_length);
+int eae_hip_coder_roundtrip_trailing(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, uint8_t truncated_unary_length,
+                                     const double* probabilities, const int32_t* prob_row, uint8_t* streams,
+                                     uint64_t stream_stride_bytes, uint32_t* bac_bits, uint32_t* bypass_bits, int32_t* status,
+                                     int32_t* stage, void* workspace, uint64_t workspace_bytes, uint32_t chunks, void* stream);
+
 /* ---- container support (the reference never serialises, compression.cpp:27-64) ------------------
  * pack_streams: gathers the valid bytes of every map's two streams (layout above) into `payload`: the arithmetic-coded
  * bytes of map m at offsets[2m], its bypass bytes at offsets[2m+1] (uint64 byte offsets, device memory, chosen by the

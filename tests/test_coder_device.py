@@ -377,6 +377,108 @@ def test_batch_full_kodak_batch(gold, dev):
         assert valid_bytes_equal(a[m], b[m], bac[m]) and valid_bytes_equal(a[m, half:], b[m, half:], byp[m]), m
 
 
+# ---- the chunked round trip: emit pass and decoder trailing the encoder core (eae_hip_coder_roundtrip_trailing) ------------
+
+def trailing_code(dev, planar, probs, prob_row, chunks):
+    sym = torch.from_numpy(planar).cuda()
+    p = torch.from_numpy(numpy.ascontiguousarray(probs, dtype=numpy.float64)).cuda()
+    rows = torch.from_numpy(numpy.ascontiguousarray(prob_row, dtype=numpy.int32)).cuda()
+    streams = dev.coder_roundtrip_trailing(sym, p, rows, probs.shape[1], chunks=chunks)
+    torch.cuda.synchronize()
+    return streams, sym, p, rows
+
+
+@pytest.mark.parametrize('chunks', [1, 2, 3, 4, 8, 16])
+@pytest.mark.parametrize('scale', [0.3, 4., 300.])
+def test_trailing_round_trip_equals_the_host_coder(gold, dev, scale, chunks):
+    """One Kodak image's worth of maps (and a ragged second group) at three densities: whatever the number of chunks, the streams,
+    bit counts, statuses and stages are the host coder's, and the round trip finds nothing to complain about."""
+    rng = numpy.random.RandomState(int(scale*10) + chunks)
+    probs = gold['real_probabilities_1']
+    n = 128 + 37
+    planar = numpy.clip(numpy.round(rng.laplace(size=(n, 1536))*rng.uniform(0.05, 1., size=(n, 1))*scale), -32768, 32767).astype(numpy.int16)
+    planar[7] = 0
+    planar[130, :40] = 0
+    prob_row = (numpy.arange(n) % 128).astype(numpy.int32)
+    prob_row[67::128] = -1
+    (streams, sym, p, rows) = trailing_code(dev, planar, probs, prob_row, chunks)
+    ok = assert_equals_host(streams, planar, probs, prob_row, (scale, chunks))
+    assert ok.all()
+    # the streams it wrote decode with the ordinary decoder too
+    out = dev.coder_decode_batch(streams, p, rows).cpu().numpy()
+    keep = prob_row >= 0
+    assert numpy.array_equal(out[keep], planar[keep])
+
+
+def test_trailing_round_trip_large_maps_and_long_pending_runs(gold, dev):
+    """The maps of test_batch_large_maps_long_pending_runs_and_every_window_tier (128 x 128 latents; nearly dead maps whose pending
+    E3 runs make the emit pass give up, streams from a few words to thousands): a decoder chunk that finds too few bits in memory
+    parks, the general kernel recodes what the fast encoder hands over, and the result is the host coder's."""
+    rng = numpy.random.RandomState(77)
+    size = 128*128
+    n = 70
+    planar = numpy.zeros((n, size), dtype=numpy.int16)
+    probs = numpy.tile(gold['real_probabilities_1'][0], (n, 1))
+    for m in range(20):
+        probs[m, 0] = 1. - 10.**(-1. - 0.2*m)
+        if m % 2:
+            planar[m, rng.randint(0, size, size=m)] = rng.choice([-2, -1, 1, 3], size=m)
+    for m in range(20, n):
+        hits = rng.rand(size) < min(0.0005*1.25**(m - 20), 0.9)
+        planar[m, hits] = numpy.clip(numpy.round(rng.laplace(size=int(hits.sum()))*3.), -300, 300).astype(numpy.int16)
+    rows = numpy.arange(n, dtype=numpy.int32)
+    for chunks in (4, 7):
+        (streams, sym, p, r) = trailing_code(dev, planar, probs, rows, chunks)
+        assert assert_equals_host(streams, planar, probs, rows, ('large', chunks)).all()
+
+
+def test_trailing_round_trip_fuzz_including_errors(gold, dev):
+    """Random sizes, L, magnitudes, a few invalid probabilities and skipped maps: the statuses and stages after the chunked round
+    trip are those after encode_batch + decode_batch(expected), the bytes and bit counts the host coder's."""
+    rng = numpy.random.RandomState(321)
+    seen = set()
+    for t in range(120):
+        n_maps = int(rng.randint(1, 200))
+        size = int(rng.randint(1, 400))
+        L = int(rng.choice([1, 2, 5, 10, 31, 32, 33]))
+        chunks = int(rng.choice([2, 3, 4, 5, 9]))
+        scale = rng.choice([0.2, 1, 3, 10, 100, 5000], size=(n_maps, 1))
+        planar = numpy.clip(numpy.round(rng.laplace(size=(n_maps, size))*scale), -32768, 32767).astype(numpy.int16)
+        probs = numpy.clip(rng.rand(n_maps, L), 0.005, 0.995)
+        if t % 5 == 0:
+            probs[rng.randint(n_maps), rng.randint(L)] = rng.choice([0., 1., numpy.nan, -0.2])
+        rows = numpy.arange(n_maps, dtype=numpy.int32)
+        if t % 7 == 0:
+            rows[rng.randint(n_maps)] = -1
+        (streams, sym, p, r) = trailing_code(dev, planar, probs, rows, chunks)
+        assert_equals_host(streams, planar, probs, rows, (t, chunks))
+        (two, _, _, _) = batch_code(dev, planar, probs, rows)
+        dev.coder_decode_batch(two, p, r, expected=sym)
+        assert torch.equal(streams.status, two.status) and torch.equal(streams.stage, two.stage), t
+        seen.update(int(v) for v in streams.status.cpu().numpy())
+    assert {0, 1, 4} <= seen
+
+
+def test_trailing_round_trip_finds_a_difference(gold, dev):
+    """The comparison at the end of the round trip is a real one: symbols that change between the encoder's read and the
+    decoder's comparison (here: the caller's buffer rewritten behind the call) give status 6 for that map only."""
+    rng = numpy.random.RandomState(5)
+    probs = gold['real_probabilities_1']
+    planar = numpy.round(rng.laplace(size=(128, 1536))*2.).astype(numpy.int16)
+    rows = numpy.arange(128, dtype=numpy.int32)
+    sym = torch.from_numpy(planar).cuda()
+    p = torch.from_numpy(probs).cuda()
+    r = torch.from_numpy(rows).cuda()
+    streams = dev.coder_roundtrip_trailing(sym, p, r, 10, chunks=4)
+    torch.cuda.synchronize()
+    assert not streams.status.cpu().numpy().any()
+    other = sym.clone()
+    other[9, 100] += 1
+    dev.coder_decode_batch(streams, p, r, expected=other)
+    status = streams.status.cpu().numpy()
+    assert status[9] == 6 and not numpy.delete(status, 9).any()
+
+
 def test_argument_checks(dev):
     lib = _native.hip()
     assert lib.eae_hip_coder_compress_maps(1, 4, None, None, 3, None, None, None, 64, None, None, None, None, 1, 0, None) == -1

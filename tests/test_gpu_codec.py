@@ -430,3 +430,27 @@ def test_the_product_mode_at_kodak_size_equals_the_conservative_one():
             r = t.result()
             for key in ('nb_bits', 'sse', 'nb_deads'):
                 assert numpy.array_equal(r[key], want[k % 3][key]), (k, key)
+
+
+@pytest.mark.parametrize('graphs', [False, True])
+def test_a_trailing_coder_gives_the_same_results(graphs):
+    """One image per batch: the coder's chains cut into launches that overlap (`coder_chunks`) against the two calls one after
+    the other (`coder_chunks=1`, the default), launched kernel by kernel and replayed as hipGraphs."""
+    from autoencoder_based_image_compression_amd import codec
+    import bench
+    with numpy.load(GOLD) as g:
+        probabilities = g['real_probabilities_1']
+    variables = bench.synthetic_model(0.25)
+    images = torch.from_numpy(bench.synthetic_images(7, 3, 128, 192)).cuda()
+    mean = numpy.zeros(128, dtype=numpy.float32)
+    results = {}
+    for chunks in (None, 4, 7):
+        kwargs = {'nb_in_flight': 2, 'nb_transform_streams': 2, 'use_graphs': True} if graphs else {}
+        with codec.BatchCodec(variables, False, variables['piecewise_linear_function/bin_widths'], mean, probabilities, 67, 1, 128, 192,
+                              coder_chunks=chunks, **kwargs) as c:
+            assert c.coder_chunks == (1 if chunks is None else chunks)
+            tickets = [c.submit(images[j:j + 1]) for j in (0, 1, 2, 0, 1, 2)]
+            results[chunks] = [t.result() for t in tickets]
+    for chunks in (4, 7):
+        for (a, b) in zip(results[None], results[chunks]):
+            assert all(numpy.array_equal(a[k], b[k]) for k in a), chunks

@@ -41,6 +41,25 @@ _SIDE_STREAMS = {}          # (device index, kind) -> list of streams
 # The result worker polls its events and sleeps in between: `Event.synchronize()` was measured to spin a whole CPU per
 # process (with blocking events too), and eight ranks share one 16-CPU quota. 0 restores synchronize().
 _POLL_SECONDS = float(os.environ.get('EAE_WORKER_POLL_SECONDS', '0.0002'))
+# How the result worker learns that a batch is through. 'sequence' (default): the last launch of the coder side and of the synthesis
+# side bumps a step counter that lands in pinned host memory (device.publish_sequence); the worker, which knows how many times the
+# slot has been submitted, reads that word -- no HIP call and no event recorded for it, so the worker can never disturb a stream
+# capture (`_capture_all`), and a poll is a load. Measured against 'events' (round 3-4's way: one event per side per step,
+# `event.query()` every 0.2 ms; profiles/r05_wait_modes.log, r05_host_cpu_threads.log): same throughput within 0.5 %, the worker's
+# own CPU 0.7-0.9 ms per 3.0 ms step either way, and the 2.85 ms per step the HIP runtime's signal thread spends in
+# kfd_wait_on_events (system time) does NOT move: it does not come from the host's events.
+_WAIT_MODE = os.environ.get('EAE_WORKER_WAIT', 'sequence')
+_SEQUENCE_POLL_SECONDS = float(os.environ.get('EAE_WORKER_SEQUENCE_POLL_SECONDS', '0.0002'))
+_SEQUENCE_TIMEOUT_SECONDS = float(os.environ.get('EAE_WORKER_SEQUENCE_TIMEOUT_SECONDS', '60'))
+
+
+def _short_sleeps_for_this_thread():
+    """PR_SET_TIMERSLACK = 1 us for the calling thread (Linux rounds a sleep up by the slack, 50 us by default)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None, use_errno=True).prctl(29, 1000, 0, 0, 0)
+    except Exception:
+        pass
 
 
 # Stream priorities (experiments: scratch/r04): EAE_TRANSFORM_STREAM_PRIORITY / EAE_CODER_STREAM_PRIORITY, torch's numbering
@@ -87,8 +106,8 @@ class Ticket(object):
         #                                       after result(); valid until the slot comes round again (nb_slots submits later)
         self.fed_event = None                 # host input: recorded behind the host -> device copy (the caller's pinned batch may
         #                                       be rewritten once it has completed)
-        self.decoded_event = None             # recorded behind the synthesis transform: wait for it on another stream before
-        #                                       reading `reconstruction_uint8` there (valid until the slot comes round again)
+        self.decoded_event = None             # with keep_reconstruction: recorded behind the synthesis transform: wait for it on another
+        #                                       stream before reading `reconstruction_uint8` there (valid until the slot comes round again)
         self._coder_span = None               # (start, stop) timing events on the coder stream (BatchCodec(time_coder=True))
 
     def coder_ms(self):
@@ -126,13 +145,29 @@ class _Worker(threading.Thread):
         else:
             event.synchronize()
 
+    @staticmethod
+    def _wait_sequence(words, expected):
+        """Until the step counters the device leaves in pinned memory (`words`: numpy int32 view) have reached `expected`."""
+        deadline = None
+        for (index, value) in enumerate(expected):
+            while ((int(words[index]) - value) & 0xFFFFFFFF) >= 0x80000000:      # words[index] < value, wrap-around safe
+                time.sleep(_SEQUENCE_POLL_SECONDS)
+                if deadline is None:
+                    deadline = time.monotonic() + _SEQUENCE_TIMEOUT_SECONDS
+                elif time.monotonic() > deadline:
+                    raise RuntimeError('the device has not reported step {0} of this slot after {1:.0f} s (step counter at {2})'.format(
+                        value, _SEQUENCE_TIMEOUT_SECONDS, int(words[index])))
+
     def run(self):
+        _short_sleeps_for_this_thread()
         while True:
             job = self.jobs.get()
             if job is None:
                 return
-            (ticket, events, views, symbols_host, slot_free, recount, fetch) = job
+            (ticket, events, views, symbols_host, slot_free, recount, fetch, sequence) = job
             try:
+                if sequence is not None:
+                    self._wait_sequence(*sequence)
                 for event in events:
                     self._wait(event)
                 if fetch is not None:
@@ -332,6 +367,12 @@ class BatchCodec(object):
         self._workspaces = [make_workspace(n_maps, self.map_size, self.truncated_unary_length, self.device) for _ in range(self.nb_slots)]
         # scratch that lets the conv GEMM launches cut their last tiles (device.conv_workspace): a slot's launches never overlap each other
         self._conv_ws = [dev.conv_workspace(self.device) for _ in range(self.nb_slots)]
+        # step counters of every slot: [coder side, synthesis side] on the device, their published values in pinned memory, and how
+        # many times the host has submitted each side (what the result worker waits for)
+        self._seq_dev = [torch.zeros(2, dtype=torch.int32, device=self.device) for _ in range(self.nb_slots)]
+        self._pinned_seq = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(self.nb_slots)]
+        self._seq_host = [t.numpy() for t in self._pinned_seq]
+        self._counts = [[0, 0] for _ in range(self.nb_slots)]
         self._slot_free = [threading.Event() for _ in range(self.nb_slots)]
         for event in self._slot_free:
             event.set()
@@ -428,6 +469,8 @@ class BatchCodec(object):
         self._index += 1
         self._slot_free[slot].wait()
         self._slot_free[slot].clear()
+        sequence_mode = _WAIT_MODE == 'sequence'
+        expected = (self._counts[slot][0] + 1, self._counts[slot][1] + 1)      # what the slot's step counters will show behind this step
         try:
             caller = torch.cuda.current_stream()
             if self._graphs[slot] is None:
@@ -449,12 +492,15 @@ class BatchCodec(object):
                 torch.cuda.set_stream(coder_stream)
                 coder_stream.wait_event(quantized)
                 graphs[1].replay()
-                coded = torch.cuda.Event()
-                coded.record(coder_stream)
+                (coded, decoded) = (None, None)
+                if not sequence_mode:
+                    coded = torch.cuda.Event()
+                    coded.record(coder_stream)
                 torch.cuda.set_stream(stream)
                 graphs[2].replay()
-                decoded = torch.cuda.Event()
-                decoded.record(stream)
+                if not sequence_mode or self.keep_reconstruction:      # (a caller reading the reconstruction on another stream waits for it)
+                    decoded = torch.cuda.Event()
+                    decoded.record(stream)
             finally:
                 torch.cuda.set_stream(caller)
             if not fed:
@@ -466,10 +512,13 @@ class BatchCodec(object):
                 ticket.reconstruction_uint8 = reconstruction       # valid until this slot is replayed again
             if self._slot_views[slot] is None:
                 self._slot_views[slot] = self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],)
-            self._worker.jobs.put((ticket, (coded, decoded), self._slot_views[slot], None,
-                                   self._slot_free[slot], lambda: self._recount_exception_maps(slot), self._fetch_job(slot, reconstruction)))
+            self._worker.jobs.put((ticket, () if sequence_mode else (coded, decoded), self._slot_views[slot], None,
+                                   self._slot_free[slot], lambda: self._recount_exception_maps(slot), self._fetch_job(slot, reconstruction),
+                                   (self._seq_host[slot], expected) if sequence_mode else None))
+            self._counts[slot] = list(expected)
             return ticket
         except BaseException:
+            self._resync(slot)
             self._slot_free[slot].set()       # nobody will report on this slot: without this, drain() / close() wait for ever
             raise
 
@@ -509,6 +558,8 @@ class BatchCodec(object):
         self._index += 1
         self._slot_free[slot].wait()
         self._slot_free[slot].clear()
+        sequence_mode = _WAIT_MODE == 'sequence'
+        expected = (self._counts[slot][0] + 1, self._counts[slot][1] + 1)
         try:
             hook = self.launch_hook
             fed = []
@@ -528,24 +579,38 @@ class BatchCodec(object):
                     started = torch.cuda.Event(enable_timing=True)
                     started.record()
                 self._launch_coder(slot, hook)
-                coded = torch.cuda.Event(enable_timing=self.time_coder)
-                coded.record()
+                (coded, decoded) = (None, None)
+                if not sequence_mode or self.time_coder:
+                    coded = torch.cuda.Event(enable_timing=self.time_coder)
+                    coded.record()
                 if self.time_coder:
                     ticket._coder_span = (started, coded)
             reconstruction = self._launch_synthesis(latents, luminances_uint8, slot, hook)
-            decoded = torch.cuda.Event()
-            decoded.record()
+            if not sequence_mode or self.keep_reconstruction:
+                decoded = torch.cuda.Event()
+                decoded.record()
             ticket.decoded_event = decoded
             ticket.fed_event = fed[0] if fed else None
             if self.keep_reconstruction:
                 ticket.reconstruction_uint8 = reconstruction
-            self._worker.jobs.put((ticket, (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],),
+            self._worker.jobs.put((ticket, () if sequence_mode else (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],),
                                    self._pinned_symbols[slot], self._slot_free[slot], lambda: self._recount_exception_maps(slot),
-                                   self._fetch_job(slot, reconstruction)))
+                                   self._fetch_job(slot, reconstruction), (self._seq_host[slot], expected) if sequence_mode else None))
+            self._counts[slot] = list(expected)
             return ticket
         except BaseException:
+            self._resync(slot)
             self._slot_free[slot].set()       # as in _submit_graph
             raise
+
+    def _resync(self, slot):
+        """A submit that raised may have launched some of its step: wait for whatever it did launch and take the slot's step
+        counters from the device, so that the next job on this slot waits for the right values."""
+        try:
+            torch.cuda.synchronize(self.device)
+            self._counts[slot] = [int(v) for v in self._seq_dev[slot].cpu().tolist()]
+        except Exception:      # the device itself is in trouble: the next submit will say so
+            pass
 
     def _fetch_job(self, slot, reconstruction):
         """What the result worker needs to copy the slot's reconstruction to the host (None: not asked for)."""
@@ -621,6 +686,7 @@ class BatchCodec(object):
         else:
             self._views(self._slot_out[slot])[0].zero_()
         dev.publish_to_host(self._slot_out[slot], self._pinned_out[slot])
+        dev.publish_sequence(self._seq_dev[slot][0:1], self._pinned_seq[slot][0:1])
 
     def _launch_synthesis(self, latents, luminances_uint8, slot, hook):
         """tconv1+IGDN5 -> tconv2+IGDN6 -> tconv3 + BT.601 cast + squared error against the input, and the publication of the
@@ -637,6 +703,7 @@ class BatchCodec(object):
         # clean workspace for the slot's next step
         dev.conv_workspace_collect(ws, self._slot_unfinished[slot])
         dev.publish_to_host(self._slot_sse[slot], self._pinned_sse[slot])
+        dev.publish_sequence(self._seq_dev[slot][1:2], self._pinned_seq[slot][1:2])
         return reconstruction
 
     def drain(self):

@@ -84,6 +84,21 @@ __global__ void publish_kernel(const uint32_t* __restrict__ src, uint32_t* __res
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
     __threadfence_system();
 }
+// A step counter for the host: bumps a device word and leaves the new value in pinned host memory, behind everything the stream
+// has done so far (a kernel boundary orders it after the publish_kernel in front of it). A host thread that knows how many times
+// the step was submitted waits for that value with plain loads -- no event to record, query or wait on.
+__global__ void sequence_kernel(uint32_t* __restrict__ counter, volatile uint32_t* __restrict__ host_word) {
+    const uint32_t v = *counter + 1u;
+    *counter = v;
+    *host_word = v;
+    __threadfence_system();
+}
+extern "C" int eae_hip_publish_sequence(void* counter_device, void* word_host_mapped, void* stream) {
+    if (!counter_device || !word_host_mapped) return -1;
+    hipLaunchKernelGGL(sequence_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint32_t*)counter_device, (volatile uint32_t*)word_host_mapped);
+    return (int)hipGetLastError();
+}
+
 extern "C" int eae_hip_publish_to_host(const void* src_device, void* dst_host_mapped, uint64_t bytes, void* stream) {
     if (!src_device || !dst_host_mapped || (bytes & 3u)) return -1;
     if (bytes == 0) return 0;

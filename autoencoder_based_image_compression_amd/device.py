@@ -545,6 +545,16 @@ def publish_to_host(src_device, dst_pinned):
     _check(_native.hip().eae_hip_publish_to_host(_p(src_device), dst_pinned.data_ptr(), nbytes, _stream()), 'eae_hip_publish_to_host')
 
 
+def publish_sequence(counter_device, word_pinned):
+    """Stream-ordered: increments `counter_device` (int32 device tensor of one element) and leaves the new value in `word_pinned`
+    (int32 pinned host tensor of one element), behind everything the current stream has done so far (include/eae_hip.h)."""
+    if counter_device.numel() != 1 or counter_device.element_size() != 4 or word_pinned.numel() != 1 or word_pinned.element_size() != 4:
+        raise HipError('expected two 32-bit words')
+    if not word_pinned.is_pinned():
+        raise HipError('expected a pinned host word')
+    _check(_native.hip().eae_hip_publish_sequence(_p(counter_device), word_pinned.data_ptr(), _stream(counter_device)), 'eae_hip_publish_sequence')
+
+
 def coder_workspace(n_maps, map_size, truncated_unary_length, device):
     """Scratch for coder_encode_batch / coder_decode_batch (one per batch in flight)."""
     nbytes = int(_native.hip().eae_hip_coder_workspace_bytes(n_maps, map_size, truncated_unary_length))

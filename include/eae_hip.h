@@ -49,6 +49,11 @@ int eae_hip_partition_info(int* compute_units, int* xcds, int* whole_device);
  * memory into PINNED, device-mapped host memory (hipHostMalloc / torch pin_memory) in stream order; the host reads them
  * after synchronising an event recorded behind it. Unlike hipMemcpyAsync this never blocks the calling thread. */
 int eae_hip_publish_to_host(const void* src_device, void* dst_host_mapped, uint64_t bytes, void* stream);
+/* A step counter for a host thread: in stream order, *counter_device (uint32, device memory) is incremented and the new value is
+ * left in *word_host_mapped (uint32, pinned host memory), behind everything the stream did before -- in particular behind an
+ * eae_hip_publish_to_host in front of it. The host, which knows how many times it submitted the step, waits for that value with
+ * plain loads: no event to record, query or wait on (capturable into a hipGraph: every replay bumps the counter). */
+int eae_hip_publish_sequence(void* counter_device, void* word_host_mapped, void* stream);
 
 /* ---- whole-path entry points (csrc/hip/model.hip) --------------------------------------------------------------------
  * What `sess.run(entropy_ae.node_y, feed_dict={node_visible_units: batch})` (eae/batching.py:96-99) and

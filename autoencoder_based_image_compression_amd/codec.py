@@ -49,6 +49,13 @@ _POLL_SECONDS = float(os.environ.get('EAE_WORKER_POLL_SECONDS', '0.0002'))
 # own CPU 0.7-0.9 ms per 3.0 ms step either way, and the 2.85 ms per step the HIP runtime's signal thread spends in
 # kfd_wait_on_events (system time) does NOT move: it does not come from the host's events.
 _WAIT_MODE = os.environ.get('EAE_WORKER_WAIT', 'sequence')
+# Where a batch's coder work starts. The coder's first kernel is wide (binarise: one wavefront per map, 3,048 of them for 24 Kodak
+# images) and, launched the moment the symbols exist, runs exactly while transpose_conv_1 does -- the shortest of the conv GEMM
+# launches, which it stretched from 0.29 to 0.34 ms. '1': the coder stream waits for transpose_conv_1 instead (its wide pass then
+# falls into transpose_conv_2's 1.07 ms: tconv1 0.339 -> 0.304 ms, 0.66 -> 0.73 of peak; the step is the same within 0.1 %,
+# profiles/r05_coder_behind_tconv1.log). For one or two images per batch the step IS the coder's chain and starting it a launch
+# later only adds to it (one image 1.23 -> 1.37 ms): there the coder starts as soon as the symbols exist. '0' / '1' force either.
+_CODER_BEHIND_TCONV1 = os.environ.get('EAE_CODER_BEHIND_TCONV1')
 _SEQUENCE_POLL_SECONDS = float(os.environ.get('EAE_WORKER_SEQUENCE_POLL_SECONDS', '0.0002'))
 _SEQUENCE_TIMEOUT_SECONDS = float(os.environ.get('EAE_WORKER_SEQUENCE_TIMEOUT_SECONDS', '60'))
 
@@ -360,6 +367,7 @@ class BatchCodec(object):
                          for _ in range(self.nb_slots)]
         self._coder_streams = [dev.CoderStreams(n_maps, self.map_size, self.truncated_unary_length, self.device,
                                                 results=self._views(self._slot_out[i])[0]) for i in range(self.nb_slots)]
+        self._coder_behind_tconv1 = (n_maps > 256) if _CODER_BEHIND_TCONV1 is None else _CODER_BEHIND_TCONV1 != '0'
         self.coder_chunks = int(default_coder_chunks(n_maps) if coder_chunks is None else coder_chunks)
         if self.coder_chunks > 1 and coder != 'device':
             self.coder_chunks = 1
@@ -546,10 +554,12 @@ class BatchCodec(object):
             graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
             with torch.cuda.graph(graphs[0], stream=stream, capture_error_mode='thread_local'):
                 latents = self._launch_analysis(static_input, slot, None)
+                if self._coder_behind_tconv1:
+                    latents = self._launch_synthesis_head(latents, slot, None)
             with torch.cuda.graph(graphs[1], stream=coder_stream, capture_error_mode='thread_local'):
                 self._launch_coder(slot)
             with torch.cuda.graph(graphs[2], stream=stream, capture_error_mode='thread_local'):
-                reconstruction = self._launch_synthesis(latents, static_input, slot, None)
+                reconstruction = self._launch_synthesis(latents, static_input, slot, None, head_done=self._coder_behind_tconv1)
             self._graphs[slot] = (graphs, static_input, latents, reconstruction)
 
     def _submit(self, luminances_uint8):
@@ -570,6 +580,8 @@ class BatchCodec(object):
                 self._feed(luminances_uint8, self._staging[slot], fed, fresh)
                 luminances_uint8 = self._staging[slot]
             latents = self._launch_analysis(luminances_uint8, slot, hook)
+            if self._coder_behind_tconv1:
+                latents = self._launch_synthesis_head(latents, slot, hook)
             quantized = torch.cuda.Event()
             quantized.record()
             ticket = Ticket(self.batch_size)
@@ -585,7 +597,7 @@ class BatchCodec(object):
                     coded.record()
                 if self.time_coder:
                     ticket._coder_span = (started, coded)
-            reconstruction = self._launch_synthesis(latents, luminances_uint8, slot, hook)
+            reconstruction = self._launch_synthesis(latents, luminances_uint8, slot, hook, head_done=self._coder_behind_tconv1)
             if not sequence_mode or self.keep_reconstruction:
                 decoded = torch.cuda.Event()
                 decoded.record()
@@ -688,14 +700,22 @@ class BatchCodec(object):
         dev.publish_to_host(self._slot_out[slot], self._pinned_out[slot])
         dev.publish_sequence(self._seq_dev[slot][0:1], self._pinned_seq[slot][0:1])
 
-    def _launch_synthesis(self, latents, luminances_uint8, slot, hook):
+    def _launch_synthesis_head(self, latents, slot, hook):
+        """tconv1+IGDN5 on the current stream (the first launch of the synthesis side, apart: `_coder_behind_tconv1`)."""
+        hook = hook or self._no_hook
+        dec = self.decoder
+        d = dec.v
+        return hook('tconv1_igdn5', lambda: dev.tconv5x5s2(latents, dec.w4, d['decoder/biases_4'], dev.NORM_IGDN, dec.g[5], d['decoder/beta_5'],
+                                                           workspace=self._conv_ws[slot]))
+
+    def _launch_synthesis(self, latents, luminances_uint8, slot, hook, head_done=False):
         """tconv1+IGDN5 -> tconv2+IGDN6 -> tconv3 + BT.601 cast + squared error against the input, and the publication of the
-        squared errors, on the current stream. Returns the uint8 reconstruction."""
+        squared errors, on the current stream. Returns the uint8 reconstruction. head_done: `latents` is already tconv1's output."""
         hook = hook or self._no_hook
         dec = self.decoder
         d = dec.v
         ws = self._conv_ws[slot]
-        t = hook('tconv1_igdn5', lambda: dev.tconv5x5s2(latents, dec.w4, d['decoder/biases_4'], dev.NORM_IGDN, dec.g[5], d['decoder/beta_5'], workspace=ws))
+        t = latents if head_done else self._launch_synthesis_head(latents, slot, hook)
         t = hook('tconv2_igdn6', lambda: dev.tconv5x5s2(t, dec.w5, d['decoder/biases_5'], dev.NORM_IGDN, dec.g[6], d['decoder/beta_6'], workspace=ws))
         (_, reconstruction, _) = hook('tconv3', lambda: dev.tconv9x9s4_luma(t, dec.w6, want_f32=False, want_u8=True, ref_u8=luminances_uint8,
                                                                             sse=self._slot_sse[slot][:self.batch_size]))

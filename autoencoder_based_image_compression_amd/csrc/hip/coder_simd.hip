@@ -57,13 +57,13 @@ int eae_coder_generic_decode(uint32_t n_maps, uint32_t map_size, int16_t* out, u
 #define EAE_RES_BINARISE 47
 #endif
 #ifndef EAE_RES_ENCODE_CORE
-#define EAE_RES_ENCODE_CORE 39
+#define EAE_RES_ENCODE_CORE 47
 #endif
 #ifndef EAE_RES_EMIT
 #define EAE_RES_EMIT 23
 #endif
 #ifndef EAE_RES_DECODE_CORE
-#define EAE_RES_DECODE_CORE 47
+#define EAE_RES_DECODE_CORE 55
 #endif
 #ifndef EAE_RES_DEBINARISE
 #define EAE_RES_DEBINARISE 23
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(64) void bac_encode_core_kernel(const SimdParams p)
         }
     const uint32_t nd = live && !retry ? p.ndec[m] : 0u;
     uint32_t steps = wave_max(nd);
+    const uint32_t nd_all = ~wave_max(~(nd ? nd : 0xFFFFFFFFu));      // the fewest decisions of a lane that has any (all lanes idle: 2^32 - 1)
     const uint8_t* dec = p.decisions + (size_t)blockIdx.x * 64u * p.dcap + (size_t)lane * 8u;
     uint32_t* rec = p.records + (size_t)(in_range ? m : 0u) * p.rcap;
     Interval s = interval_init();
@@ -298,10 +299,17 @@ __global__ __launch_bounds__(64) void bac_encode_core_kernel(const SimdParams p)
             pq[q] = probs[(ctx < L ? ctx : 0u) * 64u + lane];
         }
         uint32_t r[8];
+        if (jb + 8u <= nd_all) {
+            // every lane that codes at all has these eight decisions: no mask per step (a lane without a map computes on zeros and
+            // stores nothing). Two thirds of the rounds of a Kodak batch: a map has at least one decision per symbol.
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) {
-            r[q] = 0u;
-            if (jb + q < nd) r[q] = encode_step(s, pq[q], ((uint32_t)(d8 >> (8u * q)) & 1u) != 0u);
+            for (uint32_t q = 0; q < 8; q++) r[q] = encode_step(s, pq[q], ((uint32_t)(d8 >> (8u * q)) & 1u) != 0u);
+        } else {
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                r[q] = 0u;
+                if (jb + q < nd) r[q] = encode_step(s, pq[q], ((uint32_t)(d8 >> (8u * q)) & 1u) != 0u);
+            }
         }
         // four records per 16-byte store (up to three entries beyond the map's last decision: the pad of rcap)
         if (jb < nd) *reinterpret_cast<uint4*>(rec + jb) = make_uint4(r[0], r[1], r[2], r[3]);
@@ -588,6 +596,41 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
                 fa = fetch(loaded);
                 fb = fetch(loaded + 4u);
             }
+            // A round in which every decoding lane has eight symbols and eight steps' worth of stream left (a step takes at most 30
+            // bits) runs without the per-step masks: no `i < size`, no end-of-stream extension, and the prefix byte is stored every
+            // step -- the running count, overwritten until the symbol's last decision leaves the final value (a lane's stores to
+            // one address stay in order). All but the last rounds of a map.
+#ifdef EAE_DECODE_TOPUP_ZEROS
+            const bool fast_round = false;                  // the first form of this kernel stays as it was built (tests/test_isa_guard.py)
+#else
+            const bool fast_round = !__any(size != 0u && (i + 8u > size || left < 8u * 30u)) &&
+                                    (!CHUNKED || final_chunk || !__any(size != 0u && !(begun && left >= kStepMargin + 8u * 30u)));
+#endif
+            if (fast_round) {
+                if (size) {
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; q++) {
+                        const uint32_t wnext = ring[(rword & (kRing - 1u)) * 64u];
+                        const double pspec = probs[(unary + 1u) * 64u + lane];
+                        const bool need = rcount <= 32u;
+                        rwin |= (unsigned long long)(need ? wnext : 0u) << (need ? 32u - rcount : 0u);
+                        rcount += need ? 32u : 0u;
+                        rword += need ? 1u : 0u;
+                        const DecodeStep d = decode_step(s, code32, pk);
+                        const uint32_t bits = (uint32_t)((rwin >> 1) >> (63u - d.take));
+                        rwin <<= d.take;
+                        rcount -= d.take;
+                        left -= d.take;
+                        code32 = shift_code(code32, d, bits);
+                        const uint32_t count = unary + (d.one ? 1u : 0u);       // a one: unary + 1 (= L when it ends the symbol); a zero: unary
+                        prefix[i] = (uint8_t)count;
+                        const bool done = !d.one || count == L;
+                        i += done ? 1u : 0u;
+                        unary = done ? 0u : count;
+                        pk = done ? p0 : pspec;
+                    }
+                }
+            } else {
 #pragma unroll
             for (uint32_t q = 0; q < 8; q++) {
                 if (i < size && (!CHUNKED || final_chunk || (begun && left >= kStepMargin))) {
@@ -617,6 +660,7 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
                     unary = done ? 0u : unary + 1u;
                     pk = done ? p0 : pspec;
                 }
+            }
             }
             if (!__any(i < size && (!CHUNKED || final_chunk || (begun && left >= kStepMargin)))) break;
         }

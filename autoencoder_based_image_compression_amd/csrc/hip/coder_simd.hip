@@ -781,6 +781,453 @@ __global__ __launch_bounds__(64) void compare_kernel(const SimdParams p) {
     if (__any(differ) && lane == 0) p.status[m] = MISMATCH;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// (6) the three serial stages as ONE workgroup per 64 maps, pipelined through LDS: encoder core -> bit writer -> decoder core
+// ---------------------------------------------------------------------------------------------------------------------
+// For one or two images the coder's cost is the LENGTH of its serial chains laid end to end (encoder core 0.29 ms, emit 0.02,
+// decoder core 0.33 of the 1.2 ms one Kodak image takes). Cut into launches on three streams the chains do overlap, but a hop
+// between streams costs 60-100 us on this runtime (eae_hip_coder_roundtrip_trailing, kept as an option). Here the three stages of
+// a group of 64 maps are three wavefronts of one workgroup -- each a 64-lanes-in-step serial chain on a SIMD of its own -- and what
+// passes between them passes through LDS:
+//   wave 0, the encoder core of bac_encode_core_kernel: its records go into a ring of kPipeRecords per lane instead of to memory;
+//   wave 1, the BIT WRITER: one map per lane like the cores, not one map per wavefront like emit_kernel (that pass is prefix sums
+//           over 64 records of ONE map: 2.1 instructions per record and map, 135 per step of a group; in step over 64 maps the
+//           same work is ~45): it appends a record's first bit, the pending E3 run and the rest to a 64-bit accumulator and sends
+//           whole 32-bit words to the stream in memory AND, bit-reversed, into the decoder's ring;
+//   wave 2, the decoder core of bac_decode_core_kernel, its ring filled by wave 1 instead of from memory: it steps while 46 more
+//           bits are known to be there (as in the chunked form) and runs on the exact bit count once the writer has flushed.
+// Flow control is three counters in LDS (records written; the slowest writer lane; per lane the words written / taken) read once
+// per round of eight steps; no stage can wait in a circle (the encoder only waits for the slowest writer lane, a writer lane only
+// for room in a ring whose reader is then not starved, a reader lane only for bits), every wait is bounded, and a wait that
+// expires aborts the workgroup: its maps go to the general kernel like anything else these kernels do not finish (long pending
+// runs, a stream that outgrows its region, an invalid probability). The records never see memory; emit_kernel's 64 wavefronts
+// per group are one.
+// Measured (round 5, one Kodak image's maps alone on the GPU, profiles/r05_fused_*.log; -DEAE_PIPE_PROBE counts cycles per role):
+// same bytes in every test, and NOT faster than the kernels it replaces -- 0.97 ms against 0.64 at 0.19 bpp, 2.45 against 2.33 at
+// 2 bpp. (a) At the headline's entropy a map's whole stream is 30-500 bits and the decoder looks 46 bits ahead: for the sparse
+// maps of a group nothing can be decoded before the stream is complete, and 64 lanes in step wait for the sparsest (the decoder
+// had done 27 of its 216 rounds when the writer finished). (b) At 2 bpp the stages do overlap (597 of 791 decoder rounds without
+// per-step checks, not one lost bet) but the bit writer, ~100 vector and mask instructions per record = 700 cycles, is slower than
+// either core and both wait for it (the encoder core 54 % of its time). So eae_hip_coder_roundtrip_fused is an entry point with
+// its tests, not what BatchCodec launches; a writer at the cores' 300 cycles per record would make it 1.5 against 2.33 ms at 2 bpp.
+constexpr uint32_t kPipeRecords = 64u;            // records per lane between encoder core and bit writer (a power of two)
+constexpr uint32_t kPipeSpinLimit = 1u << 21;     // sleeps before a wait gives up (~1 s): a bug or a dead neighbour, never a normal wait
+constexpr uint32_t kPipeDone = 0x80000000u, kPipeBad = 0x40000000u;
+
+// Everything the three wavefronts tell each other lives in LDS, and the LDS serves the requests of a CU in the order they arrive,
+// a wavefront's own in program order: a counter written after the data it covers is seen after that data by whoever reads the
+// counter first and the data second. So no fence (a workgroup-scope fence also waits for every global store in flight -- the
+// stream words, the prefix bytes: 1-2 us per round of eight steps, which made the first form of this kernel slower than the three
+// kernels it replaces): only the compiler must keep the order, and the LDS counter must be drained where a wave spins on it.
+#define EAE_PIPE_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+constexpr size_t pipe_lds_bytes(uint32_t L) {
+    return ((size_t)L + 1u) * 64u * sizeof(double) + ((size_t)kPipeRecords + kRing) * 64u * sizeof(uint32_t) + (8u + 4u * 64u) * sizeof(uint32_t);
+}
+
+#ifndef EAE_RES_PIPE
+#define EAE_RES_PIPE 63
+#endif
+
+#ifdef EAE_PIPE_PROBE      // scratch/r05/pipe_probe.py: where the three wavefronts of block 0 spend their cycles
+__device__ unsigned long long g_pipe_probe[3][4];      // per role: cycles in all, cycles waiting, rounds, HW_ID
+__device__ unsigned long long g_pipe_probe2[8];        // decoder: rounds and cycles when every stream was complete, fast rounds, lost bets, waits
+#define PIPE_T0() const long long probe_t0 = clock64(); long long probe_wait = 0, probe_mark = 0; unsigned probe_rounds = 0
+#define PIPE_WAIT_BEGIN() probe_mark = clock64()
+#define PIPE_WAIT_END() probe_wait += clock64() - probe_mark
+#define PIPE_ROUND() probe_rounds++
+#define PIPE_REPORT(role_) if (blockIdx.x == 0 && lane == 0) { g_pipe_probe[role_][0] = clock64() - probe_t0; g_pipe_probe[role_][1] = probe_wait; \
+    g_pipe_probe[role_][2] = probe_rounds; g_pipe_probe[role_][3] = __builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4); }
+#else
+#define PIPE_T0()
+#define PIPE_WAIT_BEGIN()
+#define PIPE_WAIT_END()
+#define PIPE_ROUND()
+#define PIPE_REPORT(role_)
+#endif
+
+__global__ __launch_bounds__(256) void coder_pipe_kernel(const SimdParams p) {
+    EAE_KEEP_LAST_VGPR_FREE(EAE_RES_PIPE);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));      // 0 encoder core, 1 bit writer, 2 decoder core, 3 nothing
+    const uint32_t m = blockIdx.x * 64u + lane;
+    const bool in_range = m < p.n_maps;
+    const int32_t row = in_range ? (p.prob_row ? p.prob_row[m] : (int32_t)m) : -1;
+    const uint32_t L = p.L;
+    double* probs = lds_dyn;                                                              // [L + 1][64], scaled (lean_step.h)
+    uint32_t* recring = reinterpret_cast<uint32_t*>(lds_dyn + ((size_t)L + 1u) * 64u);     // [kPipeRecords][64]
+    uint32_t* wring = recring + kPipeRecords * 64u;                                       // [kRing][64] stream words, bit-reversed
+    volatile uint32_t* ctl = wring + kRing * 64u;       // [0] records every coding lane has, [1] stop records written, [2] slowest writer lane, [3] abort
+    volatile uint32_t* lane_ok = ctl + 8;               // the lane codes a map here (valid probabilities, no earlier status)
+    volatile uint32_t* wr_words = lane_ok + 64;         // stream words the writer has sent | kPipeDone (stream complete) | kPipeBad (handed over)
+    volatile uint32_t* wr_bits = wr_words + 64;         // bits of a complete stream
+    volatile uint32_t* rd_word = wr_bits + 64;          // first stream word the decoder has not moved into its window yet
+    const bool live = in_range && row >= 0 && p.status[m] == 0;
+    __builtin_amdgcn_s_setprio(EAE_SIMD_PRIO);
+    if (role == 0u) {
+        bool good = live;
+        if (live) {
+            for (uint32_t k = 0; k < L; k++) {
+                const double pk = p.probs[(size_t)row * L + k];
+                probs[k * 64u + lane] = scale_probability(pk);
+                if (!(pk > 0. && pk < 1.)) good = false;       // the general kernel names the error if that context is ever coded
+            }
+            probs[L * 64u + lane] = scale_probability(0.5);
+        }
+        lane_ok[lane] = good ? 1u : 0u;
+        wr_words[lane] = 0u;
+        wr_bits[lane] = 0u;
+        rd_word[lane] = 0u;
+        if (lane < 8u) ctl[lane] = 0u;
+    }
+    __syncthreads();
+    if (role == 3u) return;
+    const bool good = lane_ok[lane] != 0u;
+    const uint32_t nd = good ? p.ndec[m] : 0u;
+
+    PIPE_T0();
+    if (role == 0u) {
+        // ---- encoder core: bac_encode_core_kernel, records into the ring
+        const uint32_t steps = wave_max(nd);
+        const uint32_t nd_all = ~wave_max(~(nd ? nd : 0xFFFFFFFFu));
+        const uint8_t* dec = p.decisions + (size_t)blockIdx.x * 64u * p.dcap + (size_t)lane * 8u;
+        Interval s = interval_init();
+        uint2 ahead = steps ? *reinterpret_cast<const uint2*>(dec) : make_uint2(0, 0);
+        bool gave_up = false;
+        // room: records [.., upto) must not pass the slowest writer lane by more than the ring (the writer publishes that lane once
+        // per round; lanes that only wait for their stop record do not count)
+        auto wait_for_room = [&](uint32_t upto) {
+            uint32_t spins = 0;
+            for (;;) {
+                EAE_PIPE_ORDER();
+                const uint32_t slowest = ctl[2];
+                if (slowest == 0xFFFFFFFFu || upto <= slowest + kPipeRecords) return true;
+                if (ctl[3] != 0u || ++spins > kPipeSpinLimit) return false;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        };
+        for (uint32_t jb = 0; jb < steps; jb += 8) {
+            PIPE_WAIT_BEGIN();
+            const bool room_ok = wait_for_room(jb + 8u);
+            PIPE_WAIT_END();
+            PIPE_ROUND();
+            if (!room_ok) { gave_up = true; break; }
+            const unsigned long long d8 = (unsigned long long)ahead.x | ((unsigned long long)ahead.y << 32);
+            if (jb + 8 < steps) ahead = *reinterpret_cast<const uint2*>(dec + (size_t)((jb >> 3) + 1u) * 512u);
+            double pq[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                const uint32_t ctx = (uint32_t)(d8 >> (8u * q + 1u)) & 31u;
+                pq[q] = probs[(ctx < L ? ctx : 0u) * 64u + lane];
+            }
+            uint32_t r[8];
+            if (jb + 8u <= nd_all) {
+#pragma unroll
+                for (uint32_t q = 0; q < 8; q++) r[q] = encode_step(s, pq[q], ((uint32_t)(d8 >> (8u * q)) & 1u) != 0u);
+            } else {
+#pragma unroll
+                for (uint32_t q = 0; q < 8; q++) {
+                    r[q] = 0u;
+                    if (jb + q < nd) r[q] = encode_step(s, pq[q], ((uint32_t)(d8 >> (8u * q)) & 1u) != 0u);
+                }
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++)
+                if (jb + q < nd) recring[((jb + q) & (kPipeRecords - 1u)) * 64u + lane] = r[q];      // (a lane never writes beyond ITS records: the slot of its stop record stays free)
+            EAE_PIPE_ORDER();
+            if (lane == 0u) ctl[0] = jb + 8u;
+        }
+        if (!gave_up && !wait_for_room(steps + 1u)) gave_up = true;       // the stop records: slot nd of every lane
+        if (!gave_up) {
+            if (nd) recring[(nd & (kPipeRecords - 1u)) * 64u + lane] = stop_record(s);       // BinaryArithmeticCoder.cpp:61-102
+            EAE_PIPE_ORDER();
+            if (lane == 0u) ctl[1] = 1u;
+        } else if (lane == 0u) {
+            ctl[3] = 1u;
+        }
+        if (live && !good) p.status[m] = RETRY;          // the general kernel reproduces the exact code and stage
+        PIPE_REPORT(0);
+        return;
+    }
+
+    if (role == 1u) {
+        // ---- bit writer: emit_kernel's stream, one map per lane
+        uint32_t* out = reinterpret_cast<uint32_t*>(p.streams + (uint64_t)(in_range ? m : 0u) * p.stride);
+        const uint32_t size_bits = round_up_to_byte(required_bits(p.map_size, L));
+        uint32_t j = 0, cnt = 0, nwords = 0, pending = 0, total = 0;
+        unsigned long long acc = 0ull;
+        bool fin = nd == 0u, bad = false;
+        uint32_t spins = 0;
+        bool gave_up = false;
+        auto flush = [&]() {
+            const uint32_t word = (uint32_t)acc;
+            wring[(nwords & (kRing - 1u)) * 64u + lane] = __builtin_bitreverse32(word);
+            out[nwords] = word;
+            acc >>= 32;
+            cnt -= 32u;
+            nwords++;
+        };
+        for (;;) {
+            EAE_PIPE_ORDER();
+            const uint32_t have = ctl[0], stopped = ctl[1], taken_words = rd_word[lane];
+            // how many records this lane takes this round: what the encoder has left for it (its stop record once the encoder is
+            // through), at most eight, and only as many as the decoder's ring has room for -- one word per record on the short path,
+            // three spare for a long pending run, after which the lane rests until the next round
+            const uint32_t ordinary = j < nd ? (have < nd ? have : nd) - j : 0u;
+            const uint32_t ready = ordinary + ((j + ordinary == nd && stopped != 0u) ? 1u : 0u);
+            const uint32_t slots = taken_words + kRing - nwords;
+            uint32_t limit = ready < 8u ? ready : 8u;
+            limit = limit + 3u <= slots ? limit : (slots > 3u ? slots - 3u : 0u);
+            if (fin || bad) limit = 0u;
+            const bool progressed = limit != 0u;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                const bool go = q < limit;
+                const uint32_t r = recring[(j & (kPipeRecords - 1u)) * 64u + lane];
+                const uint32_t n = record_n(r), k = record_k(r), stop = (r >> 4) & 1u;
+                const uint32_t queue = pending + stop;
+                const uint32_t lead = record_leaving(r);
+                const uint32_t first = lead >> 31;
+                const uint32_t rest = __builtin_bitreverse32(lead << 1) & ((1u << ((n - 1u) & 31u)) - 1u);       // the other n - 1 leaving bits
+                const bool has = go && n != 0u;
+                // a stream beyond its region (Bitstream.cpp:32-35) or a pending run of hundreds of bits: the general kernel's
+                if (has && (total + n + queue > size_bits || queue > 64u)) bad = true;
+                const bool emit = has && !bad;
+                if (__any(emit && queue > 15u)) {
+                    // a long pending run somewhere in the wave (nearly dead maps under a very skewed first probability): bit by piece
+                    if (emit) {
+                        acc |= (unsigned long long)first << cnt;
+                        cnt += 1u;
+                        if (cnt >= 32u) flush();
+                        for (uint32_t left_run = queue; left_run != 0u;) {
+                            const uint32_t t = left_run < 16u ? left_run : 16u;
+                            acc |= (unsigned long long)(first ? 0u : ((1u << t) - 1u)) << cnt;
+                            cnt += t;
+                            if (cnt >= 32u) flush();
+                            left_run -= t;
+                        }
+                        acc |= (unsigned long long)rest << cnt;
+                        cnt += n - 1u;
+                        if (cnt >= 32u) flush();
+                        if (queue > 15u) limit = q + 1u;          // it may have sent three words: the room was counted for one
+                    }
+                } else {
+                    // the first leaving bit, `queue` copies of its complement, then the other n - 1 (first in time at bit 0): <= 31 bits
+                    const uint32_t run = first ? 0u : ((1u << (queue & 31u)) - 1u);
+                    const uint32_t v = first | (run << 1) | (rest << ((queue + 1u) & 31u));
+                    acc |= (unsigned long long)(emit ? v : 0u) << cnt;
+                    cnt += emit ? n + queue : 0u;
+                    if (cnt >= 32u) flush();
+                }
+                total += emit ? n + queue : 0u;
+                pending = go ? (n != 0u ? k : pending + k) : pending;
+                j += go ? 1u : 0u;
+                if (__any(go && stop != 0u)) {
+                    if (go && stop != 0u && !bad) {
+                        if (cnt) { cnt = 32u; flush(); }              // Bitstream flush of the partial word (zeros above the last bit)
+                        fin = true;
+                        p.bac_bits[m] = total;
+                    }
+                }
+            }
+            wr_bits[lane] = total;
+            EAE_PIPE_ORDER();
+            wr_words[lane] = nwords | (fin ? kPipeDone : 0u) | (bad ? kPipeBad : 0u);
+            const uint32_t mine = (!fin && !bad && j < nd) ? j : 0xFFFFFFFFu;
+            const uint32_t slowest = ~wave_max(~mine);
+            if (lane == 0u) ctl[2] = slowest;
+            if (!__any(!fin && !bad)) break;
+            PIPE_ROUND();
+            if (__any(progressed)) spins = 0;
+            else {
+                if (ctl[3] != 0u || ++spins > kPipeSpinLimit) { gave_up = true; break; }
+                PIPE_WAIT_BEGIN();
+                __builtin_amdgcn_s_sleep(2);
+                PIPE_WAIT_END();
+            }
+        }
+        PIPE_REPORT(1);
+        if (gave_up && lane == 0u) ctl[3] = 1u;
+        if (good && (bad || gave_up || ctl[3] != 0u)) p.status[m] = RETRY;
+        return;
+    }
+
+    // ---- decoder core: bac_decode_core_kernel, its ring filled by the bit writer
+    uint32_t* ring = wring + lane;
+    const uint32_t size = good ? p.map_size : 0u;
+    Interval s = interval_init();
+    const double p0 = probs[lane];
+    double pk = p0;
+    uint32_t unary = 0, i = 0, taken = 0, code32 = 0, rcount = 0, rword = 0;
+    unsigned long long rwin = 0ull;
+    bool begun = false, dropped = size == 0u;
+#ifdef EAE_PIPE_PROBE
+    bool probe_seen_complete = false;
+    unsigned probe_fast = 0, probe_lost = 0, probe_waits = 0;
+#endif
+    uint8_t* prefix = p.prefixes + (size_t)(in_range ? m : 0u) * p.map_size;
+    uint32_t spins = 0;
+    for (;;) {
+        EAE_PIPE_ORDER();
+        const uint32_t w = wr_words[lane];
+        const bool complete = (w & kPipeDone) != 0u;
+        if (w & kPipeBad) dropped = true;
+        EAE_PIPE_ORDER();
+        const uint32_t avail = complete ? wr_bits[lane] : (w & 0x3FFFFFFFu) * 32u;      // stream bits in the ring so far (all of them once complete)
+        bool progressed = false;
+#ifdef EAE_PIPE_PROBE
+        if (blockIdx.x == 0 && !probe_seen_complete && !__any(!dropped && !complete)) {
+            probe_seen_complete = true;
+            if (lane == 0) { g_pipe_probe2[0] = probe_rounds; g_pipe_probe2[1] = clock64() - probe_t0; }
+        }
+#endif
+        // A round costs the wavefront the same whether one lane steps or all of them: wait until every lane that still decodes has
+        // the 46 bits a step needs and two words beyond (or its whole stream) -- lanes are fed at the pace of their own maps, and
+        // stepping whenever any of them could ran 2.6 rounds per round of the encoder.
+        // ... unless some lane's ring is half full: its writer lane must never be left without room while this wave waits for
+        // another lane (the encoder stops within a ring of records of its slowest writer lane, and would starve that other lane).
+        const bool fed = complete || avail - taken >= kStepMargin + 64u;
+        const bool crowded = !dropped && i < size && avail - taken >= 16u * 32u;
+        if (__any(!dropped && i < size && !fed) && !__any(crowded)) {
+            if (ctl[3] != 0u || ++spins > kPipeSpinLimit) { if (lane == 0u) ctl[3] = 1u; break; }
+            PIPE_WAIT_BEGIN();
+            __builtin_amdgcn_s_sleep(4);
+            PIPE_WAIT_END();
+            continue;
+        }
+        spins = 0;
+        if (!dropped && !begun && (complete || avail >= 64u)) {
+            // Bac::start_decoding (BinaryArithmeticCoder.cpp:104-122): 16 bits, the last one repeated once the stream is exhausted
+            rwin = ((unsigned long long)ring[0] << 32) | (unsigned long long)ring[64];
+            rcount = 64u;
+            rword = 2u;
+            const uint32_t k = avail < 16u ? avail : 16u;
+            uint32_t bits = (uint32_t)((rwin >> 1) >> (63u - k));
+            const uint32_t sticky = bits & 1u;
+            bits = (bits << (16u - k)) | (sticky ? ((1u << (16u - k)) - 1u) : 0u);
+            rwin <<= k;
+            rcount -= k;
+            taken = k;
+            code32 = bits << 16;
+            begun = true;
+            progressed = true;
+        }
+        // A round in which every lane that still decodes has begun, has eight symbols left and -- its stream complete -- eight
+        // steps' worth of bits, or -- its stream still growing -- the 46 bits a step needs, runs WITHOUT per-step checks, like the
+        // fast rounds of bac_decode_core_kernel. For a growing stream that is a bet (a step takes 30 bits at most, 0.3-1.5 on
+        // average): the lane's state is parked in registers first, the window only takes words the writer has sent, and if any
+        // lane ends the round having taken more bits than its stream had, every lane goes back to the parked state and the
+        // round is run again step by step with the checks.
+        const uint32_t sent = complete ? 0xFFFFFFFFu : (w & 0x3FFFFFFFu);                 // words the window may take
+        bool fast_round = !__any(!dropped && i < size && (!begun || i + 8u > size || (complete ? avail - taken < 8u * 30u : avail - taken < kStepMargin)));
+        if (fast_round) {
+            const Interval s0 = s;
+            const uint32_t code0 = code32, rcount0 = rcount, rword0 = rword, taken0 = taken, unary0 = unary, i0 = i;
+            const unsigned long long rwin0 = rwin;
+            const double pk0 = pk;
+            if (!dropped && i < size) {
+#pragma unroll
+                for (uint32_t q = 0; q < 8; q++) {
+                    const uint32_t wnext = ring[(rword & (kRing - 1u)) * 64u];
+                    const double pspec = probs[(unary + 1u) * 64u + lane];
+                    const bool need = rcount <= 32u && rword < sent;
+                    rwin |= (unsigned long long)(need ? wnext : 0u) << (need ? 32u - rcount : 0u);
+                    rcount += need ? 32u : 0u;
+                    rword += need ? 1u : 0u;
+                    const DecodeStep d = decode_step(s, code32, pk);
+                    const uint32_t bits = (uint32_t)((rwin >> 1) >> (63u - d.take));
+                    rwin <<= d.take;
+                    rcount -= d.take;
+                    taken += d.take;
+                    code32 = shift_code(code32, d, bits);
+                    const uint32_t count = unary + (d.one ? 1u : 0u);
+                    prefix[i] = (uint8_t)count;
+                    const bool done = !d.one || count == L;
+                    i += done ? 1u : 0u;
+                    unary = done ? 0u : count;
+                    pk = done ? p0 : pspec;
+                }
+            }
+            if (__any(!dropped && taken > avail)) {            // the bet is lost: back to the parked state, and step by step below
+                s = s0; code32 = code0; rcount = rcount0; rword = rword0; taken = taken0; unary = unary0; i = i0; rwin = rwin0; pk = pk0;
+                fast_round = false;
+#ifdef EAE_PIPE_PROBE
+                probe_lost++;
+#endif
+            } else {
+                progressed = true;
+#ifdef EAE_PIPE_PROBE
+                probe_fast++;
+#endif
+            }
+        }
+        if (!fast_round) {
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+            if (!dropped && begun && i < size && (complete || avail - taken >= kStepMargin)) {
+                const uint32_t wnext = ring[(rword & (kRing - 1u)) * 64u];
+                const double pspec = probs[(unary + 1u) * 64u + lane];
+                const bool need = rcount <= 32u;
+                rwin |= (unsigned long long)(need ? wnext : 0u) << (need ? 32u - rcount : 0u);
+                rcount += need ? 32u : 0u;
+                rword += need ? 1u : 0u;
+                const DecodeStep d = decode_step(s, code32, pk);
+                const uint32_t left = avail - taken;
+                const uint32_t k = d.take < left ? d.take : left;
+                uint32_t bits = (uint32_t)((rwin >> 1) >> (63u - k));
+                const uint32_t ext = d.take - k;
+                bits = (bits << ext) | ((bits & 1u) ? ((1u << ext) - 1u) : 0u);
+                rwin <<= k;
+                rcount -= k;
+                taken += k;
+                code32 = shift_code(code32, d, bits);
+                const bool done = !d.one || unary + 1u == L;
+                if (done) prefix[i] = (uint8_t)(d.one ? L : unary);
+                i += done ? 1u : 0u;
+                unary = done ? 0u : unary + 1u;
+                pk = done ? p0 : pspec;
+                progressed = true;
+            }
+        }
+        }
+        rd_word[lane] = rword >= 2u ? rword - 2u : 0u;      // the window holds words rword - 2 and rword - 1 at most: everything below has left the ring
+        EAE_PIPE_ORDER();
+        if (!__any(!dropped && i < size)) break;
+        PIPE_ROUND();
+        if (__any(progressed)) spins = 0;
+        else {
+            if (ctl[3] != 0u || ++spins > kPipeSpinLimit) { if (lane == 0u) ctl[3] = 1u; break; }
+            PIPE_WAIT_BEGIN();
+            __builtin_amdgcn_s_sleep(2);
+            PIPE_WAIT_END();
+        }
+    }
+    PIPE_REPORT(2);
+#ifdef EAE_PIPE_PROBE
+    if (blockIdx.x == 0 && lane == 0) { g_pipe_probe2[2] = probe_fast; g_pipe_probe2[3] = probe_lost; }
+#endif
+    if (!dropped && i < size) p.status[m] = RETRY;      // an aborted workgroup: what was not decoded here is the general kernel's
+}
+
+#ifdef EAE_PIPE_PROBE
+extern "C" int eae_hip_debug_pipe_probe(unsigned long long* out12) {
+    return (int)hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_pipe_probe), 12 * sizeof(unsigned long long));
+}
+extern "C" int eae_hip_debug_pipe_probe2(unsigned long long* out8) {
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pipe_probe2), 8 * sizeof(unsigned long long));
+}
+#endif
+
+// which maps the pipeline handed to the general kernel: their decoder is the general kernel's too (the pipeline left no prefixes)
+__global__ void pipe_note_kernel(const SimdParams p) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < p.n_maps) p.avail_bits[m] = p.status[m] == RETRY ? 1u : 0u;
+}
+__global__ void pipe_restore_kernel(const SimdParams p) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < p.n_maps && p.avail_bits[m] != 0u && p.status[m] == 0) p.status[m] = RETRY;
+}
+
 // status 0 -> RETRY for the coded maps: hands every map that has not failed to the general kernel
 __global__ void mark_kernel(const SimdParams p) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1015,6 +1462,38 @@ int eae_hip_coder_roundtrip_trailing(uint32_t n_maps, uint32_t map_size, const i
     }
     (void)hipEventRecord(t->done, t->decode);
     (void)hipStreamWaitEvent(s, t->done, 0);
+    return (int)hipGetLastError();
+}
+// ---- the round trip with the three serial stages of a group in ONE workgroup (coder_pipe_kernel) -----------------------------
+int eae_hip_coder_roundtrip_fused(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, uint8_t L, const double* probs,
+                                  const int32_t* prob_row, uint8_t* streams, uint64_t stride, uint32_t* bac_bits,
+                                  uint32_t* bypass_bits, int32_t* status, int32_t* stage, void* workspace,
+                                  uint64_t workspace_bytes, void* stream) {
+    if (!symbols || !probs || !streams || !bac_bits || !bypass_bits || !status || !workspace) return -1;
+    if (check_simd_layout(map_size, L, streams, stride)) return 1;
+    if (workspace_bytes < eae_hip_coder_trailing_workspace_bytes(n_maps, map_size, L)) return 1;
+    if (n_maps == 0) return 0;
+    if (!fast_applies(L) || map_size == 0) {
+        const int rc = eae_hip_coder_encode_batch(n_maps, map_size, symbols, L, probs, prob_row, streams, stride, bac_bits, bypass_bits,
+                                                  status, stage, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        return eae_hip_coder_decode_batch(n_maps, map_size, nullptr, symbols, L, probs, prob_row, streams, stride, bac_bits, bypass_bits,
+                                          status, stage, workspace, workspace_bytes, stream);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SimdParams p = make_params(n_maps, map_size, L, symbols, probs, prob_row, streams, stride, bac_bits, bypass_bits, status, stage, workspace);
+    p.avail_bits = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(p.records) + piece_b_bytes(n_maps, map_size, L));      // one flag per map
+    const dim3 per_map(n_maps), per_group((n_maps + 63u) / 64u), wave(64), flat((n_maps + 255u) / 256u);
+    hipLaunchKernelGGL(binarise_kernel, per_map, wave, 0, s, p);
+    hipLaunchKernelGGL(coder_pipe_kernel, per_group, dim3(256), pipe_lds_bytes(L), s, p);
+    hipLaunchKernelGGL(pipe_note_kernel, flat, dim3(256), 0, s, p);
+    int rc = eae_coder_generic_encode(n_maps, map_size, symbols, L, probs, prob_row, streams, stride, bac_bits, bypass_bits, status, stage, RETRY, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pipe_restore_kernel, flat, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(debinarise_kernel, per_map, wave, 0, s, p);
+    rc = eae_coder_generic_decode(n_maps, map_size, p.decoded, L, probs, prob_row, streams, stride, bac_bits, bypass_bits, status, stage, RETRY, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(compare_kernel, per_map, wave, 0, s, p);
     return (int)hipGetLastError();
 }
 #endif

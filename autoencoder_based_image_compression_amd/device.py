@@ -626,6 +626,25 @@ def coder_roundtrip_trailing(symbols_planar, probabilities, prob_row, truncated_
     return out
 
 
+def coder_roundtrip_fused(symbols_planar, probabilities, prob_row, truncated_unary_length, out=None, workspace=None):
+    """Encode every map, decode it back, compare, with the three serial stages of a group of 64 maps as three wavefronts of one
+    workgroup handing records and stream words to each other through LDS (include/eae_hip.h: eae_hip_coder_roundtrip_fused). Same
+    streams, bit counts, statuses and stages as coder_encode_batch + coder_decode_batch(expected=symbols). Returns the CoderStreams."""
+    map_size = symbols_planar.shape[-1]
+    n_maps = symbols_planar.numel()//map_size
+    if symbols_planar.dtype != torch.int16 or probabilities.dtype != torch.float64:
+        raise TypeError('`symbols_planar` must be int16 and `probabilities` float64.')
+    if out is None:
+        out = CoderStreams(n_maps, map_size, truncated_unary_length, symbols_planar.device)
+    if workspace is None:
+        workspace = coder_trailing_workspace(n_maps, map_size, truncated_unary_length, symbols_planar.device)
+    _check(_native.hip().eae_hip_coder_roundtrip_fused(n_maps, map_size, _p(symbols_planar), truncated_unary_length, _p(probabilities),
+                                                       _p(prob_row), _p(out.streams), out.stride, _p(out.bac_bits), _p(out.bypass_bits),
+                                                       _p(out.status), _p(out.stage), _p(workspace), workspace.numel(), _stream(symbols_planar)),
+           'eae_hip_coder_roundtrip_fused')
+    return out
+
+
 def coder_pack_streams(streams, offsets, payload_bytes):
     """Gathers the valid stream bytes of every map into one uint8 device tensor; `offsets` int64 [n_maps, 2] (device)."""
     payload = torch.zeros(max(int(payload_bytes), 1), dtype=torch.uint8, device=streams.streams.device)

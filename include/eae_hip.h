@@ -349,6 +349,17 @@ int eae_hip_coder_roundtrip_trailing(uint32_t n_maps, uint32_t map_size, const i
                                      uint64_t stream_stride_bytes, uint32_t* bac_bits, uint32_t* bypass_bits, int32_t* status,
                                      int32_t* stage, void* workspace, uint64_t workspace_bytes, uint32_t chunks, void* stream);
 
+/* The same round trip with the three serial stages of every group of 64 maps in ONE workgroup: the encoder core, a bit writer
+ * (the emit pass, one map per lane) and the decoder core are three wavefronts that hand records and stream words to each other
+ * through rings in LDS, so the decoder runs a few hundred bits behind the encoder instead of after it, and the records never go
+ * to memory. One stream, five launches (binarise, the pipeline, the general kernel for what the pipeline hands over, debinarise,
+ * compare). Same stream bytes, bit counts, statuses and stages as encode_batch + decode_batch(expected = symbols).
+ * workspace: eae_hip_coder_trailing_workspace_bytes. */
+int eae_hip_coder_roundtrip_fused(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, uint8_t truncated_unary_length,
+                                  const double* probabilities, const int32_t* prob_row, uint8_t* streams,
+                                  uint64_t stream_stride_bytes, uint32_t* bac_bits, uint32_t* bypass_bits, int32_t* status,
+                                  int32_t* stage, void* workspace, uint64_t workspace_bytes, void* stream);
+
 /* ---- container support (the reference never serialises, compression.cpp:27-64) ------------------
  * pack_streams: gathers the valid bytes of every map's two streams (layout above) into `payload`: the arithmetic-coded
  * bytes of map m at offsets[2m], its bypass bytes at offsets[2m+1] (uint64 byte offsets, device memory, chosen by the

@@ -49,8 +49,16 @@ def main():
             dev.coder_encode_batch(symbols, prob, rows, 10, out=streams, workspace=ws)
             dev.coder_decode_batch(streams, prob, rows, expected=symbols, workspace=ws)
         print('bin width {0}: two calls                 {1:.4f} ms'.format(width, timed(two)))
+        def fused():
+            dev.coder_roundtrip_fused(symbols, prob, rows, 10, out=streams, workspace=ws)
+        print('bin width {0}: fused (one workgroup per 64 maps) {1:.4f} ms'.format(width, timed(fused)))
+        assert not streams.status.cpu().numpy().any()
         side = torch.cuda.Stream()
-        for chunks in (2, 3, 4, 6, 8, 12, 16):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side, capture_error_mode='thread_local'):
+            fused()
+        print('bin width {0}: fused as a hipGraph          {1:.4f} ms'.format(width, timed(graph.replay)))
+        for chunks in (4, 8):
             def trailing():
                 dev.coder_roundtrip_trailing(symbols, prob, rows, 10, chunks=chunks, out=streams, workspace=ws)
             direct = timed(trailing)

@@ -380,20 +380,24 @@ def test_batch_full_kodak_batch(gold, dev):
 # ---- the chunked round trip: emit pass and decoder trailing the encoder core (eae_hip_coder_roundtrip_trailing) ------------
 
 def trailing_code(dev, planar, probs, prob_row, chunks):
+    """chunks == 'fused': the three serial stages of a group as one workgroup (eae_hip_coder_roundtrip_fused)."""
     sym = torch.from_numpy(planar).cuda()
     p = torch.from_numpy(numpy.ascontiguousarray(probs, dtype=numpy.float64)).cuda()
     rows = torch.from_numpy(numpy.ascontiguousarray(prob_row, dtype=numpy.int32)).cuda()
-    streams = dev.coder_roundtrip_trailing(sym, p, rows, probs.shape[1], chunks=chunks)
+    if chunks == 'fused':
+        streams = dev.coder_roundtrip_fused(sym, p, rows, probs.shape[1])
+    else:
+        streams = dev.coder_roundtrip_trailing(sym, p, rows, probs.shape[1], chunks=chunks)
     torch.cuda.synchronize()
     return streams, sym, p, rows
 
 
-@pytest.mark.parametrize('chunks', [1, 2, 3, 4, 8, 16])
+@pytest.mark.parametrize('chunks', [1, 2, 3, 4, 8, 16, 'fused'])
 @pytest.mark.parametrize('scale', [0.3, 4., 300.])
 def test_trailing_round_trip_equals_the_host_coder(gold, dev, scale, chunks):
     """One Kodak image's worth of maps (and a ragged second group) at three densities: whatever the number of chunks, the streams,
     bit counts, statuses and stages are the host coder's, and the round trip finds nothing to complain about."""
-    rng = numpy.random.RandomState(int(scale*10) + chunks)
+    rng = numpy.random.RandomState(int(scale*10) + (99 if chunks == 'fused' else chunks))
     probs = gold['real_probabilities_1']
     n = 128 + 37
     planar = numpy.clip(numpy.round(rng.laplace(size=(n, 1536))*rng.uniform(0.05, 1., size=(n, 1))*scale), -32768, 32767).astype(numpy.int16)
@@ -427,7 +431,7 @@ def test_trailing_round_trip_large_maps_and_long_pending_runs(gold, dev):
         hits = rng.rand(size) < min(0.0005*1.25**(m - 20), 0.9)
         planar[m, hits] = numpy.clip(numpy.round(rng.laplace(size=int(hits.sum()))*3.), -300, 300).astype(numpy.int16)
     rows = numpy.arange(n, dtype=numpy.int32)
-    for chunks in (4, 7):
+    for chunks in (4, 7, 'fused'):
         (streams, sym, p, r) = trailing_code(dev, planar, probs, rows, chunks)
         assert assert_equals_host(streams, planar, probs, rows, ('large', chunks)).all()
 
@@ -441,7 +445,7 @@ def test_trailing_round_trip_fuzz_including_errors(gold, dev):
         n_maps = int(rng.randint(1, 200))
         size = int(rng.randint(1, 400))
         L = int(rng.choice([1, 2, 5, 10, 31, 32, 33]))
-        chunks = int(rng.choice([2, 3, 4, 5, 9]))
+        chunks = 'fused' if t % 2 else int(rng.choice([2, 3, 4, 5, 9]))
         scale = rng.choice([0.2, 1, 3, 10, 100, 5000], size=(n_maps, 1))
         planar = numpy.clip(numpy.round(rng.laplace(size=(n_maps, size))*scale), -32768, 32767).astype(numpy.int16)
         probs = numpy.clip(rng.rand(n_maps, L), 0.005, 0.995)

@@ -34,8 +34,8 @@ out = (ctypes.c_ulonglong*12)()
 assert lib.eae_hip_debug_pipe_probe(out) == 0
 for (r, name) in enumerate(('encoder core', 'bit writer', 'decoder core')):
     (total, wait, rounds, hwid) = out[4*r:4*r + 4]
-    print('{0:13s} {1:9d} cycles in all ({2:.1f} us at 100 MHz clock64), {3:9d} waiting, {4:5d} rounds; HW_ID {5:#x}: SIMD {6}, CU {7}, SE {8}'.format(
-        name, total, total/100., wait, rounds, hwid, (hwid >> 4) & 3, (hwid >> 8) & 15, (hwid >> 13) & 7))
+    print('{0:13s} {1:9d} cycles in all (clock64 ticks, about the shader clock){2:.0f}, {3:9d} waiting, {4:5d} rounds; HW_ID {5:#x}: SIMD {6}, CU {7}, SE {8}'.format(
+        name, total, 0, wait, rounds, hwid, (hwid >> 4) & 3, (hwid >> 8) & 15, (hwid >> 13) & 7))
 out2 = (ctypes.c_ulonglong*8)()
 assert lib.eae_hip_debug_pipe_probe2(out2) == 0
 print('decoder: every stream complete at round {0}, cycle {1}; fast rounds {2}, lost bets {3}'.format(*out2[:4]))

@@ -982,20 +982,21 @@ __global__ __launch_bounds__(256) void coder_pipe_kernel(const SimdParams p) {
             const bool progressed = limit != 0u;
 #pragma unroll
             for (uint32_t q = 0; q < 8; q++) {
-                const bool go = q < limit;
+                // integer masks, not booleans: the compiler turns the latter into SGPR-pair logic, an issue slot each for a lone wave
+                const uint32_t gom = q < limit ? 0xFFFFFFFFu : 0u;                       // this lane takes a record in this step
                 const uint32_t r = recring[(j & (kPipeRecords - 1u)) * 64u + lane];
                 const uint32_t n = record_n(r), k = record_k(r), stop = (r >> 4) & 1u;
                 const uint32_t queue = pending + stop;
-                const uint32_t lead = record_leaving(r);
-                const uint32_t first = lead >> 31;
-                const uint32_t rest = __builtin_bitreverse32(lead << 1) & ((1u << ((n - 1u) & 31u)) - 1u);       // the other n - 1 leaving bits
-                const bool has = go && n != 0u;
-                // a stream beyond its region (Bitstream.cpp:32-35) or a pending run of hundreds of bits: the general kernel's
-                if (has && (total + n + queue > size_bits || queue > 64u)) bad = true;
-                const bool emit = has && !bad;
-                if (__any(emit && queue > 15u)) {
-                    // a long pending run somewhere in the wave (nearly dead maps under a very skewed first probability): bit by piece
-                    if (emit) {
+                const uint32_t hasm = n != 0u ? gom : 0u;                                 // ... and the record shifts bits out
+                const uint32_t first = r >> 31;
+                // the other n - 1 leaving bits, first in time at bit 0 (what r << 1 drags in from the record's low half lands above them)
+                const uint32_t rest = __builtin_amdgcn_ubfe(__builtin_bitreverse32(r << 1), 0u, n - 1u);
+                // unusual, anywhere in the wave: a pending run beyond 15 bits (nearly dead maps under a very skewed first probability),
+                // a stream about to outgrow its region (Bitstream.cpp:32-35)
+                const uint32_t odd = (queue > 15u || total + n + queue > size_bits) ? hasm : 0u;
+                if (__any(odd != 0u)) {
+                    if (odd != 0u && (total + n + queue > size_bits || queue > 64u)) bad = true;       // the general kernel's
+                    if (hasm != 0u && !bad) {
                         acc |= (unsigned long long)first << cnt;
                         cnt += 1u;
                         if (cnt >= 32u) flush();
@@ -1009,21 +1010,23 @@ __global__ __launch_bounds__(256) void coder_pipe_kernel(const SimdParams p) {
                         acc |= (unsigned long long)rest << cnt;
                         cnt += n - 1u;
                         if (cnt >= 32u) flush();
+                        total += n + queue;
                         if (queue > 15u) limit = q + 1u;          // it may have sent three words: the room was counted for one
                     }
                 } else {
-                    // the first leaving bit, `queue` copies of its complement, then the other n - 1 (first in time at bit 0): <= 31 bits
-                    const uint32_t run = first ? 0u : ((1u << (queue & 31u)) - 1u);
-                    const uint32_t v = first | (run << 1) | (rest << ((queue + 1u) & 31u));
-                    acc |= (unsigned long long)(emit ? v : 0u) << cnt;
-                    cnt += emit ? n + queue : 0u;
+                    // the first leaving bit, `queue` copies of its complement, then the other n - 1: at most 31 bits, one append
+                    const uint32_t run = (first - 1u) & ((1u << (queue & 31u)) - 1u);
+                    const uint32_t v = (first | (run << 1) | (rest << ((queue + 1u) & 31u))) & hasm;
+                    const uint32_t c = (n + queue) & hasm;
+                    acc |= (unsigned long long)v << cnt;
+                    cnt += c;
+                    total += c;
                     if (cnt >= 32u) flush();
                 }
-                total += emit ? n + queue : 0u;
-                pending = go ? (n != 0u ? k : pending + k) : pending;
-                j += go ? 1u : 0u;
-                if (__any(go && stop != 0u)) {
-                    if (go && stop != 0u && !bad) {
+                pending = gom != 0u ? (n != 0u ? k : pending + k) : pending;
+                j -= gom;                                                                  // + 1 where the lane took the record
+                if (__any((gom & stop) != 0u)) {
+                    if ((gom & stop) != 0u && !bad) {
                         if (cnt) { cnt = 32u; flush(); }              // Bitstream flush of the partial word (zeros above the last bit)
                         fin = true;
                         p.bac_bits[m] = total;

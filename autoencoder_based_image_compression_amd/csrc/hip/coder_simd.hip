@@ -69,7 +69,7 @@ int eae_coder_generic_decode(uint32_t n_maps, uint32_t map_size, int16_t* out, u
 #define EAE_RES_DEBINARISE 23
 #endif
 #ifndef EAE_RES_DECODE_CORE_CHUNKED
-#define EAE_RES_DECODE_CORE_CHUNKED 55      // the resumable form of the decoder core (a parked state to load and store)
+#define EAE_RES_DECODE_CORE_CHUNKED 63      // the resumable form of the decoder core (a parked state to load and store)
 #endif
 #ifndef EAE_DECODE_TOPUP_ZEROS
 #define EAE_KEEP_VGPR_FREE_(n) asm volatile("; v" #n " reserved: the last register of the allocation holds no operand" ::: "v" #n)
@@ -443,7 +443,8 @@ __global__ __launch_bounds__(64) void emit_kernel(const SimdParams p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // LDS of a block: scaled probabilities [L + 1][64] doubles (one row beyond L: read ahead of an escape, never used), then the ring
 // [kRing][64] words.
-constexpr size_t decode_lds_bytes(uint32_t L) { return ((size_t)L + 1u) * 64u * sizeof(double) + (size_t)kRing * 64u * sizeof(uint32_t); }
+// (one row beyond the ring: row kRing mirrors row 0, so that words w and w + 1 are always rows r and r + 1 for the unchecked rounds)
+constexpr size_t decode_lds_bytes(uint32_t L) { return ((size_t)L + 1u) * 64u * sizeof(double) + ((size_t)kRing + 1u) * 64u * sizeof(uint32_t); }
 
 #ifdef EAE_HWID_PROBE      // scratch/r03_hwid_probe.py: does a long-lived coder wave ever resume on another CU / SIMD / slot (context save / restore)?
 __device__ unsigned int g_hwid_probe[8];     // [0] waves, [1] waves whose HW_ID[15:0] or XCC_ID changed, [2..5] an example (before, after)
@@ -531,6 +532,7 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
         ring[((w0 + 1u) & (kRing - 1u)) * 64u] = __builtin_bitreverse32(v.y);
         ring[((w0 + 2u) & (kRing - 1u)) * 64u] = __builtin_bitreverse32(v.z);
         ring[((w0 + 3u) & (kRing - 1u)) * 64u] = __builtin_bitreverse32(v.w);
+        if ((w0 & (kRing - 1u)) == 0u) ring[kRing * 64u] = __builtin_bitreverse32(v.x);      // row kRing mirrors row 0
     };
     // the ring starts full: words wbase .. wbase + 31
     {
@@ -590,7 +592,8 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
 #ifdef EAE_DECODE_TOPUP_ZEROS
             flying = loaded - rword <= kRing - 8u;
 #else
-            flying = loaded - rword <= kRing - 8u && loaded < nwords;
+            // (two words less than the ring allows: the unchecked rounds read words rword - 2 and rword - 1 from the ring again)
+            flying = loaded - rword <= kRing - 10u && loaded < nwords;
 #endif
             if (flying) {
                 fa = fetch(loaded);
@@ -601,26 +604,33 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
             // step -- the running count, overwritten until the symbol's last decision leaves the final value (a lane's stores to
             // one address stay in order). All but the last rounds of a map.
 #ifdef EAE_DECODE_TOPUP_ZEROS
-            const bool fast_round = false;                  // the first form of this kernel stays as it was built (tests/test_isa_guard.py)
+            bool fast_round = false;                        // the first form of this kernel stays as it was built (tests/test_isa_guard.py)
 #else
-            const bool fast_round = !__any(size != 0u && (i + 8u > size || left < 8u * 30u)) &&
-                                    (!CHUNKED || final_chunk || !__any(size != 0u && !(begun && left >= kStepMargin + 8u * 30u)));
+            // (a step takes 30 bits at most and a fraction of a bit on average -- the whole stream of a nearly dead map is a few dozen
+            // bits --: the round is run on the bet that the bits are there and undone if a lane ends it having taken more than its
+            // stream holds, which happens at the end of streams only)
+            bool fast_round = !__any(size != 0u && i + 8u > size) && (!CHUNKED || final_chunk || !__any(size != 0u && !begun));
 #endif
             if (fast_round) {
                 if (size) {
+                    // The stream as a bit position instead of a window: the next 32 bits are words w and w + 1 of the ring (rows r, r + 1:
+                    // one ds_read2st64) shifted by the position's low five bits -- no conditional top-up, no window to shift and
+                    // count (8 instructions where the window takes 19). The window form is rebuilt behind the round for the
+                    // checkpoint and the checked rounds.
+                    const uint32_t bp0 = rword * 32u - rcount;
+                    uint32_t bp = bp0;
+                    const Interval s0 = s;
+                    const uint32_t code0 = code32, unary0 = unary, i0 = i;
+                    const double pk0 = pk;
 #pragma unroll
                     for (uint32_t q = 0; q < 8; q++) {
-                        const uint32_t wnext = ring[(rword & (kRing - 1u)) * 64u];
+                        const uint32_t row = (bp >> 5) & (kRing - 1u);
+                        const uint32_t hi = ring[row * 64u], lo = ring[row * 64u + 64u];
                         const double pspec = probs[(unary + 1u) * 64u + lane];
-                        const bool need = rcount <= 32u;
-                        rwin |= (unsigned long long)(need ? wnext : 0u) << (need ? 32u - rcount : 0u);
-                        rcount += need ? 32u : 0u;
-                        rword += need ? 1u : 0u;
                         const DecodeStep d = decode_step(s, code32, pk);
-                        const uint32_t bits = (uint32_t)((rwin >> 1) >> (63u - d.take));
-                        rwin <<= d.take;
-                        rcount -= d.take;
-                        left -= d.take;
+                        const uint32_t win = (uint32_t)(((((unsigned long long)hi << 32) | (unsigned long long)lo) << (bp & 31u)) >> 32);
+                        const uint32_t bits = (win >> 1) >> (31u - d.take);                 // the step's d.take <= 30 bits, first in time on top
+                        bp += d.take;
                         code32 = shift_code(code32, d, bits);
                         const uint32_t count = unary + (d.one ? 1u : 0u);       // a one: unary + 1 (= L when it ends the symbol); a zero: unary
                         prefix[i] = (uint8_t)count;
@@ -629,8 +639,21 @@ __global__ __launch_bounds__(64) void bac_decode_core_kernel(const SimdParams p)
                         unary = done ? 0u : count;
                         pk = done ? p0 : pspec;
                     }
+                    if (__any(bp - bp0 > left)) {
+                        // the bet is lost for some lane (the end of its stream): every lane goes back -- the window was not touched, it
+                        // is only rebuilt below -- and the round runs step by step with the checks
+                        s = s0; code32 = code0; unary = unary0; i = i0; pk = pk0;
+                        fast_round = false;
+                    } else {
+                        left -= bp - bp0;
+                        const uint32_t row = (bp >> 5) & (kRing - 1u);
+                        rwin = (((unsigned long long)ring[row * 64u] << 32) | (unsigned long long)ring[row * 64u + 64u]) << (bp & 31u);
+                        rcount = 64u - (bp & 31u);
+                        rword = (bp >> 5) + 2u;
+                    }
                 }
-            } else {
+            }
+            if (!fast_round) {
 #pragma unroll
             for (uint32_t q = 0; q < 8; q++) {
                 if (i < size && (!CHUNKED || final_chunk || (begun && left >= kStepMargin))) {

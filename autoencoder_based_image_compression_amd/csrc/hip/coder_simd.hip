@@ -60,7 +60,7 @@ int eae_coder_generic_decode(uint32_t n_maps, uint32_t map_size, int16_t* out, u
 #define EAE_RES_ENCODE_CORE 47
 #endif
 #ifndef EAE_RES_EMIT
-#define EAE_RES_EMIT 23
+#define EAE_RES_EMIT 39
 #endif
 #ifndef EAE_RES_DECODE_CORE
 #define EAE_RES_DECODE_CORE 55
@@ -91,7 +91,7 @@ constexpr int32_t RETRY = -100;           // internal: recode this map with the 
 constexpr uint32_t kMaxFastL = 32;        // contexts staged in LDS: 33 x 64 lanes x 8 B = 17 KB
 constexpr uint32_t kRecordPad = 12;       // records beyond a map's decisions: the stop record + the tail of the last 16-byte store
 constexpr uint32_t kRing = 32;            // decoder: stream words per lane in LDS (a step takes <= 30 bits: 8 steps <= 8 words)
-constexpr uint32_t kEmitWords = 96;       // emit: 64-bit words of one tile of 64 records in LDS (carry + 63 x 64 + a long run or two)
+constexpr uint32_t kEmitWords = 224;      // emit: 64-bit words of one tile of 256 records in LDS (56 bits per record on average: beyond that the general kernel)
 
 struct SimdParams {
     uint32_t n_maps, map_size, L, dcap;   // dcap: bytes of decision storage per map (multiple of 8)
@@ -359,60 +359,88 @@ __global__ __launch_bounds__(64) void emit_kernel(const SimdParams p) {
             if (lane == 0) buf[0] = (unsigned long long)st.z | ((unsigned long long)st.w << 32);
         }
     }
-    for (uint32_t t = t_first; t < nrec; t += 64u) {
-        const uint32_t j = t + lane;
-        const uint32_t r = j < nrec ? rec[j] : 0u;
-        const uint32_t n = record_n(r), k = record_k(r);
-        const bool has = n != 0u;
-        uint32_t ktot;
-        const uint32_t e = wave_exclusive_scan(k, ktot);                               // scalings of the tile's records below this lane
-        const int since = wave_exclusive_max(has ? (int)e : -1);                         // ... below the last record that shifted out
-        const uint32_t queue = (since >= 0 ? e - (uint32_t)since : pending + e) + (record_is_stop(r) ? 1u : 0u);
-        const uint32_t c = has ? n + queue : 0u;
-        uint32_t ctot;
-        const uint32_t o = wave_exclusive_scan(c, ctot);
-        // the queue behind the tile: the k's from the last record that shifted out onwards
-        const unsigned long long mask = __ballot(has);
-        if (mask) {
-            const int last = 63 - __builtin_clzll(mask);
-            pending = ktot - (uint32_t)__builtin_amdgcn_readlane((int)e, last);
-        } else {
-            pending += ktot;
+    // A tile is 256 records, FOUR consecutive ones per lane (one 16-byte load): what a lane does for a record -- fields, the bit
+    // string, two LDS ORs -- is per record whatever the tile, but the three wave scans, the flush and the bookkeeping are per TILE,
+    // and they were three quarters of the pass with one record per lane (135 -> ~60 instructions per 64 records).
+    for (uint32_t t = t_first; t < nrec; t += 4u * 64u) {
+        const uint32_t j0 = t + 4u * lane;
+        uint4 rr = make_uint4(0u, 0u, 0u, 0u);
+        if (j0 < nrec) rr = *reinterpret_cast<const uint4*>(rec + j0);        // (the pad behind a map's records covers the tail of the load)
+        uint32_t r[4] = {rr.x, rr.y, rr.z, rr.w};
+        uint32_t n[4], k[4], kl[4];
+        bool has[4];
+        uint32_t ksum = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            if (j0 + q >= nrec) r[q] = 0u;
+            n[q] = record_n(r[q]);
+            k[q] = record_k(r[q]);
+            has[q] = n[q] != 0u;
+            kl[q] = ksum;                                   // scalings of this lane's records before record q
+            ksum += k[q];
         }
+        uint32_t ktot;
+        const uint32_t e0 = wave_exclusive_scan(ksum, ktot);                             // scalings of the tile's records before this lane's
+        // the running maximum of e over the records that shifted out = e of the LAST such record (e never decreases)
+        int lane_last = -1;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) lane_last = has[q] ? (int)(e0 + kl[q]) : lane_last;
+        const int below = wave_exclusive_max(lane_last);                                 // ... of the lanes below
+        uint32_t c[4], cl[4], queue[4];
+        uint32_t csum = 0;
+        int since = below;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint32_t e = e0 + kl[q];
+            queue[q] = (since >= 0 ? e - (uint32_t)since : pending + e) + (record_is_stop(r[q]) ? 1u : 0u);
+            c[q] = has[q] ? n[q] + queue[q] : 0u;
+            cl[q] = csum;
+            csum += c[q];
+            since = has[q] ? (int)e : since;
+        }
+        uint32_t ctot;
+        const uint32_t o0 = wave_exclusive_scan(csum, ctot);
+        // the queue behind the tile: the k's from the last record that shifted out onwards
+        const int tile_last = __builtin_amdgcn_readlane(since, 63);                      // lane 63's `since` has seen every record of the tile
+        pending = tile_last >= 0 ? ktot - (uint32_t)tile_last : pending + ktot;
         const uint32_t start = base & 63u;              // bits of the carried partial word in buf[0]
         // the tile must fit the LDS buffer and the stream its capacity (Bitstream.cpp:32-35): otherwise the general kernel
         if (start + ctot > kEmitWords * 64u || base + ctot > size_bits) { give_up = true; break; }
-        if (has) {
-            const uint32_t lead = record_leaving(r);
-            const unsigned long long first = lead >> 31;
-            // the other n - 1 leaving bits, first in time at bit 0
-            const unsigned long long rest = (unsigned long long)(__builtin_bitreverse32(lead << 1) & ((1u << (n - 1u)) - 1u));
-            const uint32_t pos = start + o;
-            if (c <= 64u) {
-                // first bit, `queue` complements, the rest: at most 64 bits in one piece (queue <= 63 here)
-                const unsigned long long run = first ? 0ull : (((queue < 63u ? (1ull << queue) : (1ull << 63)) - 1ull) | (queue == 63u ? (1ull << 62) : 0ull));
-                const unsigned long long v = first | (run << 1) | (queue + 1u < 64u ? rest << (queue + 1u) : 0ull);
-                const uint32_t sh = pos & 63u;
-                atomicOr(&buf[pos >> 6], v << sh);
-                if (sh + c > 64u) atomicOr(&buf[(pos >> 6) + 1u], v >> (64u - sh));
-            } else {
-                // a long queue (nearly dead maps under a very skewed first probability): the first bit, the run word by word, the rest
-                if (first) atomicOr(&buf[pos >> 6], 1ull << (pos & 63u));
-                if (!first) {
-                    uint32_t b0 = pos + 1u;
-                    const uint32_t b1 = pos + 1u + queue;            // ones over [b0, b1)
-                    while (b0 < b1) {
-                        const uint32_t sh = b0 & 63u;
-                        const uint32_t cnt = (b1 - b0) < (64u - sh) ? (b1 - b0) : (64u - sh);
-                        const unsigned long long ones = cnt == 64u ? ~0ull : (((1ull << cnt) - 1ull) << sh);
-                        atomicOr(&buf[b0 >> 6], ones);
-                        b0 += cnt;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            if (has[q]) {
+                const uint32_t lead = record_leaving(r[q]);
+                const unsigned long long first = lead >> 31;
+                // the other n - 1 leaving bits, first in time at bit 0
+                const unsigned long long rest = (unsigned long long)(__builtin_bitreverse32(lead << 1) & ((1u << (n[q] - 1u)) - 1u));
+                const uint32_t pos = start + o0 + cl[q];
+                const uint32_t qu = queue[q];
+                if (c[q] <= 64u) {
+                    // first bit, `queue` complements, the rest: at most 64 bits in one piece (queue <= 63 here)
+                    const unsigned long long run = first ? 0ull : (((qu < 63u ? (1ull << qu) : (1ull << 63)) - 1ull) | (qu == 63u ? (1ull << 62) : 0ull));
+                    const unsigned long long v = first | (run << 1) | (qu + 1u < 64u ? rest << (qu + 1u) : 0ull);
+                    const uint32_t sh = pos & 63u;
+                    atomicOr(&buf[pos >> 6], v << sh);
+                    if (sh + c[q] > 64u) atomicOr(&buf[(pos >> 6) + 1u], v >> (64u - sh));
+                } else {
+                    // a long queue (nearly dead maps under a very skewed first probability): the first bit, the run word by word, the rest
+                    if (first) atomicOr(&buf[pos >> 6], 1ull << (pos & 63u));
+                    if (!first) {
+                        uint32_t b0 = pos + 1u;
+                        const uint32_t b1 = pos + 1u + qu;            // ones over [b0, b1)
+                        while (b0 < b1) {
+                            const uint32_t sh = b0 & 63u;
+                            const uint32_t cnt = (b1 - b0) < (64u - sh) ? (b1 - b0) : (64u - sh);
+                            const unsigned long long ones = cnt == 64u ? ~0ull : (((1ull << cnt) - 1ull) << sh);
+                            atomicOr(&buf[b0 >> 6], ones);
+                            b0 += cnt;
+                        }
                     }
-                }
-                const uint32_t pr = pos + 1u + queue, sh = pr & 63u;
-                if (rest) {
-                    atomicOr(&buf[pr >> 6], rest << sh);
-                    if (sh + (n - 1u) > 64u) atomicOr(&buf[(pr >> 6) + 1u], rest >> (64u - sh));
+                    const uint32_t pr = pos + 1u + qu, sh = pr & 63u;
+                    if (rest) {
+                        atomicOr(&buf[pr >> 6], rest << sh);
+                        if (sh + (n[q] - 1u) > 64u) atomicOr(&buf[(pr >> 6) + 1u], rest >> (64u - sh));
+                    }
                 }
             }
         }

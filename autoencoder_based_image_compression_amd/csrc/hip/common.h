@@ -21,6 +21,7 @@ struct EaeLaunchOptions {
     int force_tile;     // EAE_HIP_FORCE_TILE: 0 (by shape) | 32 | 64 | 128
     int force_nt;       // EAE_HIP_FORCE_NT: 0 (by shape) | 1 | 2 | 4
     char latent;        // EAE_HIP_LATENT: 'q' (default) | 'w' | 'l'
+    int pack;           // EAE_HIP_PACK: -1 (by shape) | 0 | 1: partial channel tiles of small layers as four-wave blocks (conv_gemm.hip: launch)
     int split_wpb;      // EAE_HIP_SPLIT_WPB: 1 = one-wave blocks in the split conv GEMM (default: 4 waves per block)
     int split_mute;     // test hook, debug entry point only: heads of cut tiles never publish, tails give up after ~1 ms
     int assume_partitioned;   // EAE_HIP_ASSUME_PARTITIONED=1: behave as on a device that is not one whole MI355X (tests of the de-tuned path)

@@ -237,11 +237,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 // machine with 32-position x 128-channel waves (conv_3 at Kodak batch sizes: 1152 waves on 1024 SIMDs ran as two rounds),
 // 2 or 1: the channel tiles of one position tile are then spread over 4 / NT blocks of the same XCD, the epilogue is the
 // bias only (NORM must be NONE) and launch() runs the GDN as its own pass over the output. Same per-element FMA chain.
-template <int WAVES, int NORM, int NT = 4>
+// PACK (NT < 4, four waves): the block holds the 4 / NT channel parts of NT position tiles -- wave w = part w % PARTS of position
+// tile w / PARTS -- instead of one wave. The waves are as independent as before; what changes is where they land: the dispatcher
+// gives the four waves of a workgroup one SIMD each, while one-wave blocks arriving at a CU behind another kernel's last waves
+// were seen two to a SIMD (conv_3 of 64 x 256x256 in the step: 96 SIMDs with two waves, 96 with none, 0.22 ms against 0.15).
+template <int WAVES, int NORM, int NT = 4, bool PACK = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const ConvGemmParams p) {
     static_assert(NT == 4 || NORM == EAE_NORM_NONE, "partial channel tiles carry no normalisation");
+    static_assert(!PACK || (WAVES == 4 && NT < 4), "the packed form is four waves of partial channel tiles");
     constexpr int PARTS = 4 / NT;
-    constexpr int TM = WAVES * 32;
+    constexpr int GRID_PARTS = PACK ? 1 : PARTS;               // channel parts that are blocks of their own
+    constexpr int TM = (PACK ? WAVES / PARTS : WAVES) * 32;    // positions of a block's tile
     constexpr int TILE_W = TM / TILE_H;
     constexpr int RING = 8;        // k-pairs of weights in flight (16 for the two-tile form measured slower: 0.136 against 0.128 ms, conv_3 of 64 x 256x256)
     constexpr int ABUF = 32 * AS_STRIDE;                       // one activation buffer of one wave
@@ -265,9 +271,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
     // Blocks b and b + 8 share an XCD (round-robin over the 8 XCDs): XCD x = b % 8 owns a contiguous range of tiles_x
     // tiles (shared halos stay in its L2) and walks them once per phase, longest phase first. The grid is padded to
     // 8 * tiles_x tiles per phase; the (< 8 per phase) surplus blocks exit at once.
-    const int tiles_x = (int)gridDim.x / (8 * p.n_phases * PARTS);
-    const int part = ((int)blockIdx.x >> 3) % PARTS;          // which NT channel tiles (neighbouring blocks of one XCD)
-    const int seq = ((int)blockIdx.x >> 3) / PARTS;
+    const int tiles_x = (int)gridDim.x / (8 * p.n_phases * GRID_PARTS);
+    const int part = PACK ? wave % PARTS : ((int)blockIdx.x >> 3) % PARTS;      // which NT channel tiles (neighbouring blocks of one XCD, or waves of the block)
+    const int seq = ((int)blockIdx.x >> 3) / GRID_PARTS;
+    const int sub = PACK ? wave / PARTS : wave;                // which 32 positions of the block's tile
     const int ph = seq / tiles_x;
     int b = ((int)blockIdx.x & 7) * tiles_x + seq % tiles_x;
     if (b >= p.n * p.tiles_r * p.tiles_c) return;
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
     int a_pr[4], a_pc[4], a_ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = wave * 32 + (lane >> 3) + 8 * i;
+        const int m = sub * 32 + (lane >> 3) + 8 * i;
         a_pr[i] = tr * TILE_H + m / TILE_W;
         a_pc[i] = tc * TILE_W + m % TILE_W;
         a_ok[i] = (a_pr[i] < p.hp) & (a_pc[i] < p.wp);
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_gemm_wave_kernel(const Con
 
     if (p.stamps) t_loop_end = __builtin_amdgcn_s_memtime();
     // ---- epilogue, all in registers (common.h: wave_epilogue) ---------------------------------------------------------
-    const int m = wave * 32 + lj;
+    const int m = sub * 32 + lj;
     const int pr = tr * TILE_H + m / TILE_W, pc = tc * TILE_W + m % TILE_W;
     const bool valid = pr < p.hp && pc < p.wp;
     float* o = p.out + (size_t)img * p.hout * p.wout * EAE_C +
@@ -492,9 +499,23 @@ int launch(ConvGemmParams& p, hipStream_t stream) {
     }
     if (force_nt) nt = force_nt == 1 ? 1 : (force_nt == 2 ? 2 : 4);
     if (nt != 4 && waves == 1) {
-        grid *= 4 / nt;
-        if (nt == 2) hipLaunchKernelGGL((conv_gemm_wave_kernel<1, EAE_NORM_NONE, 2>), dim3(grid), dim3(64), 0, stream, p);
-        else hipLaunchKernelGGL((conv_gemm_wave_kernel<1, EAE_NORM_NONE, 1>), dim3(grid), dim3(64), 0, stream, p);
+        // four-wave blocks (the channel parts of nt position tiles: one wave per SIMD of a CU) when the wider tile wastes no lanes and
+        // there is a block for every CU -- conv_3 of 64 x 256x256, 1,024 waves: 0.22 -> 0.13 ms in the step; below that the launch
+        // does not fill the GPU either way and one-wave blocks spread over more CUs (one Kodak image at a time 1.18 -> 1.13 ms, but
+        // pipelined 0.31 -> 0.33 ms per image) --, one-wave blocks otherwise (EAE_HIP_PACK=0 / 1 forces either: the parity tests run both)
+        const int pack_w = nt * 32 / TILE_H;
+        const int packed_tiles = p.n * p.tiles_r * (p.wp / pack_w);
+        const int force_pack = g_eae_launch_options.pack;
+        if (force_pack != 0 && p.wp % pack_w == 0 && (packed_tiles * p.n_phases >= eae_compute_units() || force_pack == 1)) {
+            p.tiles_c = p.wp / pack_w;
+            grid = ((packed_tiles + 7) / 8) * 8 * p.n_phases;
+            if (nt == 2) hipLaunchKernelGGL((conv_gemm_wave_kernel<4, EAE_NORM_NONE, 2, true>), dim3(grid), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((conv_gemm_wave_kernel<4, EAE_NORM_NONE, 1, true>), dim3(grid), dim3(256), 0, stream, p);
+        } else {
+            grid *= 4 / nt;
+            if (nt == 2) hipLaunchKernelGGL((conv_gemm_wave_kernel<1, EAE_NORM_NONE, 2>), dim3(grid), dim3(64), 0, stream, p);
+            else hipLaunchKernelGGL((conv_gemm_wave_kernel<1, EAE_NORM_NONE, 1>), dim3(grid), dim3(64), 0, stream, p);
+        }
         EAE_HIP_CHECK_LAUNCH();
         if (p.norm != EAE_NORM_NONE)
             return eae_hip_gdn(p.out, p.gamma, p.beta, p.norm == EAE_NORM_IGDN ? 1 : 0, p.out, (int64_t)p.n * p.hout * p.wout, stream);

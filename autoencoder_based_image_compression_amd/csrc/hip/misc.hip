@@ -23,6 +23,8 @@ static EaeLaunchOptions read_launch_options() {
     e = std::getenv("EAE_HIP_LATENT");
     o.latent = e && (e[0] == 'w' || e[0] == 'l' || e[0] == 'q') ? e[0] : 'q';
     if (std::getenv("EAE_HIP_LATENT_LDS") != nullptr) o.latent = 'l';      // round 1's name for the LDS form
+    e = std::getenv("EAE_HIP_PACK");
+    o.pack = e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1;
     e = std::getenv("EAE_HIP_SPLIT_WPB");
     o.split_wpb = e && (std::atoi(e) == 1 || std::atoi(e) == 4) ? std::atoi(e) : 0;
     o.split_mute = 0;                                                      // never from the environment

@@ -61,7 +61,9 @@ def test_conv1_gdn1(T, dev, orc, shape, with_gdn):
 def _select_form(launch_options, form, tile):
     """Every form of the conv GEMM must give the same bits (EAE_HIP_GEMM, csrc/hip/conv_gemm.hip: launch):
     'wave' = conv_gemm_wave_kernel, one tile per wave (32 / 64 / 128-position blocks); 'nt1' / 'nt2' = the same with a
-    wave's output channels spread over 4 / 2 blocks (small layers); 'lds' = the block-cooperative LDS form (64- or
+    wave's output channels spread over 4 / 2 waves (small layers): as one-wave blocks, 'nt1p' / 'nt2p' as four-wave blocks holding the
+    channel parts of 1 / 2 position tiles (EAE_HIP_PACK: what a launch picks by itself when that gives every CU a block) where the
+    layer's width is a multiple of 8 / 16 positions (the (1, 32, 64) and (1, 16, 32) cases below; one-wave blocks otherwise); 'lds' = the block-cooperative LDS form (64- or
     128-position blocks); 'whole' = conv_gemm_split_kernel with whole tiles; 'cut1..3' = conv_gemm_split_kernel with the cut
     forced onto these small shapes (every tile is then cut in two and the tails wait for their heads); 'one2' / 'one3' = the same
     as blocks of one wave (EAE_HIP_SPLIT_WPB=1)."""
@@ -81,7 +83,8 @@ def _select_form(launch_options, form, tile):
     launch_options.setenv('EAE_HIP_GEMM', 'l' if form == 'lds' else 'w')
     launch_options.setenv('EAE_HIP_FORCE_TILE', tile)
     if form.startswith('nt'):
-        launch_options.setenv('EAE_HIP_FORCE_NT', form[2:])
+        launch_options.setenv('EAE_HIP_FORCE_NT', form[2])
+        launch_options.setenv('EAE_HIP_PACK', '1' if form.endswith('p') else '0')
 
 
 def _assert_handed_over(T, dev, ws):
@@ -93,7 +96,7 @@ def _assert_handed_over(T, dev, ws):
     assert int(word.item()) == 0 and int(T.count_nonzero(ws).item()) == 0
 
 
-FORMS = [('wave', '32'), ('wave', '64'), ('wave', '128'), ('lds', '64'), ('lds', '128'), ('nt1', '32'), ('nt2', '32'),
+FORMS = [('wave', '32'), ('wave', '64'), ('wave', '128'), ('lds', '64'), ('lds', '128'), ('nt1', '32'), ('nt2', '32'), ('nt1p', '32'), ('nt2p', '32'),
          ('whole', ''), ('cut1', ''), ('cut2', ''), ('cut3', ''), ('one2', ''), ('one3', '')]
 
 

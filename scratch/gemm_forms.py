@@ -6,7 +6,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
-from autoencoder_based_image_compression_amd import device as dev, pipeline
+from autoencoder_based_image_compression_amd import _native, device as dev, pipeline
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 (H, W) = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (512, 768)
@@ -34,6 +34,8 @@ forms = {
     'wave32_nt2': ({'EAE_HIP_GEMM': 'w', 'EAE_HIP_FORCE_TILE': '32', 'EAE_HIP_FORCE_NT': '2'}, False),
     'wave32_nt1': ({'EAE_HIP_GEMM': 'w', 'EAE_HIP_FORCE_TILE': '32', 'EAE_HIP_FORCE_NT': '1'}, False),
     'wave64_nt4': ({'EAE_HIP_GEMM': 'w', 'EAE_HIP_FORCE_TILE': '64', 'EAE_HIP_FORCE_NT': '4'}, False),
+    'pack_nt2': ({'EAE_HIP_GEMM': 'w', 'EAE_HIP_FORCE_NT': '2', 'EAE_HIP_PACK': '1'}, False),
+    'pack_nt1': ({'EAE_HIP_GEMM': 'w', 'EAE_HIP_FORCE_NT': '1', 'EAE_HIP_PACK': '1'}, False),
     'default': ({}, ws),
     'whole': ({'EAE_HIP_GEMM': 'u'}, ws),
     'cut1': ({'EAE_HIP_GEMM': 's', 'EAE_HIP_SPLIT_WAVES': '1'}, ws),
@@ -43,7 +45,7 @@ forms = {
 extra = [a for a in sys.argv[4:]]
 if extra:
     forms = {k: forms[k] for k in extra}
-KEYS = ('EAE_HIP_GEMM', 'EAE_HIP_FORCE_TILE', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_FORCE_NT')
+KEYS = ('EAE_HIP_GEMM', 'EAE_HIP_FORCE_TILE', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_FORCE_NT', 'EAE_HIP_PACK')
 BURST, ROUNDS = 12, 7
 flops = {'conv2': pipeline.FLOP_PER_PIXEL['conv2_gdn2'], 'conv3': 3200, 'tconv1': pipeline.FLOP_PER_PIXEL['tconv1_igdn5'], 'tconv2': pipeline.FLOP_PER_PIXEL['tconv2_igdn6']}
 times = {}
@@ -53,6 +55,7 @@ for rnd in range(ROUNDS + 1):
             for k in KEYS:
                 os.environ.pop(k, None)
             os.environ.update(env)
+            _native.hip().eae_hip_debug_reload_launch_options()      # the forms are read when the library loads (round 4 on)
             (a, b) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             fn(w)
             a.record()

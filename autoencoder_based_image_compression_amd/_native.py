@@ -78,6 +78,7 @@ CODER_SYMBOLS = {
     'eae_lossless_coder_bac_encoding': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint8, ctypes.c_double]),
     'eae_lossless_coder_bac_decoding': (ctypes.c_int, [ctypes.c_void_p, c_u8p, ctypes.c_double]),
     'eae_coder_count_binary_decisions': (ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, c_i16p, ctypes.c_uint8, c_i64p, c_i64p, ctypes.c_int]),
+    'eae_coder_pairwise_row_sums': (ctypes.c_int, [c_f64p, c_i64p, ctypes.c_int64, c_f64p]),
     'eae_crc32c': (ctypes.c_uint32, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]),
 }
 

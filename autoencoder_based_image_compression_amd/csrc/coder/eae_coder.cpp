@@ -379,6 +379,41 @@ int eae_lossless_coder_bac_encoding(eae_lossless_coder* c, uint8_t bit, double p
 int eae_lossless_coder_bac_decoding(eae_lossless_coder* c, uint8_t* storage, double p) { return c->core.bac.decode(*storage, p); }
 
 // ---- statistics (lossless/stats.py:136-195) ------------------------------------------------------------------------
+// numpy's pairwise summation of a contiguous float64 run (numpy/_core/src/umath/loops_utils.h.src, unchanged since 1.9 but for the
+// -0.0 start of the short form): n < 8 one running sum; n <= 128 eight running sums over the multiples of eight, combined as a
+// balanced tree, then the rest; longer runs halved at a multiple of eight. Compiled without contraction or reassociation (Makefile).
+static double pairwise_sum(const double* a, int64_t n) {
+    if (n < 8) {
+        double res = -0.0;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int64_t i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return pairwise_sum(a, n2) + pairwise_sum(a + n2, n - n2);
+}
+
+int eae_coder_pairwise_row_sums(const double* values, const int64_t* bounds, int64_t rows, double* sums) {
+    if (!bounds || !sums || (!values && rows > 0 && bounds[rows] > bounds[0])) return EAE_NULL_POINTER;
+    for (int64_t i = 0; i < rows; ++i) {
+        const int64_t n = bounds[i + 1] - bounds[i];
+        if (n < 0) return EAE_OUT_OF_RANGE;
+        // numpy.sum starts from the identity of the addition, +0.0, and adds the array's pairwise sum to it
+        sums[i] = 0.0 + pairwise_sum(values + bounds[i], n);
+    }
+    return EAE_SUCCESS;
+}
+
 int eae_coder_count_binary_decisions(uint32_t n_maps, uint32_t map_size, const int16_t* symbols, uint8_t L,
                                      int64_t* zeros, int64_t* ones, int n_threads) {
     if (!symbols || !zeros || !ones) return EAE_NULL_POINTER;

@@ -144,6 +144,16 @@ uint8_t eae_coder_count_nb_bits(uint32_t input);
 int eae_coder_count_binary_decisions(uint32_t n_maps, uint32_t map_size, const int16_t* symbols,
                                      uint8_t truncated_unary_length, int64_t* zeros, int64_t* ones, int n_threads);
 
+/* ---- (6) row sums in numpy's order (the approximate rate, tools/tools.py:523-537, 977-989) ------------------------------
+ * `discrete_entropy` ends in `-numpy.sum(frequency*numpy.log2(frequency))`, once per feature map: 128 calls per image on the
+ * reference's side, each over the few dozen non-empty bins of one map. numpy adds a contiguous float64 array pairwise (blocks
+ * of <= 128 elements through eight running sums, longer arrays halved at multiples of eight), and the result's last bits
+ * depend on that order. This is the same order for `rows` independent runs of one array: row i = values[bounds[i] ..
+ * bounds[i + 1]), sums[i] = what `numpy.sum` returns for that slice. kodak/tools/tools.py checks it against `numpy.sum` itself
+ * when it is first used and keeps calling `numpy.sum` if the installed numpy adds in another order. EAE_NULL_POINTER; EAE_OUT_OF_RANGE
+ * for descending bounds. */
+int eae_coder_pairwise_row_sums(const double* values, const int64_t* bounds, int64_t rows, double* sums);
+
 /* ---- checkpoint ingestion helper ------------------------------------------------------------------------------------
  * CRC-32C (Castagnoli, reflected polynomial 0x82F63B78) of `size` bytes, continuing from `crc` (0 to start). The
  * reference restores its models with tf.train.Saver (eae/graph/EntropyAutoencoder.py:454-458); TensorFlow's bundle

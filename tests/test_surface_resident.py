@@ -103,3 +103,33 @@ def test_entropies_of_all_rows_at_once_equal_the_reference_expression_row_by_row
         else:
             assert tls._entropies_from_hist_rows(hist).tobytes() == numpy.array(expected).tobytes()
     assert raised == 6
+
+
+def test_row_sums_are_numpy_sum_of_every_row_bit_for_bit(monkeypatch):
+    """The host library's pairwise row sums (include/eae_coder.h) against `numpy.sum` itself: every run length from 0 to 300 and a
+    few long ones, terms of mixed magnitude; the self-check of the first call says `numpy order`; with the check forced to fail the
+    function still returns `numpy.sum` of every row."""
+    rng = numpy.random.RandomState(3)
+    lengths = list(range(0, 301)) + [1000, 1024, 1031, 4097]
+    bounds = numpy.concatenate(([0], numpy.cumsum(lengths))).astype(numpy.int64)
+    for trial in range(4):
+        values = rng.standard_normal(int(bounds[-1]))*numpy.exp2(rng.randint(-40, 10, size=int(bounds[-1])))
+        if trial % 2:
+            values = -numpy.abs(values)
+        expected = numpy.array([numpy.sum(values[bounds[i]:bounds[i + 1]]) for i in range(len(lengths))])
+        assert tls._row_sums(values, bounds).tobytes() == expected.tobytes()
+    assert tls._ROW_SUMS_IN_NUMPY_ORDER == [True]
+    monkeypatch.setattr(tls, '_ROW_SUMS_IN_NUMPY_ORDER', [False])
+    assert tls._row_sums(values, bounds).tobytes() == expected.tobytes()
+
+
+def test_row_sums_refuse_bad_arguments():
+    import ctypes
+    from autoencoder_based_image_compression_amd import _native
+    lib = _native.coder()
+    out = numpy.empty(2)
+    values = numpy.ones(4)
+    descending = numpy.array([0, 3, 1], dtype=numpy.int64)
+    as_p = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
+    assert lib.eae_coder_pairwise_row_sums(as_p(values, ctypes.c_double), as_p(descending, ctypes.c_int64), 2, as_p(out, ctypes.c_double)) == 5      # EAE_OUT_OF_RANGE
+    assert lib.eae_coder_pairwise_row_sums(as_p(values, ctypes.c_double), None, 2, as_p(out, ctypes.c_double)) == -1      # EAE_NULL_POINTER

@@ -375,9 +375,9 @@ class BatchCodec(object):
         self._workspaces = [make_workspace(n_maps, self.map_size, self.truncated_unary_length, self.device) for _ in range(self.nb_slots)]
         # scratch that lets the conv GEMM launches cut their last tiles (device.conv_workspace): a slot's launches never overlap each other
         self._conv_ws = [dev.conv_workspace(self.device) for _ in range(self.nb_slots)]
-        # step counters of every slot: [coder side, synthesis side] on the device, their published values in pinned memory, and how
-        # many times the host has submitted each side (what the result worker waits for)
-        self._seq_dev = [torch.zeros(2, dtype=torch.int32, device=self.device) for _ in range(self.nb_slots)]
+        # step counters of every slot: [coder side, synthesis side] on the device (+ the two ticket words of device.publish_step), their
+        # published values in pinned memory, and how many times the host has submitted each side (what the result worker waits for)
+        self._seq_dev = [torch.zeros(4, dtype=torch.int32, device=self.device) for _ in range(self.nb_slots)]
         self._pinned_seq = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(self.nb_slots)]
         self._seq_host = [t.numpy() for t in self._pinned_seq]
         self._counts = [[0, 0] for _ in range(self.nb_slots)]
@@ -620,7 +620,9 @@ class BatchCodec(object):
         counters from the device, so that the next job on this slot waits for the right values."""
         try:
             torch.cuda.synchronize(self.device)
-            self._counts[slot] = [int(v) for v in self._seq_dev[slot].cpu().tolist()]
+            self._counts[slot] = [int(v) for v in self._seq_dev[slot][:2].cpu().tolist()]
+            self._seq_dev[slot][2:].zero_()                    # ticket words of a publish that never ran to its end
+            self._slot_all[slot][4*self._n_maps:].zero_()      # accumulators a publish would have cleared
         except Exception:      # the device itself is in trouble: the next submit will say so
             pass
 
@@ -659,8 +661,9 @@ class BatchCodec(object):
         gdn_1 = hook('conv1_gdn1', lambda: dev.conv9x9s4_u8(luminances_uint8, enc.w1, v['encoder/biases_1'], enc.g[1], v['encoder/beta_1']))
         ws = self._conv_ws[slot]
         gdn_2 = hook('conv2_gdn2', lambda: dev.conv5x5s2(gdn_1, enc.w2, v['encoder/biases_2'], dev.NORM_GDN, enc.g[2], v['encoder/beta_2'], workspace=ws))
+        # (histograms, overflow, flags, checks, squared errors are accumulated into: zero when the slot is made, and zeroed again by the
+        # launches that publish them, `_launch_coder` / `_launch_synthesis`)
         (_, hist, overflow, flags, checks) = self._views(self._slot_out[slot])
-        self._slot_all[slot][4*self._n_maps:].zero_()    # histograms, overflow, flags, checks, squared errors: accumulated into
         gdn_in = None if self.learned else (enc.g[3], v['encoder/beta_3'])
         igdn_out = None if self.learned else (self.decoder.g[4], d['decoder/beta_4'])
         if self.fuse_latent:
@@ -697,8 +700,8 @@ class BatchCodec(object):
             self._pinned_symbols[slot].copy_(self._symbols[slot], non_blocking=True)
         else:
             self._views(self._slot_out[slot])[0].zero_()
-        dev.publish_to_host(self._slot_out[slot], self._pinned_out[slot])
-        dev.publish_sequence(self._seq_dev[slot][0:1], self._pinned_seq[slot][0:1])
+        seq = self._seq_dev[slot]
+        dev.publish_step(self._slot_out[slot], self._pinned_out[slot], 4*self._n_maps, seq[2:3], seq[0:1], self._pinned_seq[slot][0:1])
 
     def _launch_synthesis_head(self, latents, slot, hook):
         """tconv1+IGDN5 on the current stream (the first launch of the synthesis side, apart: `_coder_behind_tconv1`)."""
@@ -721,9 +724,9 @@ class BatchCodec(object):
                                                                             sse=self._slot_sse[slot][:self.batch_size]))
         # every conv launch of this step (analysis side too: same stream, same workspace) is behind us: its error word, and a
         # clean workspace for the slot's next step
-        dev.conv_workspace_collect(ws, self._slot_unfinished[slot])
-        dev.publish_to_host(self._slot_sse[slot], self._pinned_sse[slot])
-        dev.publish_sequence(self._seq_dev[slot][1:2], self._pinned_seq[slot][1:2])
+        seq = self._seq_dev[slot]
+        dev.publish_step(self._slot_sse[slot], self._pinned_sse[slot], 0, seq[3:4], seq[1:2], self._pinned_seq[slot][1:2],
+                         conv_ws=ws, error_word=self._slot_unfinished[slot])
         return reconstruction
 
     def drain(self):

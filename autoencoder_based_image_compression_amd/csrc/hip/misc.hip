@@ -1,5 +1,6 @@
 // misc.hip -- library identity and device probing.
 #include "common.h"
+#include "conv_gemm.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -98,6 +99,55 @@ __global__ void sequence_kernel(uint32_t* __restrict__ counter, volatile uint32_
 extern "C" int eae_hip_publish_sequence(void* counter_device, void* word_host_mapped, void* stream) {
     if (!counter_device || !word_host_mapped) return -1;
     hipLaunchKernelGGL(sequence_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (uint32_t*)counter_device, (volatile uint32_t*)word_host_mapped);
+    return (int)hipGetLastError();
+}
+
+// The end of one side of a step in ONE launch (a launch costs the submitting thread ~10 us, and a step of one image is two dozen of
+// them): [the conv workspace's error word collected, as conv_workspace_collect_kernel does] -> the result block copied to pinned
+// memory -> the accumulators among it (words from `clear_from` on) zeroed for the slot's next step -> the step counter bumped and
+// left in pinned memory behind the copy. Several blocks copy; the last one through (a ticket word, left at zero) bumps the counter.
+__global__ __launch_bounds__(256) void publish_step_kernel(uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint64_t words, uint64_t clear_from,
+                                                           unsigned int* ws, uint32_t* error_word, uint32_t* tickets, uint32_t* counter,
+                                                           volatile uint32_t* host_word) {
+    if (ws != nullptr) {      // one block (the entry point sees to it): the error word lies in `src`
+        const unsigned int e = ws[eae_conv_gemm::SPLIT_ERROR_WORD];
+        if (e != 0u) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < eae_conv_gemm::SPLIT_WORDS; i += blockDim.x) ws[i] = 0u;
+            if (threadIdx.x == 0) atomicAdd(error_word, e);
+            __threadfence();
+        }
+        __syncthreads();
+    }
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x) {
+        dst[i] = __builtin_nontemporal_load(src + i);
+        if (i >= clear_from) src[i] = 0u;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool last = gridDim.x == 1u || atomicAdd(tickets, 1u) == gridDim.x - 1u;
+        if (last) {
+            if (gridDim.x != 1u) *tickets = 0u;
+            __threadfence_system();      // the other blocks' copies (fenced before their tickets) before the counter
+            const uint32_t v = *counter + 1u;
+            *counter = v;
+            *host_word = v;
+            __threadfence_system();
+        }
+    }
+}
+extern "C" int eae_hip_publish_step(void* src_device, void* dst_host_mapped, uint64_t bytes, uint64_t clear_from_byte, void* conv_workspace,
+                                    uint32_t* error_word, void* tickets_device, void* counter_device, void* word_host_mapped, void* stream) {
+    if (!src_device || !dst_host_mapped || !tickets_device || !counter_device || !word_host_mapped || (bytes & 3u) || (clear_from_byte & 3u)) return -1;
+    if ((conv_workspace == nullptr) != (error_word == nullptr)) return -1;
+    const uint64_t words = bytes / 4;
+    if (conv_workspace && words > 65536u) return -1;      // the collected word is copied by the block that collected it
+    unsigned blocks = (unsigned)((words + 255) / 256 > 64 ? 64 : (words + 255) / 256);
+    if (blocks == 0u || conv_workspace) blocks = 1u;
+    hipLaunchKernelGGL(publish_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (uint32_t*)src_device, (uint32_t*)dst_host_mapped, words,
+                       clear_from_byte / 4, (unsigned int*)conv_workspace, error_word, (uint32_t*)tickets_device, (uint32_t*)counter_device,
+                       (volatile uint32_t*)word_host_mapped);
     return (int)hipGetLastError();
 }
 

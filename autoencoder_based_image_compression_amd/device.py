@@ -555,6 +555,20 @@ def publish_sequence(counter_device, word_pinned):
     _check(_native.hip().eae_hip_publish_sequence(_p(counter_device), word_pinned.data_ptr(), _stream(counter_device)), 'eae_hip_publish_sequence')
 
 
+def publish_step(src_device, dst_pinned, clear_from, tickets_device, counter_device, word_pinned, conv_ws=None, error_word=None):
+    """One launch for the end of a step's side (include/eae_hip.h: eae_hip_publish_step): [`conv_workspace_collect(conv_ws,
+    error_word)`] -> `publish_to_host(src_device, dst_pinned)` -> `src_device` zeroed from element `clear_from` on (its accumulators,
+    for the step that uses it next) -> `publish_sequence(counter_device, word_pinned)`. `tickets_device`: a zeroed int32 on the device."""
+    nbytes = src_device.numel()*src_device.element_size()
+    if not dst_pinned.is_pinned() or dst_pinned.numel()*dst_pinned.element_size() != nbytes or not dst_pinned.is_contiguous() or not word_pinned.is_pinned():
+        raise HipError('expected contiguous pinned host tensors, the first of the size of the source')
+    if any(t.numel() != 1 or t.element_size() != 4 for t in (tickets_device, counter_device, word_pinned)):
+        raise HipError('expected three 32-bit words')
+    _check(_native.hip().eae_hip_publish_step(_p(src_device), dst_pinned.data_ptr(), nbytes, int(clear_from)*src_device.element_size(),
+                                              _p(conv_ws), _p(error_word), _p(tickets_device), _p(counter_device),
+                                              word_pinned.data_ptr(), _stream(src_device)), 'eae_hip_publish_step')
+
+
 def coder_workspace(n_maps, map_size, truncated_unary_length, device):
     """Scratch for coder_encode_batch / coder_decode_batch (one per batch in flight)."""
     nbytes = int(_native.hip().eae_hip_coder_workspace_bytes(n_maps, map_size, truncated_unary_length))

@@ -54,6 +54,15 @@ int eae_hip_publish_to_host(const void* src_device, void* dst_host_mapped, uint6
  * eae_hip_publish_to_host in front of it. The host, which knows how many times it submitted the step, waits for that value with
  * plain loads: no event to record, query or wait on (capturable into a hipGraph: every replay bumps the counter). */
 int eae_hip_publish_sequence(void* counter_device, void* word_host_mapped, void* stream);
+/* The end of one side of a step in ONE launch (what codec.BatchCodec enqueues behind a batch's coder and behind its synthesis
+ * transform; each launch costs the submitting thread ~10 us): in stream order, (1) when `conv_workspace` is given, what
+ * eae_hip_conv_workspace_collect does with it and `error_word` (which must lie inside the source block: it is copied in (2); the block
+ * is then at most 256 KB); (2) eae_hip_publish_to_host of `bytes` from `src_device`; (3) the source's bytes from `clear_from_byte` on are
+ * zeroed -- the accumulators of the next step that uses the block (pass `bytes` to clear nothing); (4) eae_hip_publish_sequence on
+ * `counter_device` / `word_host_mapped`, behind the copy. `tickets_device`: a zeroed uint32 in device memory, left zeroed (the copying
+ * blocks count themselves in; steps that may run concurrently need their own). */
+int eae_hip_publish_step(void* src_device, void* dst_host_mapped, uint64_t bytes, uint64_t clear_from_byte, void* conv_workspace,
+                         uint32_t* error_word, void* tickets_device, void* counter_device, void* word_host_mapped, void* stream);
 
 /* ---- whole-path entry points (csrc/hip/model.hip) --------------------------------------------------------------------
  * What `sess.run(entropy_ae.node_y, feed_dict={node_visible_units: batch})` (eae/batching.py:96-99) and

@@ -20,6 +20,7 @@ memory (no hipMemcpyAsync on the launch thread) and a worker thread turns them i
 and sleeps in between instead of spinning in `synchronize()` (eight ranks share one host CPU quota). For small batches the
 step can be replayed as three hipGraphs per slot (`use_graphs`) over several transform streams (`nb_transform_streams`).
 """
+import contextlib
 import os
 import queue
 import threading
@@ -273,7 +274,7 @@ class BatchCodec(object):
     def __init__(self, variables, are_bin_widths_learned, bin_widths_test, map_mean, binary_probabilities, idx_map_exception,
                  batch_size, h_in, w_in, device='cuda', nb_in_flight=None, keep_reconstruction=False, launch_hook=None,
                  coder='device', host_coder_threads=0, hist_radius=2047, nb_transform_streams=1, use_graphs=False,
-                 time_coder=False, fuse_latent=False, fetch_reconstruction=False, coder_chunks=None):
+                 time_coder=False, fuse_latent=False, fetch_reconstruction=False, coder_chunks=None, one_stream_steps=False):
         """coder: 'device' (the coder kernels on side streams), 'host' (ONE device -> host copy of the symbols per batch, then
         the host C-ABI coder `eae_coder_compress_maps` on `host_coder_threads` threads: the shape BASELINE.json sketches) or
         'none' (transforms only; the bit counts come back as zeros).
@@ -281,6 +282,11 @@ class BatchCodec(object):
         `default_nb_in_flight(h_in, w_in)`).
         nb_transform_streams: 1 = the transforms run on the caller's current stream; more = consecutive batches alternate
         between that many private streams (worth it only for small batches, whose kernels leave most of the GPU idle).
+        one_stream_steps: a step's coder runs on the step's transform stream, behind its synthesis transform, instead of beside it on a
+        coder stream: ONE graph launch per step, no event between streams. For one or two images per step, where consecutive steps on
+        `nb_transform_streams` streams are what fills the GPU and the HIP runtime's signal thread -- one wake-up per graph launch and
+        per event -- is what bounds the rate (one Kodak image per step: 0.30 -> 0.2 ms per image; a single step takes the coder's
+        0.2 ms longer).
         use_graphs: capture the launches of one step into three hipGraphs per slot on first use (analysis side, coder,
         synthesis side) and replay them afterwards: three host launches per step instead of about twenty. For small batches, where the launch thread is the
         bottleneck (one Kodak image per step); `launch_hook` is not called for replayed steps. Not for coder='host'.
@@ -337,6 +343,7 @@ class BatchCodec(object):
         self.coder = coder
         self.time_coder = bool(time_coder)      # Ticket.coder_ms(): the launch-by-launch path only
         self.fuse_latent = bool(fuse_latent)
+        self.one_stream_steps = bool(one_stream_steps)
         # launch_hook(name, fn): called for every timed launch of the launch-by-launch path with name in ('conv1_gdn1',
         # 'conv2_gdn2', 'conv3', 'latent', 'tconv1_igdn5', 'tconv2_igdn6', 'tconv3', 'coder_encode', 'coder_decode') on the
         # stream the launch goes to (bench.py brackets them with HIP events); it must return fn()
@@ -353,9 +360,19 @@ class BatchCodec(object):
             nb_in_flight = default_nb_in_flight(h_in, w_in)
         self.nb_in_flight = nb_in_flight
         self.nb_slots = nb_in_flight + 2
-        self._streams = _side_streams(nb_in_flight, self.device)
         nb_private = nb_transform_streams if (nb_transform_streams > 1 or use_graphs) else 0      # replays never go to the caller's stream
-        self._transform_streams = _side_streams(nb_private, self.device, kind='transform')
+        if self.one_stream_steps:
+            # no coder streams; the steps' streams come from both of the process's lists, so that a process that has run other codecs
+            # makes as few new streams as it can (streams beyond GPU_MAX_HW_QUEUES share hardware queues, busy ones with busy ones)
+            self._streams = []
+            made = len(_SIDE_STREAMS.get((self.device.index, 'transform'), ())) + len(_SIDE_STREAMS.get((self.device.index, 'coder'), ()))
+            nb_coder_kind = min(len(_SIDE_STREAMS.get((self.device.index, 'coder'), ())), max(0, nb_private - len(_SIDE_STREAMS.get((self.device.index, 'transform'), ()))))
+            if made == 0:
+                nb_coder_kind = 0
+            self._transform_streams = _side_streams(nb_private - nb_coder_kind, self.device, kind='transform') + _side_streams(nb_coder_kind, self.device)
+        else:
+            self._streams = _side_streams(nb_in_flight, self.device)
+            self._transform_streams = _side_streams(nb_private, self.device, kind='transform')
         # ... and behind the squared errors one more 64-bit word whose low half is the conv workspace's error word of the step
         self._slot_all = [torch.zeros(nb_words + 2*batch_size + 2, dtype=torch.int32, device=self.device) for _ in range(self.nb_slots)]
         self._slot_out = [t[:nb_words] for t in self._slot_all]
@@ -473,7 +490,7 @@ class BatchCodec(object):
             self._warm = True
         slot = self._index % self.nb_slots
         stream = self._transform_streams[self._index % len(self._transform_streams)]
-        coder_stream = self._streams[self._index % len(self._streams)]
+        coder_stream = self._streams[self._index % len(self._streams)] if self._streams else None
         self._index += 1
         self._slot_free[slot].wait()
         self._slot_free[slot].clear()
@@ -495,17 +512,22 @@ class BatchCodec(object):
                     stream.wait_stream(caller)
                     static_input.copy_(luminances_uint8, non_blocking=True)
                 graphs[0].replay()
-                quantized = torch.cuda.Event()
-                quantized.record(stream)
-                torch.cuda.set_stream(coder_stream)
-                coder_stream.wait_event(quantized)
-                graphs[1].replay()
                 (coded, decoded) = (None, None)
-                if not sequence_mode:
-                    coded = torch.cuda.Event()
-                    coded.record(coder_stream)
-                torch.cuda.set_stream(stream)
-                graphs[2].replay()
+                if self.one_stream_steps:
+                    if not sequence_mode:                     # the whole step is graphs[0]: both of the worker's events behind it
+                        coded = torch.cuda.Event()
+                        coded.record(stream)
+                else:
+                    quantized = torch.cuda.Event()
+                    quantized.record(stream)
+                    torch.cuda.set_stream(coder_stream)
+                    coder_stream.wait_event(quantized)
+                    graphs[1].replay()
+                    if not sequence_mode:
+                        coded = torch.cuda.Event()
+                        coded.record(coder_stream)
+                    torch.cuda.set_stream(stream)
+                    graphs[2].replay()
                 if not sequence_mode or self.keep_reconstruction:      # (a caller reading the reconstruction on another stream waits for it)
                     decoded = torch.cuda.Event()
                     decoded.record(stream)
@@ -549,8 +571,16 @@ class BatchCodec(object):
             # any of the codec's streams will do for the capture: a replay runs on the stream it is launched into, which
             # `_submit_graph` picks from the submission index (slots and streams go round at different periods)
             stream = self._transform_streams[slot % len(self._transform_streams)]
-            coder_stream = self._streams[slot % len(self._streams)]
+            coder_stream = self._streams[slot % len(self._streams)] if self._streams else None
             static_input = torch.empty(tuple(like.shape), dtype=torch.uint8, device=self.device)      # `like` may be a host batch
+            if self.one_stream_steps:
+                graphs = [torch.cuda.CUDAGraph()]
+                with torch.cuda.graph(graphs[0], stream=stream, capture_error_mode='thread_local'):
+                    latents = self._launch_analysis(static_input, slot, None)
+                    reconstruction = self._launch_synthesis(latents, static_input, slot, None)
+                    self._launch_coder(slot)
+                self._graphs[slot] = (graphs, static_input, latents, reconstruction)
+                continue
             graphs = [torch.cuda.CUDAGraph() for _ in range(3)]
             with torch.cuda.graph(graphs[0], stream=stream, capture_error_mode='thread_local'):
                 latents = self._launch_analysis(static_input, slot, None)
@@ -564,7 +594,7 @@ class BatchCodec(object):
 
     def _submit(self, luminances_uint8):
         slot = self._index % self.nb_slots
-        stream = self._streams[self._index % len(self._streams)]
+        stream = self._streams[self._index % len(self._streams)] if self._streams else None
         self._index += 1
         self._slot_free[slot].wait()
         self._slot_free[slot].clear()
@@ -580,13 +610,18 @@ class BatchCodec(object):
                 self._feed(luminances_uint8, self._staging[slot], fed, fresh)
                 luminances_uint8 = self._staging[slot]
             latents = self._launch_analysis(luminances_uint8, slot, hook)
-            if self._coder_behind_tconv1:
+            head_done = self._coder_behind_tconv1 and not self.one_stream_steps
+            if head_done:
                 latents = self._launch_synthesis_head(latents, slot, hook)
-            quantized = torch.cuda.Event()
-            quantized.record()
             ticket = Ticket(self.batch_size)
-            with torch.cuda.stream(stream):
-                stream.wait_event(quantized)
+            if self.one_stream_steps:                          # the coder behind the synthesis transform, on this stream
+                reconstruction = self._launch_synthesis(latents, luminances_uint8, slot, hook)
+            else:
+                quantized = torch.cuda.Event()
+                quantized.record()
+            with (contextlib.nullcontext() if self.one_stream_steps else torch.cuda.stream(stream)):
+                if not self.one_stream_steps:
+                    stream.wait_event(quantized)
                 if self.time_coder:
                     started = torch.cuda.Event(enable_timing=True)
                     started.record()
@@ -597,7 +632,8 @@ class BatchCodec(object):
                     coded.record()
                 if self.time_coder:
                     ticket._coder_span = (started, coded)
-            reconstruction = self._launch_synthesis(latents, luminances_uint8, slot, hook, head_done=self._coder_behind_tconv1)
+            if not self.one_stream_steps:
+                reconstruction = self._launch_synthesis(latents, luminances_uint8, slot, hook, head_done=head_done)
             if not sequence_mode or self.keep_reconstruction:
                 decoded = torch.cuda.Event()
                 decoded.record()

@@ -66,15 +66,16 @@ device = torch.device('cuda', 0)
 torch.cuda.set_device(device)
 ctx = Ctx(args, device, 1, 0, bench.usable_cpus())
 variables = bench.synthetic_model(1.)
-run = bench.run_pipeline(ctx, 24, STEPS, 10, variables, 512, 768, coder_streams=bench.auto_coder_streams(512, 768), transform_streams=TSTREAMS,
-                         use_graphs=GRAPHS)
+BATCH = int(os.environ.get('BATCH', '24'))      # BATCH=1 CODER_STREAMS=8 ... 3000 1 6: the pipelined single-image leg of bench.py
+run = bench.run_pipeline(ctx, BATCH, STEPS, 10, variables, 512, 768, coder_streams=int(os.environ.get('CODER_STREAMS', '0')) or bench.auto_coder_streams(512, 768),
+                         transform_streams=TSTREAMS, use_graphs=GRAPHS, one_stream_steps=os.environ.get('ONE', '0') == '1')
 (a, _), (b, names) = ctx.snaps[0], ctx.snaps[1]
 hz = os.sysconf('SC_CLK_TCK')
 sec = run['elapsed']
 print('graphs', GRAPHS, 'transform streams', TSTREAMS, {k: v for (k, v) in os.environ.items() if k.startswith(('HSA_', 'ROC_', 'AMD_', 'GPU_', 'EAE_', 'DEBUG_'))})
 print('block %.3f s, %.3f ms/step' % (sec, sec/STEPS*1e3))
 rows = sorted(((b[t][0] - a.get(t, (0, 0))[0] + b[t][1] - a.get(t, (0, 0))[1])/hz, t) for t in b)
-for (cpu, t) in rows[::-1][:4]:
+for (cpu, t) in rows[::-1][:6]:
     print('%6.3f s cpu = %5.2f ms/step  user %.2f sys %.2f  tid %d %s' % (cpu, cpu/STEPS*1e3, (b[t][0] - a.get(t, (0, 0))[0])/hz, (b[t][1] - a.get(t, (0, 0))[1])/hz,
                                                                        t, names.get(t, '(not a Python thread: runtime)')))
 print('total %.2f ms/step' % (sum(r[0] for r in rows)/STEPS*1e3))

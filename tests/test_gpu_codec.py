@@ -454,3 +454,36 @@ def test_a_trailing_coder_gives_the_same_results(graphs):
     for chunks in (4, 7):
         for (a, b) in zip(results[None], results[chunks]):
             assert all(numpy.array_equal(a[k], b[k]) for k in a), chunks
+
+
+@pytest.mark.parametrize('graphs', [False, True])
+@pytest.mark.parametrize('batch', [1, 3])
+def test_steps_on_one_stream_give_the_same_results(graphs, batch):
+    """`one_stream_steps`: a step's coder behind its synthesis transform on the step's own stream (one graph launch per step, no
+    event between streams; the mode for one or two images per step) against the default schedule: every result of every step
+    equal, the reconstructions too, through many more steps than there are slots."""
+    from autoencoder_based_image_compression_amd import codec
+    import bench
+    with numpy.load(GOLD) as g:
+        probabilities = g['real_probabilities_1']
+    variables = bench.synthetic_model(0.25)
+    images = torch.from_numpy(bench.synthetic_images(11, 3*batch, 128, 192)).cuda()
+    mean = numpy.zeros(128, dtype=numpy.float32)
+    (results, reconstructions) = ({}, {})
+    for one in (False, True):
+        kwargs = {'nb_in_flight': 4, 'nb_transform_streams': 4, 'use_graphs': True} if graphs else {'nb_in_flight': 2, 'nb_transform_streams': 2}
+        with codec.BatchCodec(variables, False, variables['piecewise_linear_function/bin_widths'], mean, probabilities, 67, batch, 128, 192,
+                              keep_reconstruction=True, one_stream_steps=one, **kwargs) as c:
+            (results[one], reconstructions[one]) = ([], [])
+            for j in [0, 1, 2]*7:
+                t = c.submit(images[j*batch:(j + 1)*batch])
+                results[one].append(t.result())
+                reconstructions[one].append(t.reconstruction_uint8.cpu().numpy().copy())
+            tickets = [c.submit(images[j*batch:(j + 1)*batch]) for j in [2, 1, 0]*5]      # ... and with the steps in flight together
+            results[one].extend(t.result() for t in tickets)
+    assert len(results[True]) == len(results[False]) == 36
+    for (a, b) in zip(results[False], results[True]):
+        assert all(numpy.array_equal(a[k], b[k]) for k in a)
+    for (a, b) in zip(reconstructions[False], reconstructions[True]):
+        assert numpy.array_equal(a, b)
+    assert sum(int(r['nb_bits'].sum()) for r in results[True]) > 0

@@ -153,18 +153,25 @@ class _Worker(threading.Thread):
         else:
             event.synchronize()
 
-    @staticmethod
-    def _wait_sequence(words, expected):
-        """Until the step counters the device leaves in pinned memory (`words`: numpy int32 view) have reached `expected`."""
+    _typical_wait = 0.      # seconds this thread lately had to wait per job (a running mean): `_wait_sequence` sleeps through most of it
+
+    def _wait_sequence(self, words, expected):
+        """Until the step counters the device leaves in pinned memory (`words`: numpy int32 view) have reached `expected`. Every
+        sleep is a system call and a wake-up of this thread (a fifth of its time per step at twelve polls a step): the first sleep
+        is three quarters of what the wait has lately been, the polls come after it."""
         deadline = None
+        started = time.monotonic()
+        first = 0.75*self._typical_wait if self._typical_wait > 4.*_SEQUENCE_POLL_SECONDS else 0.
         for (index, value) in enumerate(expected):
             while ((int(words[index]) - value) & 0xFFFFFFFF) >= 0x80000000:      # words[index] < value, wrap-around safe
-                time.sleep(_SEQUENCE_POLL_SECONDS)
+                time.sleep(max(first, _SEQUENCE_POLL_SECONDS))
+                first = 0.
                 if deadline is None:
                     deadline = time.monotonic() + _SEQUENCE_TIMEOUT_SECONDS
                 elif time.monotonic() > deadline:
                     raise RuntimeError('the device has not reported step {0} of this slot after {1:.0f} s (step counter at {2})'.format(
                         value, _SEQUENCE_TIMEOUT_SECONDS, int(words[index])))
+        self._typical_wait += 0.25*(min(time.monotonic() - started, 0.05) - self._typical_wait)
 
     def run(self):
         _short_sleeps_for_this_thread()
@@ -219,8 +226,7 @@ class _Worker(threading.Thread):
                         # a symbol beyond +-hist_radius: the reference's histogram runs from the smallest to the largest symbol
                         # whatever they are (lossless/compression.py:68-75, tools.py:376-388), so count again over all of int16
                         hist = recount()
-                    exception_bits = numpy.array([int(lossless_compression.exception_map_nb_bits(row, self.map_size))
-                                                  for row in hist.astype(numpy.int64)], dtype=numpy.int64)
+                    exception_bits = lossless_compression.exception_maps_nb_bits(hist.astype(numpy.int64), self.map_size)
                 ticket._values = {'nb_bits': coder_bits + exception_bits, 'coder_bits': coder_bits,
                                   'exception_bits': exception_bits, 'sse': sse.astype(numpy.int64).copy(),
                                   'nb_deads': (flags == 0).sum(axis=1).astype(numpy.int64)}

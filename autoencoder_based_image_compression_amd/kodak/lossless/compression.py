@@ -168,6 +168,13 @@ def exception_map_nb_bits(hist_row, map_size):
     return numpy.ceil(cumulated_entropy).astype(numpy.uint32)
 
 
+def exception_maps_nb_bits(hist_rows, map_size):
+    """`exception_map_nb_bits` of every row of `hist_rows` (int64 [N, bins]) -> int64 [N], bit for bit: the entropies of all rows in
+    one pass (`tools._entropies_from_hist_rows`: the element-wise steps at once, every row's sum in `numpy.sum`'s own order, rows near
+    a bound through the verbatim expression so that the reference's ValueError still comes from its own comparison)."""
+    return numpy.ceil(map_size*tls._entropies_from_hist_rows(hist_rows)).astype(numpy.uint32).astype(numpy.int64)
+
+
 # The functions are sorted in alphabetic order.
 
 def compress_lossless_maps(ref_int16, path_to_binary_probabilities, idx_map_exception=-1):

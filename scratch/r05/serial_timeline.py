@@ -24,13 +24,13 @@ stamps = {}
 orig_wait = codec._Worker._wait_sequence
 
 
-def wait_sequence(words, expected):
+def wait_sequence(self, words, expected):
     stamps['worker_has_job'] = time.perf_counter()
-    orig_wait(words, expected)
+    orig_wait(self, words, expected)
     stamps['worker_sees_counters'] = time.perf_counter()
 
 
-codec._Worker._wait_sequence = staticmethod(wait_sequence)
+codec._Worker._wait_sequence = wait_sequence
 orig_set = codec.threading.Event.set
 rows = []
 with codec.BatchCodec(v, False, v[var.BIN_WIDTHS_NAME], mean, prob, 67, 1, 512, 768, nb_in_flight=1, nb_transform_streams=1, use_graphs=True) as c:

@@ -133,3 +133,21 @@ def test_row_sums_refuse_bad_arguments():
     as_p = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
     assert lib.eae_coder_pairwise_row_sums(as_p(values, ctypes.c_double), as_p(descending, ctypes.c_int64), 2, as_p(out, ctypes.c_double)) == 5      # EAE_OUT_OF_RANGE
     assert lib.eae_coder_pairwise_row_sums(as_p(values, ctypes.c_double), None, 2, as_p(out, ctypes.c_double)) == -1      # EAE_NULL_POINTER
+
+
+def test_exception_bits_of_a_batch_equal_the_per_map_function():
+    """`exception_maps_nb_bits` (the result worker's one call per batch) == `exception_map_nb_bits` row by row, incl. histograms
+    whose occupied bins have gaps, single-bin maps and the widths a recount over all of int16 gives."""
+    from autoencoder_based_image_compression_amd.kodak.lossless import compression
+    rng = numpy.random.RandomState(8)
+    for (bins, map_size) in ((4095, 1536), (65535, 1536), (511, 256), (4095, 16384)):
+        hist = numpy.zeros((24, bins), dtype=numpy.int64)
+        for i in range(24):
+            k = int(rng.choice([1, 2, 3, 9, 40, 200]))
+            centre = bins//2 + int(rng.randint(-20, 21))
+            idx = numpy.unique(numpy.clip(centre + rng.randint(-150, 151, size=k), 0, bins - 1))
+            counts = rng.multinomial(map_size - idx.size, numpy.ones(idx.size)/idx.size) + 1
+            hist[i, idx] = counts
+        expected = numpy.array([int(compression.exception_map_nb_bits(row, map_size)) for row in hist], dtype=numpy.int64)
+        got = compression.exception_maps_nb_bits(hist, map_size)
+        assert got.dtype == numpy.int64 and numpy.array_equal(got, expected)

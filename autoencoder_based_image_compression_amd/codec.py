@@ -290,9 +290,9 @@ class BatchCodec(object):
         between that many private streams (worth it only for small batches, whose kernels leave most of the GPU idle).
         one_stream_steps: a step's coder runs on the step's transform stream, behind its synthesis transform, instead of beside it on a
         coder stream: ONE graph launch per step, no event between streams. For one or two images per step, where consecutive steps on
-        `nb_transform_streams` streams are what fills the GPU and the HIP runtime's signal thread -- one wake-up per graph launch and
-        per event -- is what bounds the rate (one Kodak image per step: 0.30 -> 0.2 ms per image; a single step takes the coder's
-        0.2 ms longer).
+        `nb_transform_streams` streams are what fills the GPU and a hop between streams costs 60-100 us on this runtime (one Kodak
+        image per step on 14 streams: 0.295 -> 0.252 ms per image, the launching thread 0.15 -> 0.06 ms; a single step takes the
+        coder's 0.2 ms longer).
         use_graphs: capture the launches of one step into three hipGraphs per slot on first use (analysis side, coder,
         synthesis side) and replay them afterwards: three host launches per step instead of about twenty. For small batches, where the launch thread is the
         bottleneck (one Kodak image per step); `launch_hook` is not called for replayed steps. Not for coder='host'.

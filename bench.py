@@ -794,8 +794,8 @@ def main(args):
 
 def single_image_pipelined_leg(ctx, variables, h, w, steps=1000):
     """One image per step, pipelined: fourteen steps in flight, each ONE graph launch on a stream of its own with the coder behind the
-    synthesis transform instead of beside it (codec.BatchCodec(one_stream_steps=True)). What bounds this rate is the HIP runtime's signal
-    thread, busy for ~10 us per kernel, event and graph launch of a step."""
+    synthesis transform instead of beside it (codec.BatchCodec(one_stream_steps=True)): no hop between streams, a third of the launching
+    thread's work per step."""
     one = run_pipeline(ctx, 1, steps, 30, variables, h, w, coder_streams=14, transform_streams=14, use_graphs=True, one_stream_steps=True)
     return {'ms_per_image': round(one['elapsed']/steps*1e3, 4), 'mpixels_per_s': round(steps*h*w/one['elapsed']/1e6, 2), 'steps': steps, 'warmup': 30,
             'host_cpu_ms_per_image': one['host_cpu_ms_per_step'][0], 'pipelined_in': 'a process of its own (python bench.py --only-single-image-pipelined)'}

@@ -67,7 +67,8 @@ torch.cuda.set_device(device)
 ctx = Ctx(args, device, 1, 0, bench.usable_cpus())
 variables = bench.synthetic_model(1.)
 BATCH = int(os.environ.get('BATCH', '24'))      # BATCH=1 CODER_STREAMS=8 ... 3000 1 6: the pipelined single-image leg of bench.py
-run = bench.run_pipeline(ctx, BATCH, STEPS, 10, variables, 512, 768, coder_streams=int(os.environ.get('CODER_STREAMS', '0')) or bench.auto_coder_streams(512, 768),
+(H, W) = (int(os.environ.get('H', '512')), int(os.environ.get('W', '768')))
+run = bench.run_pipeline(ctx, BATCH, STEPS, 10, variables, H, W, coder_streams=int(os.environ.get('CODER_STREAMS', '0')) or bench.auto_coder_streams(H, W),
                          transform_streams=TSTREAMS, use_graphs=GRAPHS, one_stream_steps=os.environ.get('ONE', '0') == '1')
 (a, _), (b, names) = ctx.snaps[0], ctx.snaps[1]
 hz = os.sysconf('SC_CLK_TCK')

@@ -487,3 +487,40 @@ def test_steps_on_one_stream_give_the_same_results(graphs, batch):
     for (a, b) in zip(reconstructions[False], reconstructions[True]):
         assert numpy.array_equal(a, b)
     assert sum(int(r['nb_bits'].sum()) for r in results[True]) > 0
+
+
+@pytest.mark.parametrize('words', [2, 50, 4096, 300001])
+def test_publish_step_copies_clears_and_counts(words):
+    """include/eae_hip.h: eae_hip_publish_step on its own -- the block reaches pinned memory whole, the source is zeroed from `clear_from`
+    on and untouched below it, the step counter is bumped once per call and left in pinned memory, the ticket word is back at zero
+    (one block and many blocks); with a conv workspace whose error word is set, the count lands in the error word inside the block
+    before it is copied and the workspace is all zero again."""
+    from autoencoder_based_image_compression_amd import device as dev
+    rng = numpy.random.RandomState(words)
+    src_host = rng.randint(1, 1 << 30, size=words).astype(numpy.int32)
+    src = torch.from_numpy(src_host.copy()).cuda()
+    dst = torch.zeros(words, dtype=torch.int32).pin_memory()
+    seq = torch.zeros(2, dtype=torch.int32, device='cuda')
+    word = torch.zeros(1, dtype=torch.int32).pin_memory()
+    clear_from = words//3
+    for call in (1, 2, 3):
+        dev.publish_step(src, dst, clear_from, seq[1:2], seq[0:1], word)
+        torch.cuda.synchronize()
+        expected = src_host.copy()
+        if call > 1:
+            expected[clear_from:] = 0
+        assert numpy.array_equal(dst.numpy(), expected)
+        assert numpy.array_equal(src.cpu().numpy()[:clear_from], src_host[:clear_from]) and not src[clear_from:].any().item()
+        assert int(word.item()) == call and seq.cpu().tolist() == [call, 0]
+    if words <= 65536:
+        ws = dev.conv_workspace('cuda')
+        ws[255] = 3                                           # the error word of a workspace: three tails gave up
+        ws[300] = 1                                           # a flag nobody reset
+        src.copy_(torch.from_numpy(src_host))
+        src[words - 1] = 0
+        dev.publish_step(src, dst, words, seq[1:2], seq[0:1], word, conv_ws=ws, error_word=src[words - 1:words])
+        torch.cuda.synchronize()
+        assert int(dst[words - 1].item()) == 3 and numpy.array_equal(dst.numpy()[:-1], src_host[:-1])
+        assert not ws.any().item() and int(word.item()) == 4
+        with pytest.raises(dev.HipError):
+            dev.publish_step(src, dst, 0, seq[1:2], seq[0:1], word, conv_ws=ws)      # a workspace without its error word

@@ -36,7 +36,7 @@ while time.time() - t0 < budget:
     rec_ref = orc.decoder(cq + mm, v, learned)[..., 0]
     u8_ref = numpy.round(rec_ref.clip(min=16., max=235.)).astype(numpy.uint8)
     c = codec.BatchCodec(v, learned, bw, mm, probabilities, 67, n, h, w, keep_reconstruction=True, use_graphs=bool(rng.randint(2)),
-                         nb_transform_streams=int(rng.randint(1, 3)))
+                         nb_transform_streams=int(rng.randint(1, 3)), one_stream_steps=bool(rng.randint(2)))
     for _ in range(2):
         t = c.submit(xd)
         r = t.result()

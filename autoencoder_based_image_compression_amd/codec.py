@@ -101,6 +101,14 @@ def _side_streams(count, device, kind='coder'):
     return streams[:count]
 
 
+def _step_streams(count, device):
+    """`count` streams for `one_stream_steps`: the device's transform streams as far as they exist, then its existing coder streams,
+    and only then new (transform) streams."""
+    existing_transform = len(_SIDE_STREAMS.get((device.index, 'transform'), ()))
+    from_coder = min(len(_SIDE_STREAMS.get((device.index, 'coder'), ())), max(0, count - existing_transform))
+    return _side_streams(count - from_coder, device, kind='transform') + _side_streams(from_coder, device)
+
+
 class Ticket(object):
     """Handle on one submitted batch."""
 
@@ -371,11 +379,7 @@ class BatchCodec(object):
             # no coder streams; the steps' streams come from both of the process's lists, so that a process that has run other codecs
             # makes as few new streams as it can (streams beyond GPU_MAX_HW_QUEUES share hardware queues, busy ones with busy ones)
             self._streams = []
-            made = len(_SIDE_STREAMS.get((self.device.index, 'transform'), ())) + len(_SIDE_STREAMS.get((self.device.index, 'coder'), ()))
-            nb_coder_kind = min(len(_SIDE_STREAMS.get((self.device.index, 'coder'), ())), max(0, nb_private - len(_SIDE_STREAMS.get((self.device.index, 'transform'), ()))))
-            if made == 0:
-                nb_coder_kind = 0
-            self._transform_streams = _side_streams(nb_private - nb_coder_kind, self.device, kind='transform') + _side_streams(nb_coder_kind, self.device)
+            self._transform_streams = _step_streams(nb_private, self.device)
         else:
             self._streams = _side_streams(nb_in_flight, self.device)
             self._transform_streams = _side_streams(nb_private, self.device, kind='transform')

@@ -241,8 +241,9 @@ def _entropies_from_hist_rows(hist_rows):
     """`_entropy_from_hist` (tools.py:523-537) of every row of `hist_rows` (int64 [C, bins]) -> float64 [C], bit for bit: the
     element-wise steps (counts / total, f*log2(f)) run once over the non-empty bins of all rows (element-wise results do not
     depend on where an element sits in its array), the sum of each row's terms is `numpy.sum` over that row's own contiguous run
-    (numpy's pairwise order depends on the length only; `_row_sums`: the same order, all rows in one call), and a row whose entropy comes within 1e-9 of a bound goes through the
-    verbatim function so that its two comparisons see the reference's own scalars."""
+    (numpy's pairwise order depends on the length only; `_row_sums`: the same order, all rows in one call), and a row whose
+    entropy comes within 1e-9 of a bound goes through the verbatim function so that its two comparisons see the reference's
+    own scalars."""
     nonzero = hist_rows != 0
     lengths = nonzero.sum(axis=1)
     counts = hist_rows[nonzero]                                     # row-major: each row's non-empty bins, ascending

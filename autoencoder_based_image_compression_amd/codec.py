@@ -252,9 +252,10 @@ def default_nb_in_flight(h_in, w_in):
     (profiles/r03_depth_sweep.txt, profiles/r03_i_bench.json): 24 Kodak-sized images per step (maps of 1,536 symbols): three
     to five in flight are equal within 1 % at 0.2 bpp, five is the best at 1.4 bpp and 16 % ahead of three at 3.2 bpp; 64
     images of 256x256 (maps of 256 symbols: short chains, short steps) lose 10 % with five against three; a 2048x2048 image
-    has maps of 16,384 symbols and needs eight."""
+    has maps of 16,384 symbols and needs eight. Round 5, on the shorter chains of that round's cores (profiles/r05_coder_waves_per_block.log):
+    six against five for Kodak-sized maps is equal within noise up to 2 bpp and 2 % ahead at 3.2 bpp (seven no better), so: six."""
     map_size = (h_in//csts.STRIDE_PROD)*(w_in//csts.STRIDE_PROD)
-    return int(min(8, 3 + map_size//768))
+    return int(min(8, 3 + map_size//512))
 
 
 def default_coder_chunks(n_maps):

@@ -57,7 +57,8 @@ _WAIT_MODE = os.environ.get('EAE_WORKER_WAIT', 'sequence')
 # profiles/r05_coder_behind_tconv1.log). For one or two images per batch the step IS the coder's chain and starting it a launch
 # later only adds to it (one image 1.23 -> 1.37 ms): there the coder starts as soon as the symbols exist. '0' / '1' force either.
 _CODER_BEHIND_TCONV1 = os.environ.get('EAE_CODER_BEHIND_TCONV1')
-_SEQUENCE_POLL_SECONDS = float(os.environ.get('EAE_WORKER_SEQUENCE_POLL_SECONDS', '0.0002'))
+# (0.1 ms between polls, behind the one long sleep of `_Worker._wait_sequence`: one image at a time 1.09 -> 1.05 ms against 0.2 ms, 0.03 ms more CPU per step)
+_SEQUENCE_POLL_SECONDS = float(os.environ.get('EAE_WORKER_SEQUENCE_POLL_SECONDS', '0.0001'))
 _SEQUENCE_TIMEOUT_SECONDS = float(os.environ.get('EAE_WORKER_SEQUENCE_TIMEOUT_SECONDS', '60'))
 
 

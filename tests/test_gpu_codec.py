@@ -407,15 +407,15 @@ def test_host_reconstructions_one_at_a_time_are_all_right():
 
 
 def test_the_product_mode_at_kodak_size_equals_the_conservative_one():
-    """`codec.product_mode(h, w)` (three transform streams, hipGraph replay, five coder batches in flight at this size: what
+    """`codec.product_mode(h, w)` (three transform streams, hipGraph replay, six coder batches in flight at this size: what
     bench.py's headline runs) against the constructor's defaults (every launch on the caller's stream), 24 images of 512 x 768,
-    twelve steps through the seven slots: same bits, errors, dead maps."""
+    twelve steps through the eight slots: same bits, errors, dead maps."""
     from autoencoder_based_image_compression_amd import codec
     from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
     with numpy.load(GOLD) as g:
         probabilities = g['real_probabilities_1']
     mode = codec.product_mode(512, 768)
-    assert mode == {'nb_in_flight': 5, 'nb_transform_streams': 3, 'use_graphs': True}
+    assert mode == {'nb_in_flight': 6, 'nb_transform_streams': 3, 'use_graphs': True}
     rng = numpy.random.RandomState(37)
     v = var.random_variables(1., False, seed=8, bias_std=0.01)
     v['decoder/weights_6'] = (v['decoder/weights_6']*numpy.float32(30.)).astype(numpy.float32)

@@ -765,11 +765,13 @@ def main(args):
             line['dropin_surface'] = {'error': '{0}: {1}'.format(type(exc).__name__, exc)}
     if side and 'single_image' in line:
         # the pipelined figure of one image per step, measured in a process of its own (this one waits, its GPU idle): the leg needs
-        # fourteen busy streams, this process has made fifteen by now, and streams beyond GPU_MAX_HW_QUEUES share hardware queues --
-        # busy ones with busy ones (in here: 0.28-0.36 ms per image where a fresh process measures 0.25-0.27, and whatever leg runs
-        # behind it loses up to 8 %). A child process, never an exec: this process has initialised the GPU.
+        # twenty busy streams, this process has made fifteen by now, and streams beyond GPU_MAX_HW_QUEUES share hardware queues --
+        # busy ones with busy ones (in here, with fourteen: 0.28-0.36 ms per image where a fresh process measures 0.25, and whatever leg
+        # runs behind it loses up to 8 %). A child process, never an exec: this process has initialised the GPU.
         try:
-            child = subprocess.run([sys.executable, os.path.abspath(__file__), '--only-single-image-pipelined', '--no-cpu-baseline'],
+            same_model = ['--bin-width', repr(args.bin_width)] + (['--checkpoint', args.checkpoint] if args.checkpoint else []) + (
+                ['--learned-bin-widths'] if args.learned_bin_widths else [])
+            child = subprocess.run([sys.executable, os.path.abspath(__file__), '--only-single-image-pipelined', '--no-cpu-baseline'] + same_model,
                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, check=True, text=True,
                                    env=dict(os.environ, GPU_MAX_HW_QUEUES='24'))      # twenty busy streams + the default one
             line['single_image'].update(json.loads([ln for ln in child.stdout.splitlines() if ln.startswith('{')][-1])['single_image_pipelined'])

@@ -179,9 +179,10 @@ class _Worker(threading.Thread):
         self._alone = self._alone + 1 if queued == 0 else 0
         steady = _LONG_SLEEP and (queued >= 2 or self._alone >= 4) and self._typical_wait > 4.*_SEQUENCE_POLL_SECONDS
         first = 0.75*self._typical_wait if steady else 0.
+        poll = 0.5*_SEQUENCE_POLL_SECONDS if self._alone >= 4 else _SEQUENCE_POLL_SECONDS      # one step at a time: the caller is waiting for this
         for (index, value) in enumerate(expected):
             while ((int(words[index]) - value) & 0xFFFFFFFF) >= 0x80000000:      # words[index] < value, wrap-around safe
-                time.sleep(max(first, _SEQUENCE_POLL_SECONDS))
+                time.sleep(max(first, poll))
                 first = 0.
                 if deadline is None:
                     deadline = time.monotonic() + _SEQUENCE_TIMEOUT_SECONDS

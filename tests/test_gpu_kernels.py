@@ -184,7 +184,7 @@ def test_tconv9x9s4_luma(T, dev, orc, shape):
         assert len(numpy.unique(ref_u8)) > 4   # the data exercises the cast, not only the clip floor
 
 
-@pytest.mark.parametrize('rows', [1, 127, 128, 1000])
+@pytest.mark.parametrize('rows', [1, 127, 128, 1000, 32767, 32801])      # below 128 rows per CU: 32-row blocks (a 32-channel tile per wave); from there on 128-row blocks
 @pytest.mark.parametrize('inverse', [False, True])
 def test_gdn(T, dev, orc, rows, inverse):
     v = _vars(10)

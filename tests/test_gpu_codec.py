@@ -524,3 +524,33 @@ def test_publish_step_copies_clears_and_counts(words):
         assert not ws.any().item() and int(word.item()) == 4
         with pytest.raises(dev.HipError):
             dev.publish_step(src, dst, 0, seq[1:2], seq[0:1], word, conv_ws=ws)      # a workspace without its error word
+
+
+@pytest.mark.parametrize('graphs', [False, True])
+def test_steps_on_one_stream_with_host_batches_and_the_host_coder(graphs):
+    """`one_stream_steps` next to the codec's other options: a pinned host batch in and the reconstruction back in pinned memory
+    (`fetch_reconstruction`), and the host coder (`coder='host'`): the same results and reconstructions as the default schedule."""
+    from autoencoder_based_image_compression_amd import codec
+    import bench
+    with numpy.load(GOLD) as g:
+        probabilities = g['real_probabilities_1']
+    variables = bench.synthetic_model(0.25)
+    host_images = torch.from_numpy(bench.synthetic_images(13, 4, 128, 192)).pin_memory()
+    mean = numpy.zeros(128, dtype=numpy.float32)
+    outcomes = {}
+    cases = ((False, 'device'), (True, 'device')) + (() if graphs else ((True, 'host'),))      # (graph replay needs the coder on the device)
+    for (one, coder) in cases:
+        kwargs = {'nb_in_flight': 3, 'nb_transform_streams': 3, 'use_graphs': True} if graphs else {'nb_in_flight': 2, 'nb_transform_streams': 2}
+        with codec.BatchCodec(variables, False, variables['piecewise_linear_function/bin_widths'], mean, probabilities, 67, 2, 128, 192,
+                              fetch_reconstruction=True, one_stream_steps=one, coder=coder, host_coder_threads=2, **kwargs) as c:
+            rows = []
+            for j in [0, 1]*6:
+                t = c.submit(host_images[2*j:2*j + 2])
+                r = t.result()
+                rows.append((r, t.reconstruction_host.copy()))
+            outcomes[(one, coder)] = rows
+    reference = outcomes[(False, 'device')]
+    for key in cases[1:]:
+        for ((a, rec_a), (b, rec_b)) in zip(reference, outcomes[key]):
+            assert all(numpy.array_equal(a[k], b[k]) for k in ('nb_bits', 'sse', 'nb_deads')), key
+            assert numpy.array_equal(rec_a, rec_b), key

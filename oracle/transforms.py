@@ -22,6 +22,8 @@ def lib():
                                          ctypes.c_int, ctypes.c_int, fp, fp]
         _lib.orc_conv2d_transpose_same.restype = None
         _lib.orc_conv2d_transpose_same.argtypes = _lib.orc_conv2d_same.argtypes
+        _lib.orc_conv2d_transpose_same_col2im.restype = None
+        _lib.orc_conv2d_transpose_same_col2im.argtypes = _lib.orc_conv2d_same.argtypes
         _lib.orc_gdn.restype = None
         _lib.orc_gdn.argtypes = [fp, ctypes.c_int64, ctypes.c_int, fp, fp, ctypes.c_int, fp]
     return _lib
@@ -48,8 +50,12 @@ def conv2d_same(x, w, stride, bias=None):
     return out
 
 
-def conv2d_transpose_same(x, w, stride, bias=None):
-    """tf.nn.conv2d_transpose(x, w[k,k,cout,cin], [n, s*h, s*w, cout], [1,s,s,1], 'SAME') (+ bias)."""
+def conv2d_transpose_same(x, w, stride, bias=None, col2im=False):
+    """tf.nn.conv2d_transpose(x, w[k,k,cout,cin], [n, s*h, s*w, cout], [1,s,s,1], 'SAME') (+ bias).
+
+    `col2im=False`: every output element one fmaf chain (channel block, u, v, channel). `col2im=True`: the order of a GEMM +
+    col2im implementation -- one 128-channel chain per (site, tap), the overlapping taps of an output pixel then added site
+    by site in raster order (transforms_oracle.c: orc_conv2d_transpose_same_col2im): the order of transpose_conv_3."""
     x = _f32(x)
     w = _f32(w)
     bias = _f32(bias) if bias is not None else None
@@ -57,7 +63,8 @@ def conv2d_transpose_same(x, w, stride, bias=None):
     (k, k2, cout, cin2) = w.shape
     assert k == k2 and cin == cin2
     out = numpy.empty((n, h*stride, wd*stride, cout), dtype=numpy.float32)
-    lib().orc_conv2d_transpose_same(_fp(x), n, h, wd, cin, _fp(w), k, stride, cout, _fp(bias), _fp(out))
+    fn = lib().orc_conv2d_transpose_same_col2im if col2im else lib().orc_conv2d_transpose_same
+    fn(_fp(x), n, h, wd, cin, _fp(w), k, stride, cout, _fp(bias), _fp(out))
     return out
 
 
@@ -94,6 +101,11 @@ DECODER_LAYERS = (
 )
 
 
+# The layer whose summation order is that of a GEMM + col2im implementation (round 6: the 9x9 stride-4 synthesis layer, where a
+# single chain per output pixel costs the gfx950 kernel 7 structural zeros in every 16 products; transforms_oracle.c).
+COL2IM_ORDER_LAYERS = frozenset(['decoder/weights_6'])
+
+
 def layers_of(table, are_bin_widths_learned):
     """The rows of a table that the model has."""
     return tuple(row for row in table if not (are_bin_widths_learned and len(row) == 4 and row[3] is True))
@@ -105,7 +117,8 @@ def _run(x, table, variables, are_bin_widths_learned):
         if row[0] == 'conv2d':
             x = conv2d_same(x, variables[row[1]], row[2], variables[row[3]] if row[3] else None)
         elif row[0] == 'conv2d_transpose':
-            x = conv2d_transpose_same(x, variables[row[1]], row[2], variables[row[3]] if row[3] else None)
+            x = conv2d_transpose_same(x, variables[row[1]], row[2], variables[row[3]] if row[3] else None,
+                                      col2im=row[1] in COL2IM_ORDER_LAYERS)
         else:
             x = gdn(x, variables[row[1]], variables[row[2]], inverse=row[0] == 'inverse_gdn')
         outputs.append(x)

@@ -127,6 +127,67 @@ void orc_conv2d_transpose_same(const float* x, int n, int h, int w, int cin, con
     free(wp);
 }
 
+/* The same operator in the order of a GEMM + col2im implementation (what im2col-based convolution code does for
+ * conv2d_transpose: one matrix product [sites x cin] . [cin x k*k*cout] into a column buffer, then the overlapping
+ * patches added into the image site by site). Used for transpose_conv_3 (components.py:79-83: 9x9, stride 4, 128 -> 1),
+ * where the fused single chain above forces 7 of every 16 matrix-unit products of the gfx950 kernel to be structural
+ * zeros (round 6):
+ *     part[p][q][u][v][co] = one fmaf chain over ci = 0 .. cin-1 ascending, started from +0
+ *     y[I][J][co]          = (((+0 + part(first site)) + part(next site)) + ...)   plain float additions, the
+ *                            contributing sites (p, q) in raster order: p ascending, then q ascending
+ *                            (u = I + pb - s p and v = J + pb - s q therefore descending), bias added last.
+ * Same value as orc_conv2d_transpose_same up to float32 rounding (tests/test_oracle_transforms.py holds both against the
+ * float64 definition). */
+void orc_conv2d_transpose_same_col2im(const float* x, int n, int h, int w, int cin, const float* wt, int k, int s, int cout,
+                                      const float* bias, float* out) {
+    const int ho = h * s, wo = w * s;
+    const int pbh = same_pad_before(ho, k, s), pbw = same_pad_before(wo, k, s);
+    const int kc = k * k * cout;
+    /* layout-only: [u][v][cout][cin] -> [cin][u][v][cout] so that the inner loop runs over contiguous (tap, co) */
+    float* wp = (float*)malloc(sizeof(float) * (size_t)kc * cin);
+    for (int t = 0; t < kc; ++t)
+        for (int ci = 0; ci < cin; ++ci) wp[(size_t)ci * kc + t] = wt[(size_t)t * cin + ci];
+    /* the column buffer: [b][p][q][u][v][co] */
+    float* col = (float*)malloc(sizeof(float) * (size_t)n * h * w * kc);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < n; ++b)
+        for (int p = 0; p < h; ++p)
+            for (int q = 0; q < w; ++q) {
+                const float* xp = x + (((size_t)b * h + p) * w + q) * cin;
+                float* cp = col + (((size_t)b * h + p) * w + q) * kc;
+                for (int t = 0; t < kc; ++t) cp[t] = 0.f;
+                for (int ci = 0; ci < cin; ++ci) {
+                    const float xv = xp[ci];
+                    const float* wrow = wp + (size_t)ci * kc;
+                    for (int t = 0; t < kc; ++t) cp[t] = fmaf(xv, wrow[t], cp[t]);
+                }
+            }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < n; ++b)
+        for (int I = 0; I < ho; ++I)
+            for (int J = 0; J < wo; ++J) {
+                /* the sites with 0 <= u = I + pb - s p < k: p from ceil((I + pb - k + 1) / s) to floor((I + pb) / s) */
+                int p_lo = I + pbh - k + 1, q_lo = J + pbw - k + 1;
+                p_lo = p_lo <= 0 ? 0 : (p_lo + s - 1) / s;
+                q_lo = q_lo <= 0 ? 0 : (q_lo + s - 1) / s;
+                const int p_hi = (I + pbh) / s < h - 1 ? (I + pbh) / s : h - 1;
+                const int q_hi = (J + pbw) / s < w - 1 ? (J + pbw) / s : w - 1;
+                for (int co = 0; co < cout; ++co) {
+                    float acc = 0.f;
+                    for (int p = p_lo; p <= p_hi; ++p) {
+                        const int u = I + pbh - p * s;
+                        for (int q = q_lo; q <= q_hi; ++q) {
+                            const int v = J + pbw - q * s;
+                            acc = acc + col[(((size_t)b * h + p) * w + q) * kc + (size_t)(u * k + v) * cout + co];
+                        }
+                    }
+                    out[(((size_t)b * ho + I) * wo + J) * cout + co] = bias ? acc + bias[co] : acc;
+                }
+            }
+    free(col);
+    free(wp);
+}
+
 /* tfuls.gdn (tfutils.py:393-397) / tfuls.inverse_gdn (tfutils.py:505-509) on rows of c channels:
  *   d[c] = (sum_k x[k]^2 * gamma[k][c]) + beta[c];  gdn: x[c] / sqrt(d[c]);  igdn: x[c] * sqrt(d[c]).
  * `matmul(x**2, gamma)` then `+ beta`, then sqrt, then divide / multiply -- in that order, float32. */

@@ -39,12 +39,16 @@ def test_conv2d_same_against_float64_definition(k, s, cin, shape):
     assert numpy.all(numpy.abs(got - ref.permute(0, 2, 3, 1).numpy()) <= REL*bound + ABS)
 
 
-@pytest.mark.parametrize('k,s,cout,shape', [(5, 2, 128, (2, 8, 12)), (9, 4, 1, (1, 8, 12)), (5, 2, 128, (1, 3, 5))])
-def test_conv2d_transpose_is_the_gradient_of_the_forward_conv(k, s, cout, shape):
+@pytest.mark.parametrize('col2im', [False, True])
+@pytest.mark.parametrize('k,s,cout,shape', [(5, 2, 128, (2, 8, 12)), (9, 4, 1, (1, 8, 12)), (5, 2, 128, (1, 3, 5)), (9, 4, 1, (2, 1, 1)),
+                                            (9, 4, 1, (1, 3, 17))])
+def test_conv2d_transpose_is_the_gradient_of_the_forward_conv(k, s, cout, shape, col2im):
+    """Both summation orders of the restatement (one chain per output element; GEMM + col2im, the order of transpose_conv_3)
+    against the float64 definition."""
     rng = numpy.random.RandomState(k*s)
     x = rng.standard_normal(size=shape + (128,)).astype(numpy.float32)
     w = (rng.standard_normal(size=(k, k, cout, 128))*0.05).astype(numpy.float32)      # [k, k, out, in]
-    got = T.conv2d_transpose_same(x, w, s, None)
+    got = T.conv2d_transpose_same(x, w, s, None, col2im=col2im)
     (h, wd) = (shape[1]*s, shape[2]*s)
     inp = torch.zeros(shape[0], cout, h, wd, dtype=torch.double, requires_grad=True)
     pad = k - s   # (out-1)*s + k - s*out

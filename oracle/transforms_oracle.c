@@ -132,7 +132,10 @@ void orc_conv2d_transpose_same(const float* x, int n, int h, int w, int cin, con
  * patches added into the image site by site). Used for transpose_conv_3 (components.py:79-83: 9x9, stride 4, 128 -> 1),
  * where the fused single chain above forces 7 of every 16 matrix-unit products of the gfx950 kernel to be structural
  * zeros (round 6):
- *     part[p][q][u][v][co] = one fmaf chain over ci = 0 .. cin-1 ascending, started from +0
+ *     part[p][q][u][v][co] = one fmaf chain over the cin channels, started from +0; the channels of each block of 16 in the order
+ *                            0 4 8 12 1 5 9 13 2 6 10 14 3 7 11 15 -- the order in which a matrix unit whose four operand rows are
+ *                            fed by 16-byte loads (four consecutive channels per row) takes them; any channels beyond the last
+ *                            whole block of 16 ascending
  *     y[I][J][co]          = (((+0 + part(first site)) + part(next site)) + ...)   plain float additions, the
  *                            contributing sites (p, q) in raster order: p ascending, then q ascending
  *                            (u = I + pb - s p and v = J + pb - s q therefore descending), bias added last.
@@ -156,7 +159,10 @@ void orc_conv2d_transpose_same_col2im(const float* x, int n, int h, int w, int c
                 const float* xp = x + (((size_t)b * h + p) * w + q) * cin;
                 float* cp = col + (((size_t)b * h + p) * w + q) * kc;
                 for (int t = 0; t < kc; ++t) cp[t] = 0.f;
-                for (int ci = 0; ci < cin; ++ci) {
+                for (int step = 0; step < cin; ++step) {
+                    /* block of 16: step 4 e + r of the block is channel 4 r + e */
+                    const int in_block = step & 15;
+                    const int ci = (step & ~15) + 16 <= cin ? (step & ~15) + 4 * (in_block & 3) + (in_block >> 2) : step;
                     const float xv = xp[ci];
                     const float* wrow = wp + (size_t)ci * kc;
                     for (int t = 0; t < kc; ++t) cp[t] = fmaf(xv, wrow[t], cp[t]);

@@ -24,14 +24,15 @@ dev.tconv9x9s4_luma(x, wph, want_f32=False, want_u8=True, ref_u8=ref, sse=sse)
 b.record()
 torch.cuda.synchronize()
 ms = a.elapsed_time(b)
-acc = sse[64:73].cpu().numpy().astype('float64')
+acc = sse[64:74].cpu().numpy().astype('float64')
 rows = n*H//4
 blocks = min(256, rows)
-chunks = acc[6]
-names = ['setup (filter, LDS zero, first sites)', 'prepare + tiles 0-1', 'barrier', 'parts written, LDS reads issued', 'tiles 2-3', 'tiles 4-5 + col2im + transpose']
+chunks = acc[9]
+names = ['setup (filter, LDS zero, first sites)', 'col2im finish of chunk - 2, next sites asked for', 'tiles 0-1', 'barrier',
+         'parts written, col2im of chunk - 1 requested', 'tiles 2-3, context', 'tiles 4-5']
 print('launch %.4f ms; %d blocks, %.1f chunks per block; ticks per block %.0f (longest %.0f) -> %.0f MHz' % (
     ms, blocks, chunks/blocks, acc[7]/blocks, acc[8], acc[8]/(ms*1e3)))
-print('  %-40s %9.0f ticks per block' % (names[0], acc[0]/blocks))
-for i in range(1, 6):
-    print('  %-40s %9.0f ticks per chunk' % (names[i], acc[i]/chunks))
-print('  sum per chunk %.0f; a chunk of a body row is 192 MFMAs = 6144 ticks' % (acc[1:6].sum()/chunks))
+print('  %-52s %9.0f ticks per block' % (names[0], acc[0]/blocks))
+for i in range(1, 7):
+    print('  %-52s %9.0f ticks per chunk' % (names[i], acc[i]/chunks))
+print('  sum per chunk %.0f; a chunk of a body row is 192 MFMAs = 6144 ticks' % (acc[1:7].sum()/chunks))

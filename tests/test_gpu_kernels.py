@@ -204,10 +204,11 @@ def test_tconv9x9s4_luma(T, dev, orc, shape, strips, launch_options):
 
 def test_tconv9x9s4_weight_fragments(T, dev):
     """The packed filter: position (rows of the kernel in the order 6 7 8 | 2 3 4 5 | one idle position | 0 1) x channel, as the
-    A fragments of six 16-position tiles."""
+    A fragments of six 16-position tiles, [tile][k-step][lane]: lane (kq, m) of k-step s holds position 16 tile + m of channel
+    16 (s // 4) + 4 kq + s % 4 (the order in which 16-byte loads hand the channels of a site to the matrix unit)."""
     w6 = numpy.random.RandomState(3).standard_normal(size=(9, 9, 1, 128)).astype(numpy.float32)
-    got = dev.pack_tconv9x9s4_weights(_cuda(T, w6)).cpu().numpy()          # [tile][k-step / 4][lane][4]
-    assert got.shape == (6, 8, 64, 4)
+    got = dev.pack_tconv9x9s4_weights(_cuda(T, w6)).cpu().numpy()
+    assert got.shape == (6, 32, 64)
     expect = numpy.zeros((96, 128), dtype=numpy.float32)
     rank = {6: 0, 7: 1, 8: 2, 2: 3, 3: 4, 4: 5, 5: 6, 0: 7, 1: 8}
     for u in range(9):
@@ -216,7 +217,7 @@ def test_tconv9x9s4_weight_fragments(T, dev):
     lane = numpy.arange(64)
     for t in range(6):
         for s in range(32):
-            assert numpy.array_equal(got[t, s//4, :, s % 4], expect[16*t + (lane & 15), 4*s + (lane >> 4)])
+            assert numpy.array_equal(got[t, s], expect[16*t + (lane & 15), 16*(s//4) + 4*(lane >> 4) + s % 4])
 
 
 @pytest.mark.parametrize('rows', [1, 127, 128, 1000, 32767, 32801])      # below 128 rows per CU: 32-row blocks (a 32-channel tile per wave); from there on 128-row blocks

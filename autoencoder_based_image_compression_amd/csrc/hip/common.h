@@ -25,7 +25,6 @@ struct EaeLaunchOptions {
     int split_wpb;      // EAE_HIP_SPLIT_WPB: 1 = one-wave blocks in the split conv GEMM (default: 4 waves per block)
     int split_mute;     // test hook, debug entry point only: heads of cut tiles never publish, tails give up after ~1 ms
     int assume_partitioned;   // EAE_HIP_ASSUME_PARTITIONED=1: behave as on a device that is not one whole MI355X (tests of the de-tuned path)
-    int t3_strips_per_cu;     // EAE_HIP_T3_STRIPS: strips of site rows per compute unit in transpose_conv_3 (default 1; tconv3.hip)
 };
 extern EaeLaunchOptions g_eae_launch_options;
 

@@ -31,9 +31,6 @@ static EaeLaunchOptions read_launch_options() {
     o.split_mute = 0;                                                      // never from the environment
     e = std::getenv("EAE_HIP_ASSUME_PARTITIONED");
     o.assume_partitioned = e && e[0] == '1' ? 1 : 0;
-    e = std::getenv("EAE_HIP_T3_STRIPS");
-    o.t3_strips_per_cu = e ? std::atoi(e) : 1;
-    if (o.t3_strips_per_cu < 1 || o.t3_strips_per_cu > 64) o.t3_strips_per_cu = 1;
     return o;
 }
 EaeLaunchOptions g_eae_launch_options = read_launch_options();

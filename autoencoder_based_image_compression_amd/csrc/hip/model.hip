@@ -23,7 +23,7 @@ struct eae_hip_model {
 namespace {
 
 constexpr size_t C = EAE_NB_MAPS;
-constexpr size_t W1 = 82 * C, W5x5 = 25 * C * C, GAMMA = C * C, VEC = C, W6 = EAE_HIP_TCONV9X9S4_PACKED_FLOATS;
+constexpr size_t W1 = 82 * C, W5x5 = 25 * C * C, GAMMA = C * C, VEC = C, W6 = 9 * C * 16;
 
 inline size_t align_up(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 

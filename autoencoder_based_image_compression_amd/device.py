@@ -300,8 +300,8 @@ def packed_channel_order():
 
 
 def pack_tconv9x9s4_weights(w_tf):
-    """[9,9,1,128] -> the matrix-unit fragments of the 81 taps, [6 tap tiles, 32 k-steps, 64 lanes] (include/eae_hip.h)."""
-    out = torch.empty((6, 32, 64), dtype=torch.float32, device=w_tf.device)
+    """[9,9,1,128] -> [9,128,16]."""
+    out = torch.empty((9, NB_MAPS, 16), dtype=torch.float32, device=w_tf.device)
     _check(_native.hip().eae_hip_pack_tconv9x9s4_weights(_p(w_tf), _p(out), _stream()), 'eae_hip_pack_tconv9x9s4_weights')
     return out
 

@@ -170,18 +170,14 @@ int eae_hip_tconv5x5s2_ws(const float* x, const float* w_packed, const float* bi
 
 /* transpose_conv_3 (components.py:79-83; 9x9, 128->1, stride 4, 'SAME', no bias) fused with what follows it on the
  * path: tls.cast_bt601 (tools.py:93: uint8(round_half_even(clip(x,16,235)))) and the squared error of tls.psnr_2d
- * (tools.py:873-875). Summation order (round 6): a GEMM + col2im -- one 128-channel fmaf chain per (input site, tap) (the
- * channels of each block of 16 in the order 0 4 8 12 1 5 9 13 ...), the <= 9 overlapping taps of an output pixel then added site
- * by site in raster order (oracle: orc_conv2d_transpose_same_col2im).
- * x: [N][h][w][128]; w_phase: EAE_HIP_TCONV9X9S4_PACKED_FLOATS floats from eae_hip_pack_tconv9x9s4_weights;
+ * (tools.py:873-875). x: [N][h][w][128]; w_phase: 18432 floats from eae_hip_pack_tconv9x9s4_weights;
  * out_f32 (nullable): [N][4h][4w] float reconstruction; out_u8 (nullable): [N][4h][4w] BT.601 cast;
  * ref_u8 + sse (both nullable): sse[i] += sum over image i of (ref - out_u8)^2, exact uint64 (caller zeroes). */
 int eae_hip_tconv9x9s4_luma(const float* x, const float* w_phase, float* out_f32, uint8_t* out_u8,
                             const uint8_t* ref_u8, uint64_t* sse, int n, int h, int w_in, void* stream);
 
-/* TF filter [9][9][1][128] -> the matrix-unit fragments of the 81 taps: [6 tap tiles][32 k-steps][64 lanes]
- * (zeros at the 15 positions of the 96 no tap has). */
-#define EAE_HIP_TCONV9X9S4_PACKED_FLOATS 12288
+/* TF filter [9][9][1][128] -> per-lane MFMA fragments [4 channel blocks][9 neighbours][64 lanes][8] (zeros where an
+ * output phase has no tap). */
 int eae_hip_pack_tconv9x9s4_weights(const float* w_tf, float* w_phase, void* stream);
 
 /* Kernel-side layouts, packed once per model on the device. "Packed" channel order: out channel c sits at position

@@ -101,9 +101,12 @@ DECODER_LAYERS = (
 )
 
 
-# The layer whose summation order is that of a GEMM + col2im implementation (round 6: the 9x9 stride-4 synthesis layer, where a
-# single chain per output pixel costs the gfx950 kernel 7 structural zeros in every 16 products; transforms_oracle.c).
-COL2IM_ORDER_LAYERS = frozenset(['decoder/weights_6'])
+# Layers whose summation order is that of a GEMM + col2im implementation: none. Round 6 built transpose_conv_3 that way (the single
+# chain per output pixel costs the gfx950 kernel 7 structural zeros in every 16 products), bit for bit against
+# orc_conv2d_transpose_same_col2im, measured it and kept the round-5 kernel and order (the kernel and its logs:
+# scratch/r06/, profiles/r06_tconv3_*); the restatement of that order stays here, checked against the float64 definition
+# (tests/test_oracle_transforms.py), for whoever takes it up again.
+COL2IM_ORDER_LAYERS = frozenset()
 
 
 def layers_of(table, are_bin_widths_learned):

@@ -24,15 +24,13 @@ dev.tconv9x9s4_luma(x, wph, want_f32=False, want_u8=True, ref_u8=ref, sse=sse)
 b.record()
 torch.cuda.synchronize()
 ms = a.elapsed_time(b)
-acc = sse[64:74].cpu().numpy().astype('float64')
+acc = sse[64:98].cpu().numpy().astype('float64')
 rows = n*H//4
 blocks = min(256, rows)
-chunks = acc[9]
-names = ['setup (filter, LDS zero, first sites)', 'col2im finish of chunk - 2, next sites asked for', 'tiles 0-1', 'barrier',
-         'parts written, col2im of chunk - 1 requested', 'tiles 2-3, context', 'tiles 4-5']
-print('launch %.4f ms; %d blocks, %.1f chunks per block; ticks per block %.0f (longest %.0f) -> %.0f MHz' % (
-    ms, blocks, chunks/blocks, acc[7]/blocks, acc[8], acc[8]/(ms*1e3)))
-print('  %-52s %9.0f ticks per block' % (names[0], acc[0]/blocks))
-for i in range(1, 7):
-    print('  %-52s %9.0f ticks per chunk' % (names[i], acc[i]/chunks))
-print('  sum per chunk %.0f; a chunk of a body row is 192 MFMAs = 6144 ticks' % (acc[1:7].sum()/chunks))
+chunks = acc[33]
+(a0, a1) = (acc[0:8]/4, acc[16:24]/4)                    # per wave of each half
+print('launch %.4f ms; %d blocks, %.1f chunks per block; longest wave %.0f ticks -> %.0f MHz' % (ms, blocks, chunks/blocks, acc[32], acc[32]/(ms*1e3)))
+print('  setup (filter, LDS zero, first sites): %.0f / %.0f ticks per block' % (a0[0]/blocks, a1[0]/blocks))
+print('  waves 0-3: barrier %.0f, col2im etc. %.0f, MFMAs + parts + next sites %.0f ticks per chunk' % (a0[1]/chunks, a0[2]/chunks, a0[3]/chunks))
+print('  waves 4-7: barrier %.0f, MFMAs + parts + next sites %.0f ticks per chunk' % (a1[1]/chunks, a1[4]/chunks))
+print('  per chunk %.0f / %.0f; a chunk of a body row is 192 MFMAs = 6144 ticks on its SIMD' % (a0[1:4].sum()/chunks, (a1[1] + a1[4])/chunks))

@@ -34,7 +34,7 @@ class _LaunchOptions(object):
     test that changes them inside the process has the library read them again (eae_hip_debug_reload_launch_options); the
     hand-off fault injection has no environment variable at all (eae_hip_debug_set_split_mute)."""
     NAMES = ('EAE_HIP_GEMM', 'EAE_HIP_SPLIT_WAVES', 'EAE_HIP_SPLIT_WPB', 'EAE_HIP_FORCE_TILE', 'EAE_HIP_FORCE_NT', 'EAE_HIP_LATENT', 'EAE_HIP_LATENT_LDS',
-             'EAE_HIP_ASSUME_PARTITIONED', 'EAE_HIP_PACK', 'EAE_HIP_T3_STRIPS')
+             'EAE_HIP_ASSUME_PARTITIONED', 'EAE_HIP_PACK')
 
     def __init__(self, monkeypatch):
         from autoencoder_based_image_compression_amd import _native

@@ -50,6 +50,8 @@ _POLL_SECONDS = float(os.environ.get('EAE_WORKER_POLL_SECONDS', '0.0002'))
 # own CPU 0.7-0.9 ms per 3.0 ms step either way, and the 2.85 ms per step the HIP runtime's signal thread spends in
 # kfd_wait_on_events (system time) does NOT move: it does not come from the host's events.
 _WAIT_MODE = os.environ.get('EAE_WORKER_WAIT', 'sequence')
+if _WAIT_MODE not in ('sequence', 'events'):
+    raise ValueError('EAE_WORKER_WAIT={0!r}: expected "sequence" or "events"'.format(_WAIT_MODE))
 # Where a batch's coder work starts. The coder's first kernel is wide (binarise: one wavefront per map, 3,048 of them for 24 Kodak
 # images) and, launched the moment the symbols exist, runs exactly while transpose_conv_1 does -- the shortest of the conv GEMM
 # launches, which it stretched from 0.29 to 0.34 ms. '1': the coder stream waits for transpose_conv_1 instead (its wide pass then
@@ -145,6 +147,10 @@ class Ticket(object):
         return self._values
 
 
+class StepTimeout(RuntimeError):
+    """The device did not report a submitted step within EAE_WORKER_SEQUENCE_TIMEOUT_SECONDS: the codec is unusable from here on."""
+
+
 class _Worker(threading.Thread):
     def __init__(self, map_size, nb_maps, host_probabilities, idx_map_exception, host_threads):
         super(_Worker, self).__init__(daemon=True)
@@ -165,13 +171,16 @@ class _Worker(threading.Thread):
 
     _typical_wait = 0.      # seconds this thread lately had to wait per job (a running mean): `_wait_sequence` sleeps through most of it
     _alone = 0              # consecutive jobs that found nothing queued behind them (one step at a time)
+    failed = None           # StepTimeout: the device stopped reporting; the codec refuses further work (BatchCodec.submit)
+    _sleep = staticmethod(time.sleep)          # (a test drives `_wait_sequence` with a clock of its own: tests/test_host_logic.py)
+    _now = staticmethod(time.monotonic)
 
     def _wait_sequence(self, words, expected):
         """Until the step counters the device leaves in pinned memory (`words`: numpy int32 view) have reached `expected`. Every
         sleep is a system call and a wake-up of this thread (a fifth of its time per step at twelve polls a step): the first sleep
         is three quarters of what the wait has lately been, the polls come after it."""
         deadline = None
-        started = time.monotonic()
+        started = self._now()
         # (only in a steady regime -- more jobs queued behind this one, or one job at a time for a while: the last batches of a pipelined
         # run have the GPU to themselves and come back sooner than the mean says, and sleeping through that cost 20-step blocks 3 %:
         # 2,990 against 3,080 Mpx/s)
@@ -182,14 +191,15 @@ class _Worker(threading.Thread):
         poll = 0.5*_SEQUENCE_POLL_SECONDS if self._alone >= 4 else _SEQUENCE_POLL_SECONDS      # one step at a time: the caller is waiting for this
         for (index, value) in enumerate(expected):
             while ((int(words[index]) - value) & 0xFFFFFFFF) >= 0x80000000:      # words[index] < value, wrap-around safe
-                time.sleep(max(first, poll))
+                self._sleep(max(first, poll))
                 first = 0.
                 if deadline is None:
-                    deadline = time.monotonic() + _SEQUENCE_TIMEOUT_SECONDS
-                elif time.monotonic() > deadline:
-                    raise RuntimeError('the device has not reported step {0} of this slot after {1:.0f} s (step counter at {2})'.format(
-                        value, _SEQUENCE_TIMEOUT_SECONDS, int(words[index])))
-        waited = min(time.monotonic() - started, 0.05)
+                    deadline = self._now() + _SEQUENCE_TIMEOUT_SECONDS
+                elif self._now() > deadline:
+                    raise StepTimeout('the device has not reported step {0} of this slot after {1:.0f} s (step counter at {2}): the slot\'s '
+                                      'buffers may still be written to, so this codec takes no further batches -- close it'.format(
+                                          value, _SEQUENCE_TIMEOUT_SECONDS, int(words[index])))
+        waited = min(self._now() - started, 0.05)
         if queued >= 2 or self._alone >= 3:      # (a regime change shows in the mean after a few jobs: `first` is a lower bound by then)
             self._typical_wait = waited if self._alone == 3 else self._typical_wait + 0.25*(waited - self._typical_wait)
         elif self._typical_wait == 0.:
@@ -252,6 +262,9 @@ class _Worker(threading.Thread):
                 ticket._values = {'nb_bits': coder_bits + exception_bits, 'coder_bits': coder_bits,
                                   'exception_bits': exception_bits, 'sse': sse.astype(numpy.int64).copy(),
                                   'nb_deads': (flags == 0).sum(axis=1).astype(numpy.int64)}
+            except StepTimeout as exc:    # nothing says the device is through with this slot: no later submit may reuse it
+                self.failed = exc
+                ticket._error = exc
             except Exception as exc:      # surfaced by Ticket.result()
                 ticket._error = exc
             finally:
@@ -295,6 +308,36 @@ def product_mode(h_in, w_in):
     the map size. `BatchCodec(..., **codec.product_mode(h, w))`; the constructor's own defaults are the conservative ones (every
     launch on the caller's stream, kernel by kernel: what the per-launch hooks and the roofline leg need)."""
     return {'nb_in_flight': default_nb_in_flight(h_in, w_in), 'nb_transform_streams': PRODUCT_TRANSFORM_STREAMS, 'use_graphs': True}
+
+
+_BUDGET_WARNED = [False]
+
+
+def stream_budget(nb_transform_streams, nb_in_flight, hw_queues=None, copies=0):
+    """Caps a codec's busy streams to the hardware queues the process has: -> (nb_transform_streams, nb_in_flight, message or None).
+
+    The HIP runtime gives a process GPU_MAX_HW_QUEUES hardware queues (4 unless the variable says otherwise; the package sets 16 at
+    import when it still can: `__init__._configure_hw_queues`); streams beyond that share queues, busy ones with busy ones, which was
+    measured to cost the product mode up to 30 %. One queue is left to the caller's own stream, `copies` to the feed / fetch streams.
+    Coder streams (batches in flight) go first, down to two; then the transform streams, down to one; then the coder streams again."""
+    if hw_queues is None:
+        from autoencoder_based_image_compression_amd import HW_QUEUES
+        hw_queues = HW_QUEUES[0]
+    (nt, nf) = (max(1, int(nb_transform_streams)), max(1, int(nb_in_flight)))
+    budget = max(2, int(hw_queues) - 1 - int(copies))
+    (nt0, nf0) = (nt, nf)
+    while nt + nf > budget and nf > 2:
+        nf -= 1
+    while nt + nf > budget and nt > 1:
+        nt -= 1
+    while nt + nf > budget and nf > 1:
+        nf -= 1
+    message = None
+    if (nt, nf) != (nt0, nf0):
+        message = ('BatchCodec: {0} transform + {1} coder streams asked for, but this process has {2} hardware queues (GPU_MAX_HW_QUEUES; '
+                   'streams beyond them share queues and serialise): running {3} + {4}. Set GPU_MAX_HW_QUEUES=16 in the environment before '
+                   'the first GPU call, or import this package before anything initialises the GPU.'.format(nt0, nf0, hw_queues, nt, nf))
+    return (nt, nf, message)
 
 
 class BatchCodec(object):
@@ -387,7 +430,16 @@ class BatchCodec(object):
         assert nb_words % 2 == 0
         if nb_in_flight is None:
             nb_in_flight = default_nb_in_flight(h_in, w_in)
+        if coder == 'device' and not one_stream_steps and os.environ.get('EAE_IGNORE_HW_QUEUES') != '1':
+            # no more busy streams than the process has hardware queues (said once; EAE_IGNORE_HW_QUEUES=1: the experiments' switch)
+            (nb_transform_streams, nb_in_flight, message) = stream_budget(nb_transform_streams, nb_in_flight,
+                                                                          copies=1 if fetch_reconstruction else 0)
+            if message is not None and not _BUDGET_WARNED[0]:
+                _BUDGET_WARNED[0] = True
+                import warnings
+                warnings.warn(message, RuntimeWarning, stacklevel=2)
         self.nb_in_flight = nb_in_flight
+        self.nb_transform_streams = nb_transform_streams
         self.nb_slots = nb_in_flight + 2
         nb_private = nb_transform_streams if (nb_transform_streams > 1 or use_graphs) else 0      # replays never go to the caller's stream
         if self.one_stream_steps:
@@ -467,6 +519,8 @@ class BatchCodec(object):
             raise TypeError('`luminances_uint8.dtype` is not equal to `torch.uint8`.')
         if tuple(luminances_uint8.shape) != (self.batch_size, self.h_in, self.w_in):
             raise ValueError('`luminances_uint8.shape` is not (batch_size, h_in, w_in).')
+        if self._worker.failed is not None:
+            raise StepTimeout('this codec stopped taking batches: {0}'.format(self._worker.failed))
         host = luminances_uint8.device.type == 'cpu'
         if host and not luminances_uint8.is_pinned():
             raise ValueError('a host batch must be in pinned memory (`torch.Tensor.pin_memory()`): its copy is asynchronous.')

@@ -149,6 +149,10 @@ class Model(object):
         latents = out if out is not None else torch.empty((n, h//16, wd//16, NB_MAPS), dtype=torch.float32, device=images_u8.device)
         if latents.dtype != torch.float32 or tuple(latents.shape) != (n, h//16, wd//16, NB_MAPS):
             raise HipError('`out` must be float32 of shape (N, H/16, W/16, 128)')
+        if not latents.is_contiguous() or latents.device != self.device:
+            # the kernels get a raw pointer and write N x h x w x 128 floats flat behind it
+            raise HipError('`out` must be a contiguous tensor on {0} (got {1}, {2})'.format(
+                self.device, 'contiguous' if latents.is_contiguous() else 'non-contiguous', latents.device))
         _check(_native.hip().eae_hip_encode(self._handle, _p(images_u8), n, h, wd, _p(latents), _p(scratch), nbytes, _stream(images_u8)),
                'eae_hip_encode')
         self._track(scratch)
@@ -168,6 +172,9 @@ class Model(object):
         out_f32 = torch.empty((n, 16*h, 16*wd), dtype=torch.float32, device=d) if want_f32 else None
         if out_u8 is not None and (out_u8.dtype != torch.uint8 or out_u8.numel() != n*16*h*16*wd):
             raise HipError('`out_u8` must hold N x 16h x 16w uint8 elements')
+        if out_u8 is not None and (not out_u8.is_contiguous() or out_u8.device != self.device):
+            raise HipError('`out_u8` must be a contiguous tensor on {0} (got {1}, {2})'.format(
+                self.device, 'contiguous' if out_u8.is_contiguous() else 'non-contiguous', out_u8.device))
         if out_u8 is None:
             out_u8 = torch.empty((n, 16*h, 16*wd), dtype=torch.uint8, device=d) if want_u8 else None
         if ref_u8 is not None and sse is None:

@@ -71,3 +71,24 @@ def test_bad_inputs_are_refused(tmp_path, bench):
     (_, _, stats) = _files(tmp_path, bench)
     with pytest.raises(IOError):      # the directory holds the table of multiplier 1.25 only
         bench.load_inputs(bench.parse_args(['--stats-dir', stats, '--bin-width', '2.0']))
+
+
+def test_the_exception_index_file_is_read_as_an_integer_and_nothing_else(tmp_path, bench):
+    """`idx_map_exception.pkl` comes from a directory the caller names: a pickle that asks for any class or function is refused
+    before anything is looked up, and so is one that holds something other than an integer."""
+    import pickle
+    good = tmp_path/'good.pkl'
+    good.write_bytes(pickle.dumps(67, protocol=2))
+    assert bench.load_pickled_int(str(good)) == 67
+    numpy_int = tmp_path/'numpy_int.pkl'
+    numpy_int.write_bytes(pickle.dumps(numpy.int64(5), protocol=2))           # needs numpy's reconstructor: refused
+    with pytest.raises(pickle.UnpicklingError):
+        bench.load_pickled_int(str(numpy_int))
+    evil = tmp_path/'evil.pkl'
+    evil.write_bytes(b"cos\nsystem\n(S'echo pwned > /dev/null'\ntR.")
+    with pytest.raises(pickle.UnpicklingError):
+        bench.load_pickled_int(str(evil))
+    text = tmp_path/'text.pkl'
+    text.write_bytes(pickle.dumps('67', protocol=2))
+    with pytest.raises(SystemExit):
+        bench.load_pickled_int(str(text))

@@ -220,12 +220,17 @@ def test_graph_capture_with_one_transform_stream_at_kodak_size():
             assert numpy.array_equal(r['nb_bits'], expected['nb_bits']) and numpy.array_equal(r['sse'], expected['sse'])
 
 
+@pytest.mark.parametrize('wait_mode', ['sequence', 'events'])
 @pytest.mark.parametrize('graphs', [False, True])
-def test_a_failed_submit_does_not_hang_the_codec(graphs, monkeypatch):
+def test_a_failed_submit_does_not_hang_the_codec(graphs, wait_mode, monkeypatch):
     """A launch that raises in the middle of `submit` must surface as that exception: the slot it had taken is given back, so
     leaving the `with` block (close -> drain) returns instead of waiting for a result nobody will post, and the codec goes on
-    working (round 2: a failed graph capture showed up as a bench run that sat in drain() for its whole time limit)."""
+    working (round 2: a failed graph capture showed up as a bench run that sat in drain() for its whole time limit) -- every slot
+    of it, the one whose step was cut short included (`_resync`: its step counters read back, its ticket words and accumulators
+    zeroed again), whichever way the result worker learns that a step is through (EAE_WORKER_WAIT: the step counter in pinned
+    memory, or the events of rounds 3-4)."""
     from autoencoder_based_image_compression_amd import codec
+    monkeypatch.setattr(codec, '_WAIT_MODE', wait_mode)
     from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
     with numpy.load(GOLD) as g:
         probabilities = g['real_probabilities_1']
@@ -259,8 +264,12 @@ def test_a_failed_submit_does_not_hang_the_codec(graphs, monkeypatch):
             monkeypatch.undo()
         c._launch_coder = real
         torch.cuda.synchronize()
-        again = c.submit(images).result()
-        assert numpy.array_equal(again['nb_bits'], good['nb_bits'])
+        # twice round the slots, several in flight: same bits, same squared errors, same dead maps every time
+        tickets = [c.submit(images) for _ in range(2*c.nb_slots)]
+        for ticket in tickets:
+            again = ticket.result()
+            for key in ('nb_bits', 'sse', 'nb_deads'):
+                assert numpy.array_equal(again[key], good[key]), key
 
 
 @pytest.mark.parametrize('learned', [False, True])

@@ -106,3 +106,28 @@ def test_one_sided_and_incomplete_models():
     assert lib.eae_hip_model_create(ctypes.cast(pointers, ctypes.c_void_p), 0, ctypes.byref(handle)) == -1
     assert lib.eae_hip_model_create(None, 0, ctypes.byref(handle)) == -1
     lib.eae_hip_model_destroy(None)                           # like free(NULL)
+
+
+def test_the_out_arguments_must_be_contiguous_and_on_the_model_s_device():
+    """`Model.encode(out=)` / `Model.decode(out_u8=)` hand a raw pointer to the kernels, which write flat behind it: a strided view or
+    a tensor somewhere else is refused instead of being written through."""
+    import torch
+    from autoencoder_based_image_compression_amd import device as dev
+    from autoencoder_based_image_compression_amd.kodak.eae.graph import variables as var
+    v = var.random_variables(1., False, seed=3, bias_std=0.01)
+    model = dev.Model(v, False)
+    images = torch.randint(16, 236, (2, 32, 48), dtype=torch.uint8, device='cuda')
+    whole = torch.empty((2, 2, 3, 256), dtype=torch.float32, device='cuda')
+    with pytest.raises(dev.HipError, match='contiguous'):
+        model.encode(images, out=whole[..., ::2])                      # right shape and dtype, every other channel
+    with pytest.raises(dev.HipError, match='contiguous'):
+        model.encode(images, out=torch.empty((2, 2, 3, 128), dtype=torch.float32))      # host memory
+    latents = model.encode(images, out=torch.empty((2, 2, 3, 128), dtype=torch.float32, device='cuda'))
+    wide = torch.empty((2, 32, 96), dtype=torch.uint8, device='cuda')
+    with pytest.raises(dev.HipError, match='contiguous'):
+        model.decode(latents, out_u8=wide[:, :, ::2])
+    with pytest.raises(dev.HipError, match='contiguous'):
+        model.decode(latents, out_u8=torch.empty((2, 32, 48), dtype=torch.uint8))
+    (_, rec, _) = model.decode(latents, out_u8=torch.empty((2, 32, 48), dtype=torch.uint8, device='cuda'))
+    assert numpy.array_equal(rec.cpu().numpy(), model.decode(latents)[1].cpu().numpy())
+    model.close()

@@ -328,3 +328,123 @@ def test_numpy_mean_over_leading_axes_is_a_row_by_row_float32_sum():
         for row in rows:
             acc = acc + row
         assert numpy.array_equal(numpy.mean(y, axis=(0, 1, 2)), acc/numpy.float32(rows.shape[0]))
+
+
+def test_the_package_asks_for_its_hardware_queues_when_it_still_can():
+    """GPU_MAX_HW_QUEUES: the caller's value wins; the package sets 16 while no HIP call has been made; too late otherwise."""
+    import autoencoder_based_image_compression_amd as package
+    env = {}
+    assert package._configure_hw_queues(env, runtime_is_up=False) == (16, 'package') and env['GPU_MAX_HW_QUEUES'] == '16'
+    env = {'GPU_MAX_HW_QUEUES': '8'}
+    assert package._configure_hw_queues(env, runtime_is_up=False) == (8, 'caller') and env['GPU_MAX_HW_QUEUES'] == '8'
+    assert package._configure_hw_queues({'GPU_MAX_HW_QUEUES': '24'}, runtime_is_up=True) == (24, 'caller')
+    env = {}
+    assert package._configure_hw_queues(env, runtime_is_up=True) == (4, 'runtime default') and 'GPU_MAX_HW_QUEUES' not in env
+    assert package._configure_hw_queues({'GPU_MAX_HW_QUEUES': 'many'}, runtime_is_up=False) == (4, 'caller')
+    assert package.HW_QUEUES[0] >= 1 and package.HW_QUEUES[1] in ('caller', 'package', 'runtime default')
+
+
+def test_a_codec_keeps_no_more_busy_streams_than_the_process_has_hardware_queues():
+    from autoencoder_based_image_compression_amd import codec
+    # the product mode on the queues the package asks for: untouched, nothing to say
+    assert codec.stream_budget(3, 6, hw_queues=16) == (3, 6, None)
+    assert codec.stream_budget(3, 8, hw_queues=16, copies=1) == (3, 8, None)
+    # four queues (the runtime's default): coder streams go first, down to two, then the transform streams
+    (nt, nf, message) = codec.stream_budget(3, 6, hw_queues=4)
+    assert (nt, nf) == (1, 2) and 'GPU_MAX_HW_QUEUES' in message and '3 transform + 6 coder' in message
+    assert codec.stream_budget(3, 6, hw_queues=8)[:2] == (3, 4)
+    assert codec.stream_budget(3, 6, hw_queues=6)[:2] == (3, 2)
+    assert codec.stream_budget(3, 6, hw_queues=5)[:2] == (2, 2)
+    assert codec.stream_budget(1, 3, hw_queues=4)[:2] == (1, 2)
+    assert codec.stream_budget(1, 1, hw_queues=1) == (1, 1, None)
+    for queues in range(1, 20):
+        for nt0 in range(1, 6):
+            for nf0 in range(1, 9):
+                (nt, nf, message) = codec.stream_budget(nt0, nf0, hw_queues=queues)
+                assert 1 <= nt <= nt0 and 1 <= nf <= nf0
+                assert nt + nf <= max(2, queues - 1) or (nt, nf) == (1, 1)
+                assert (message is None) == ((nt, nf) == (nt0, nf0))
+
+
+class _FakeQueue(object):
+    def __init__(self, size):
+        self.size = size
+
+    def qsize(self):
+        return self.size
+
+
+def _drive_wait(worker, queued, device_done_at, start):
+    """Runs `_wait_sequence` for one job on a clock of the test's own: the pinned step counter turns 1 once the clock has reached
+    `device_done_at`. Returns (the sleeps the worker took, the clock afterwards)."""
+    import numpy
+    clock = [start]
+    words = numpy.zeros(1, dtype=numpy.int32)
+    sleeps = []
+
+    def sleep(seconds):
+        sleeps.append(seconds)
+        clock[0] += seconds
+        if clock[0] >= device_done_at:
+            words[0] = 1
+
+    worker.jobs = _FakeQueue(queued)
+    worker._sleep = sleep
+    worker._now = lambda: clock[0]
+    if start >= device_done_at:
+        words[0] = 1
+    worker._wait_sequence(words, (1,))
+    return (sleeps, clock[0])
+
+
+def test_the_result_worker_sleeps_long_only_in_a_steady_regime():
+    """codec._Worker._wait_sequence: with jobs queued behind the one it waits for (a pipelined run) or one job at a time for a while
+    (a caller that waits for every result), the first sleep is three quarters of what the wait has lately been and short polls
+    follow; a job that finds nothing queued after a pipelined run (its last batches) is polled from the start."""
+    from autoencoder_based_image_compression_amd import codec
+    worker = codec._Worker(1536, 128, None, -1, 0)
+    poll = codec._SEQUENCE_POLL_SECONDS
+    # a pipelined run: two jobs queued behind each; every step takes 3 ms
+    t = 0.
+    (sleeps, t) = _drive_wait(worker, 2, t + 3e-3, t)
+    assert all(abs(s - poll) < 1e-12 for s in sleeps) and len(sleeps) >= 25          # nothing known yet: polls only
+    assert 0. < worker._typical_wait < 3.2e-3
+    for _ in range(16):                                                               # (the mean moves a quarter of the way per job)
+        (sleeps, t) = _drive_wait(worker, 2, t + 3e-3, t)
+    typical = worker._typical_wait
+    assert 2.8e-3 < typical < 3.3e-3
+    (sleeps, t) = _drive_wait(worker, 2, t + 3e-3, t)
+    assert abs(sleeps[0] - 0.75*typical) < 1e-9 and 2e-3 < sleeps[0] < 3e-3           # one long sleep ...
+    assert all(abs(s - poll) < 1e-12 for s in sleeps[1:]) and 1 <= len(sleeps) - 1 <= 12    # ... then a few polls
+    # the run's last batches: nothing queued behind them, and they come back sooner than the mean -- no long sleep through that
+    (sleeps, t) = _drive_wait(worker, 0, t + 1e-3, t)
+    assert all(abs(s - poll) < 1e-12 for s in sleeps) and 8 <= len(sleeps) <= 12
+    # one step at a time (the caller waits for each result): after a few such jobs the long sleep is back, with polls twice as dense
+    for _ in range(5):
+        (sleeps, t) = _drive_wait(worker, 0, t + 1e-3, t)
+    assert worker._alone >= 4
+    assert 0.5e-3 < sleeps[0] < 1e-3 and all(abs(s - 0.5*poll) < 1e-12 for s in sleeps[1:])
+    # a step that is through before the worker looks: no sleep at all
+    (sleeps, t) = _drive_wait(worker, 2, t, t)
+    assert sleeps == []
+
+
+def test_a_step_the_device_never_reports_fails_the_codec(monkeypatch):
+    """The sequence wait gives up after EAE_WORKER_SEQUENCE_TIMEOUT_SECONDS with StepTimeout (the codec then refuses further batches:
+    nothing says the device is through with the slot's buffers)."""
+    from autoencoder_based_image_compression_amd import codec
+    worker = codec._Worker(1536, 128, None, -1, 0)
+    monkeypatch.setattr(codec, '_SEQUENCE_TIMEOUT_SECONDS', 0.01)
+    with pytest.raises(codec.StepTimeout):
+        _drive_wait(worker, 0, 1e9, 0.)
+    assert issubclass(codec.StepTimeout, RuntimeError)
+
+
+def test_an_unknown_wait_mode_is_refused_at_import():
+    import subprocess
+    import sys
+    code = 'import autoencoder_based_image_compression_amd.codec'
+    env = dict(os.environ, EAE_WORKER_WAIT='evnets')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    done = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, cwd=root)
+    assert done.returncode != 0 and 'EAE_WORKER_WAIT' in done.stderr

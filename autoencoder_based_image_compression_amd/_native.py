@@ -31,7 +31,11 @@ def _load(name):
     if name == 'libeae_coder.so' and os.environ.get('EAE_CODER_LIB'):
         path = os.environ['EAE_CODER_LIB']      # e.g. the sanitizer build (`make -C csrc sanitize-test`); same ABI, same checks
     if name == 'libeae_hip.so' and os.environ.get('EAE_HIP_LIB'):
-        path = os.environ['EAE_HIP_LIB']        # an instrumented build of the same ABI (scratch/t3_trace.sh)
+        # another build of the same ABI: `test` = lib/libeae_hip_test.so (the whole test-suite on the test build), or a path
+        # (an instrumented build, scratch/t3_trace.sh)
+        path = os.environ['EAE_HIP_LIB']
+        if path == 'test':
+            path = os.path.join(LIB_DIR, 'libeae_hip_test.so')
     if not os.path.isfile(path):
         raise NativeLibraryMissing(
             '{0} not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` '
@@ -42,6 +46,7 @@ def _load(name):
 _lock = threading.Lock()
 _coder = None
 _hip = None
+_hip_test = None
 
 # name -> (restype, argtypes); every symbol include/eae_coder.h declares.
 CODER_SYMBOLS = {
@@ -83,8 +88,10 @@ CODER_SYMBOLS = {
 }
 
 
-def _bind(lib, table):
+def _bind(lib, table, optional=False):
     for name, (restype, argtypes) in table.items():
+        if optional and not hasattr(lib, name):
+            continue
         f = getattr(lib, name)  # AttributeError if the symbol is not exported
         f.restype = restype
         f.argtypes = argtypes
@@ -107,9 +114,32 @@ def hip():
     if _hip is None:
         with _lock:
             if _hip is None:
-                from ._native_hip import HIP_SYMBOLS
-                _hip = _bind(_load('libeae_hip.so'), HIP_SYMBOLS)
+                from ._native_hip import EXPERIMENTAL_CODER_SYMBOLS, HIP_SYMBOLS, TEST_HOOK_SYMBOLS
+                lib = _bind(_load('libeae_hip.so'), HIP_SYMBOLS)
+                # the product library has neither section; a build named by EAE_HIP_LIB may
+                _bind(lib, EXPERIMENTAL_CODER_SYMBOLS, optional=True)
+                _hip = _bind(lib, TEST_HOOK_SYMBOLS, optional=True)
     return _hip
+
+
+def hip_test():
+    """lib/libeae_hip_test.so: the product's sources compiled with -DEAE_TEST_HOOKS -DEAE_EXPERIMENTAL_CODER (csrc/Makefile). For
+    tests (tests/conftest.py: the fixtures `launch_options` and `test_library` make it what `hip()` returns while a test that needs
+    the hooks or the experimental coder runs); the package itself never calls this."""
+    global _hip_test
+    if _hip_test is None:
+        with _lock:
+            if _hip_test is None:
+                from ._native_hip import EXPERIMENTAL_CODER_SYMBOLS, HIP_SYMBOLS, TEST_HOOK_SYMBOLS
+                lib = _bind(_load('libeae_hip_test.so'), HIP_SYMBOLS)
+                _bind(lib, EXPERIMENTAL_CODER_SYMBOLS)
+                _hip_test = _bind(lib, TEST_HOOK_SYMBOLS)
+    return _hip_test
+
+
+def has_experimental_coder():
+    """Whether the library `hip()` returns holds the experimental coder round trips (include/eae_hip.h)."""
+    return hasattr(hip(), 'eae_hip_coder_roundtrip_trailing')
 
 
 def ptr(array, ctype_pointer):

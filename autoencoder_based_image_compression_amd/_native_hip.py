@@ -1,4 +1,6 @@
-"""Prototypes of every symbol include/eae_hip.h declares (bound by `_native.hip()`)."""
+"""Prototypes of every symbol include/eae_hip.h declares: HIP_SYMBOLS is the product (lib/libeae_hip.so exports exactly these,
+bound by `_native.hip()`); EXPERIMENTAL_CODER_SYMBOLS and TEST_HOOK_SYMBOLS are the header's two conditional sections, compiled
+into lib/libeae_hip_test.so only (`_native.hip_test()`)."""
 import ctypes
 
 _vp = ctypes.c_void_p
@@ -50,11 +52,6 @@ HIP_SYMBOLS = {
                                         _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp]),
     'eae_hip_coder_decode_batch': (_i, [ctypes.c_uint32, ctypes.c_uint32, _vp, _vp, ctypes.c_uint8, _vp, _vp, _vp, ctypes.c_uint64,
                                         _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp]),
-    'eae_hip_coder_trailing_workspace_bytes': (ctypes.c_uint64, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint8]),
-    'eae_hip_coder_roundtrip_trailing': (_i, [ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_uint8, _vp, _vp, _vp, ctypes.c_uint64,
-                                              _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint32, _vp]),
-    'eae_hip_coder_roundtrip_fused': (_i, [ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_uint8, _vp, _vp, _vp, ctypes.c_uint64,
-                                           _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp]),
     'eae_hip_map_minmax': (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     'eae_hip_floor_histograms': (_i, [_vp, _vp, _i, _vp, _i64, _i, _vp]),
     'eae_hip_coder_pack_streams': (_i, [ctypes.c_uint32, _vp, ctypes.c_uint64, _vp, _vp, _vp, _vp, _vp]),
@@ -65,10 +62,6 @@ HIP_SYMBOLS = {
     'eae_hip_rgb_to_ycbcr': (_i, [_vp, _vp, _vp, _i64, _vp]),
     'eae_hip_publish_to_host': (_i, [_vp, _vp, ctypes.c_uint64, _vp]),
     'eae_hip_symbol_histograms_strided': (_i, [_vp, _vp, _i, _vp, _i, _i, _i64, _i64, _vp]),
-    'eae_hip_debug_set_stamp_buffer': (_i, [_vp]),
-    'eae_hip_debug_reload_launch_options': (_i, []),
-    'eae_hip_debug_set_split_mute': (_i, [_i]),
-    'eae_hip_debug_check_mid_forms': (_i, [_i, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),
     'eae_hip_cast_bt601': (_i, [_vp, _vp, _i64, _vp]),
     'eae_hip_sse_u8': (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     'eae_hip_svhn_dense_f64': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -77,4 +70,21 @@ HIP_SYMBOLS = {
     'eae_hip_svhn_symbol_range': (_i, [_vp, _i64, _vp, _vp]),
     'eae_hip_svhn_symbol_histogram': (_i, [_vp, _i64, ctypes.c_int32, ctypes.c_int32, _vp, _vp, _vp]),
     'eae_hip_svhn_postprocess': (_i, [_vp, ctypes.c_double, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+}
+
+# include/eae_hip.h, #ifdef EAE_EXPERIMENTAL_CODER
+EXPERIMENTAL_CODER_SYMBOLS = {
+    'eae_hip_coder_trailing_workspace_bytes': (ctypes.c_uint64, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint8]),
+    'eae_hip_coder_roundtrip_trailing': (_i, [ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_uint8, _vp, _vp, _vp, ctypes.c_uint64,
+                                              _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_uint32, _vp]),
+    'eae_hip_coder_roundtrip_fused': (_i, [ctypes.c_uint32, ctypes.c_uint32, _vp, ctypes.c_uint8, _vp, _vp, _vp, ctypes.c_uint64,
+                                           _vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp]),
+}
+
+# include/eae_hip.h, #ifdef EAE_TEST_HOOKS
+TEST_HOOK_SYMBOLS = {
+    'eae_hip_debug_set_stamp_buffer': (_i, [_vp]),
+    'eae_hip_debug_reload_launch_options': (_i, []),
+    'eae_hip_debug_set_split_mute': (_i, [_i]),
+    'eae_hip_debug_check_mid_forms': (_i, [_i, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _vp, _vp]),
 }

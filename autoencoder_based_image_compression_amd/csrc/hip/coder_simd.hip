@@ -34,6 +34,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../coder/lean_step.h"
 #include "eae_hip.h"
 
@@ -832,6 +834,14 @@ __global__ __launch_bounds__(64) void compare_kernel(const SimdParams p) {
     if (__any(differ) && lane == 0) p.status[m] = MISMATCH;
 }
 
+// =====================================================================================================================
+// EXPERIMENTAL, not in the product library (round 6): everything between here and the matching #endif, and the two round-trip
+// entry points at the end of this file, is compiled only with -DEAE_EXPERIMENTAL_CODER (lib/libeae_hip_test.so, csrc/Makefile).
+// Both forms are byte-exact and both lose to the plain encode_batch + decode_batch pair on this runtime (numbers below and in
+// DESIGN.md section 5); they are kept, with their tests, as the measured record of why. The <CHUNKED = true> instances of the
+// kernels above exist only where eae_hip_coder_roundtrip_trailing instantiates them, i.e. in that build.
+// =====================================================================================================================
+#ifdef EAE_EXPERIMENTAL_CODER
 // ---------------------------------------------------------------------------------------------------------------------
 // (6) the three serial stages as ONE workgroup per 64 maps, pipelined through LDS: encoder core -> bit writer -> decoder core
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1282,6 +1292,8 @@ __global__ void pipe_restore_kernel(const SimdParams p) {
     if (m < p.n_maps && p.avail_bits[m] != 0u && p.status[m] == 0) p.status[m] = RETRY;
 }
 
+#endif  // EAE_EXPERIMENTAL_CODER
+
 // status 0 -> RETRY for the coded maps: hands every map that has not failed to the general kernel
 __global__ void mark_kernel(const SimdParams p) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1399,7 +1411,7 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
     return (int)hipGetLastError();
 }
 
-#ifndef EAE_DECODE_TOPUP_ZEROS
+#if defined(EAE_EXPERIMENTAL_CODER) && !defined(EAE_DECODE_TOPUP_ZEROS)
 // ---- the chunked round trip: decoder and emit pass trailing the encoder core ------------------------------------------------
 // For a batch of one or two images the coder is two to four wavefronts and its time is the LENGTH of its serial chains: binarise
 // -> encoder core -> emit -> decoder core -> debinarise, one after the other (0.72 ms of the 1.2 ms one Kodak image takes, of
@@ -1417,25 +1429,40 @@ namespace {
 struct TrailingStreams {
     hipStream_t emit = nullptr, decode = nullptr;
     hipEvent_t encoded[16] = {}, emitted[16] = {}, start = nullptr, done = nullptr;
+    bool complete = false;
 };
-// a few sets, handed out in turn: calls that overlap in time (one per batch in flight) then do not share their side streams
+// a few sets, handed out in turn: calls that overlap in time (one per batch in flight) then do not share their side streams.
+// Hand-out and first-use creation are under one mutex (callers on different threads, e.g. one per codec); a set whose creation
+// failed half way is never handed out (`complete`).
 TrailingStreams* trailing_streams() {
     static TrailingStreams sets[16][4];
     static unsigned next[16] = {0};
+    static std::mutex guard;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> hold(guard);
     TrailingStreams& t = sets[dev][next[dev]++ & 3u];
-    if (!t.emit) {
-        if (hipStreamCreateWithFlags(&t.emit, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipStreamCreateWithFlags(&t.decode, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (!t.complete) {
+        if (!t.emit && hipStreamCreateWithFlags(&t.emit, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (!t.decode && hipStreamCreateWithFlags(&t.decode, hipStreamNonBlocking) != hipSuccess) return nullptr;
         for (int i = 0; i < 16; i++) {
-            if (hipEventCreateWithFlags(&t.encoded[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-            if (hipEventCreateWithFlags(&t.emitted[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+            if (!t.encoded[i] && hipEventCreateWithFlags(&t.encoded[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+            if (!t.emitted[i] && hipEventCreateWithFlags(&t.emitted[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         }
-        if (hipEventCreateWithFlags(&t.start, hipEventDisableTiming) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (!t.start && hipEventCreateWithFlags(&t.start, hipEventDisableTiming) != hipSuccess) return nullptr;
+        if (!t.done && hipEventCreateWithFlags(&t.done, hipEventDisableTiming) != hipSuccess) return nullptr;
+        t.complete = true;
     }
     return &t;
+}
+// Whatever was put on the side streams, the caller's stream waits for it: also on the error returns, so that a caller who frees
+// or reuses the buffers behind a failed call does not race the launches that did go out.
+int trailing_join(TrailingStreams* t, hipStream_t s, int rc) {
+    (void)hipEventRecord(t->emitted[0], t->emit);
+    (void)hipStreamWaitEvent(t->decode, t->emitted[0], 0);
+    (void)hipEventRecord(t->done, t->decode);
+    (void)hipStreamWaitEvent(s, t->done, 0);
+    return rc;
 }
 }  // namespace
 
@@ -1500,7 +1527,7 @@ int eae_hip_coder_roundtrip_trailing(uint32_t n_maps, uint32_t map_size, const i
     // complete streams, the data-parallel rest of the decoder and the comparison: the tail of eae_hip_coder_decode_batch
     int rc = eae_coder_generic_encode(n_maps, map_size, symbols, L, probs, prob_row, streams, stride, bac_bits, bypass_bits, status, stage,
                                       RETRY, t->emit);
-    if (rc) return rc;
+    if (rc) return trailing_join(t, s, rc);
     (void)hipEventRecord(t->emitted[chunks - 1u], t->emit);
     (void)hipStreamWaitEvent(t->decode, t->emitted[chunks - 1u], 0);
     {
@@ -1511,7 +1538,7 @@ int eae_hip_coder_roundtrip_trailing(uint32_t n_maps, uint32_t map_size, const i
         hipLaunchKernelGGL(debinarise_kernel, per_map, wave, 0, t->decode, d);
         rc = eae_coder_generic_decode(n_maps, map_size, d.decoded, L, probs, prob_row, streams, stride, bac_bits, bypass_bits, status, stage,
                                       RETRY, t->decode);
-        if (rc) return rc;
+        if (rc) return trailing_join(t, s, rc);
         hipLaunchKernelGGL(compare_kernel, per_map, wave, 0, t->decode, d);
     }
     (void)hipEventRecord(t->done, t->decode);

@@ -681,11 +681,14 @@ __global__ void pack_rows_kernel(const float* __restrict__ src, float* __restric
 }
 }  // namespace
 
-// Diagnostic: when set (device pointer to grid * waves * 8 u64), the wave kernel records s_memtime stamps per wave.
+// Diagnostic (test build only, -DEAE_TEST_HOOKS): when set (device pointer to grid * waves * 8 u64), the wave kernel records
+// s_memtime stamps per wave. The product library has no way to set it: the pointer stays null there.
+#ifdef EAE_TEST_HOOKS
 extern "C" int eae_hip_debug_set_stamp_buffer(uint64_t* device_buffer) {
     g_stamp_buffer = reinterpret_cast<unsigned long long*>(device_buffer);
     return EAE_HIP_OK;
 }
+#endif
 
 // [5][5][ci][co] (HWIO) -> [25][ci][packed co]
 extern "C" int eae_hip_pack_conv_weights(const float* w_hwio, float* w_packed, int taps, void* stream) {

@@ -55,7 +55,8 @@ extern "C" int eae_hip_gdn(const float* x, const float* gamma, const float* beta
     return EAE_HIP_OK;
 }
 
-// ---- proof harness of common.h's sqrt_mid / div_mid (tests/test_gpu_kernels.py; not part of the path) ----------------------------
+// ---- proof harness of common.h's sqrt_mid / div_mid (tests/test_gpu_kernels.py; not part of the path: test build only) ----------
+#ifdef EAE_TEST_HOOKS
 namespace {
 __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {       // splitmix64
     z += 0x9E3779B97F4A7C15ull;
@@ -103,3 +104,4 @@ extern "C" int eae_hip_debug_check_mid_forms(int mode, uint64_t first, uint64_t 
     EAE_HIP_CHECK_LAUNCH();
     return EAE_HIP_OK;
 }
+#endif

@@ -7,8 +7,9 @@
 #include <cstring>
 
 // ---- kernel-form overrides: the environment is read here, once per library load (and on a test's explicit request) ----
-// g_eae_launch_options is a plain global: the two eae_hip_debug_* setters below are TEST HOOKS, to be called from the one thread
-// that launches, with nothing in flight (tests/conftest.py: launch_options); a deployment never calls them, so launches only read.
+// g_eae_launch_options is a plain global: the two eae_hip_debug_* setters below are TEST HOOKS, compiled only into the test build
+// (-DEAE_TEST_HOOKS: lib/libeae_hip_test.so, csrc/Makefile), to be called from the one thread that launches, with nothing in
+// flight (tests/conftest.py: launch_options); the product library does not hold them, so its launches only ever read.
 static EaeLaunchOptions read_launch_options() {
     EaeLaunchOptions o{};
     const char* e = std::getenv("EAE_HIP_GEMM");
@@ -35,6 +36,7 @@ static EaeLaunchOptions read_launch_options() {
 }
 EaeLaunchOptions g_eae_launch_options = read_launch_options();
 
+#ifdef EAE_TEST_HOOKS
 extern "C" int eae_hip_debug_reload_launch_options(void) {
     const int mute = g_eae_launch_options.split_mute;
     g_eae_launch_options = read_launch_options();
@@ -45,6 +47,7 @@ extern "C" int eae_hip_debug_set_split_mute(int on) {
     g_eae_launch_options.split_mute = on ? 1 : 0;
     return EAE_HIP_OK;
 }
+#endif
 
 extern "C" int eae_hip_partition_info(int* compute_units, int* xcds, int* whole_device) {
     const int cus = eae_compute_units();

@@ -622,16 +622,30 @@ def coder_decode_batch(streams, probabilities, prob_row, expected=None, workspac
     return out
 
 
+class ExperimentalCoderMissing(HipError):
+    """The library in use was built without -DEAE_EXPERIMENTAL_CODER (the product library always is: include/eae_hip.h)."""
+
+
+def _experimental_coder():
+    lib = _native.hip()
+    if not hasattr(lib, 'eae_hip_coder_roundtrip_trailing'):
+        raise ExperimentalCoderMissing(
+            'the chunked / fused coder round trips are experimental and not part of lib/libeae_hip.so (both measured slower than '
+            'encode_batch + decode_batch: DESIGN.md section 5); they live in lib/libeae_hip_test.so (EAE_HIP_LIB=test, or '
+            '`make -C csrc EXTRA_HIPFLAGS=-DEAE_EXPERIMENTAL_CODER`)')
+    return lib
+
+
 def coder_trailing_workspace(n_maps, map_size, truncated_unary_length, device):
-    """Scratch for coder_roundtrip_trailing (one per batch in flight)."""
-    nbytes = int(_native.hip().eae_hip_coder_trailing_workspace_bytes(n_maps, map_size, truncated_unary_length))
+    """Scratch for coder_roundtrip_trailing (one per batch in flight). Experimental build only."""
+    nbytes = int(_experimental_coder().eae_hip_coder_trailing_workspace_bytes(n_maps, map_size, truncated_unary_length))
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
 def coder_roundtrip_trailing(symbols_planar, probabilities, prob_row, truncated_unary_length, chunks=4, out=None, workspace=None):
     """Encode every map, decode it back, compare (coder_encode_batch + coder_decode_batch(expected=symbols)) with the serial
     chains cut into `chunks` launches so that emit pass and decoder trail the encoder core (include/eae_hip.h: for one or two
-    images). Same streams, bit counts, statuses and stages. Returns the CoderStreams."""
+    images). Same streams, bit counts, statuses and stages. Returns the CoderStreams. Experimental build only."""
     map_size = symbols_planar.shape[-1]
     n_maps = symbols_planar.numel()//map_size
     if symbols_planar.dtype != torch.int16 or probabilities.dtype != torch.float64:
@@ -640,7 +654,7 @@ def coder_roundtrip_trailing(symbols_planar, probabilities, prob_row, truncated_
         out = CoderStreams(n_maps, map_size, truncated_unary_length, symbols_planar.device)
     if workspace is None:
         workspace = coder_trailing_workspace(n_maps, map_size, truncated_unary_length, symbols_planar.device)
-    _check(_native.hip().eae_hip_coder_roundtrip_trailing(n_maps, map_size, _p(symbols_planar), truncated_unary_length, _p(probabilities),
+    _check(_experimental_coder().eae_hip_coder_roundtrip_trailing(n_maps, map_size, _p(symbols_planar), truncated_unary_length, _p(probabilities),
                                                           _p(prob_row), _p(out.streams), out.stride, _p(out.bac_bits), _p(out.bypass_bits),
                                                           _p(out.status), _p(out.stage), _p(workspace), workspace.numel(), int(chunks),
                                                           _stream(symbols_planar)), 'eae_hip_coder_roundtrip_trailing')
@@ -650,7 +664,8 @@ def coder_roundtrip_trailing(symbols_planar, probabilities, prob_row, truncated_
 def coder_roundtrip_fused(symbols_planar, probabilities, prob_row, truncated_unary_length, out=None, workspace=None):
     """Encode every map, decode it back, compare, with the three serial stages of a group of 64 maps as three wavefronts of one
     workgroup handing records and stream words to each other through LDS (include/eae_hip.h: eae_hip_coder_roundtrip_fused). Same
-    streams, bit counts, statuses and stages as coder_encode_batch + coder_decode_batch(expected=symbols). Returns the CoderStreams."""
+    streams, bit counts, statuses and stages as coder_encode_batch + coder_decode_batch(expected=symbols). Returns the CoderStreams.
+    Experimental build only."""
     map_size = symbols_planar.shape[-1]
     n_maps = symbols_planar.numel()//map_size
     if symbols_planar.dtype != torch.int16 or probabilities.dtype != torch.float64:
@@ -659,7 +674,7 @@ def coder_roundtrip_fused(symbols_planar, probabilities, prob_row, truncated_una
         out = CoderStreams(n_maps, map_size, truncated_unary_length, symbols_planar.device)
     if workspace is None:
         workspace = coder_trailing_workspace(n_maps, map_size, truncated_unary_length, symbols_planar.device)
-    _check(_native.hip().eae_hip_coder_roundtrip_fused(n_maps, map_size, _p(symbols_planar), truncated_unary_length, _p(probabilities),
+    _check(_experimental_coder().eae_hip_coder_roundtrip_fused(n_maps, map_size, _p(symbols_planar), truncated_unary_length, _p(probabilities),
                                                        _p(prob_row), _p(out.streams), out.stride, _p(out.bac_bits), _p(out.bypass_bits),
                                                        _p(out.status), _p(out.stage), _p(workspace), workspace.numel(), _stream(symbols_planar)),
            'eae_hip_coder_roundtrip_fused')

@@ -344,6 +344,11 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
                                const uint32_t* bypass_bits, int32_t* status, int32_t* stage, void* workspace,
                                uint64_t workspace_bytes, void* stream);
 
+/* ==== EXPERIMENTAL (-DEAE_EXPERIMENTAL_CODER): NOT exported by the product library lib/libeae_hip.so ==========================
+ * Two byte-exact alternatives for the coder's round trip on small batches, both measured slower than the encode_batch +
+ * decode_batch pair on this runtime. They are compiled into lib/libeae_hip_test.so only
+ * (csrc/Makefile: `make hip-test`), where their parity tests run (tests/test_coder_device.py). */
+#ifdef EAE_EXPERIMENTAL_CODER
 /* The round trip of lossless/c++/source/compression.cpp:27-64 (encode every map, decode it back, compare) for SMALL batches -- one or
  * two images, two to four wavefronts of maps -- where what it costs is the length of its serial chains one after the other. The
  * chains are cut into `chunks` launches (2..16; 4 is a good value): while the encoder core runs chunk c + 1 the emit pass assembles
@@ -369,6 +374,8 @@ int eae_hip_coder_roundtrip_fused(uint32_t n_maps, uint32_t map_size, const int1
                                   uint64_t stream_stride_bytes, uint32_t* bac_bits, uint32_t* bypass_bits, int32_t* status,
                                   int32_t* stage, void* workspace, uint64_t workspace_bytes, void* stream);
 
+#endif /* EAE_EXPERIMENTAL_CODER */
+
 /* ---- container support (the reference never serialises, compression.cpp:27-64) ------------------
  * pack_streams: gathers the valid bytes of every map's two streams (layout above) into `payload`: the arithmetic-coded
  * bytes of map m at offsets[2m], its bypass bytes at offsets[2m+1] (uint64 byte offsets, device memory, chosen by the
@@ -383,6 +390,11 @@ int eae_hip_coder_unpack_streams(uint32_t n_maps, const uint8_t* payload, const 
 int eae_hip_dequantize_maps(const int16_t* symbols_planar, const float* bin_widths, const float* map_mean, float* cq_out,
                             float* shifted_out, int n, int hw, int c, void* stream);
 
+/* ==== TEST HOOKS (-DEAE_TEST_HOOKS): NOT exported by the product library lib/libeae_hip.so ====================================
+ * Four entry points the test-suite needs and a deployment must not have (they change what later launches do, or only
+ * exist to prove something about the kernels). Compiled into lib/libeae_hip_test.so only; tests/test_abi.py checks that
+ * the product library exports no symbol of this section (nor any other `debug` symbol). */
+#ifdef EAE_TEST_HOOKS
 /* Diagnostic hook (not part of the path): when given a device buffer of grid * waves * 8 uint64, the conv GEMM kernel
  * records s_memtime stamps per wave (start, loop start, loop end, GDN end, end, K-steps, XCC id, HW id). NULL disables. */
 int eae_hip_debug_set_stamp_buffer(uint64_t* device_buffer);
@@ -402,6 +414,7 @@ int eae_hip_debug_set_split_mute(int on);
  * through sqrt_mid and sqrtf; mode 1: `count` pseudo-random operand pairs of the guarded range (all exponents, random and extreme
  * mantissas) through div_mid and `/`. out2_device[0] += results whose bits differ, out2_device[1] = one such operand (pair). */
 int eae_hip_debug_check_mid_forms(int mode, uint64_t first, uint64_t count, uint64_t seed, uint64_t* out2_device, void* stream);
+#endif /* EAE_TEST_HOOKS */
 
 /* tls.cast_bt601 (tools.py:61-93) on its own: u8 = uint8(round_half_even(clip(x, 16, 235))). */
 int eae_hip_cast_bt601(const float* x, uint8_t* out, int64_t count, void* stream);

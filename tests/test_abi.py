@@ -11,10 +11,33 @@ from autoencoder_based_image_compression_amd import _native_hip
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared(header):
+def declared(header, section=None):
+    """The functions `header` declares outside any `#ifdef EAE_...` section (section=None: the product), or inside the section of
+    that name (the header's own include guard and `__cplusplus` blocks are not sections)."""
     text = open(os.path.join(ROOT, 'include', header)).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(eae_[a-z0-9_]+)\s*\(', text)))
+    names = set()
+    inside = []
+    for line in text.split('\n'):
+        m = re.match(r'\s*#\s*(ifdef|ifndef|if|endif)\b\s*(\w*)', line)
+        if m:
+            if m.group(1) == 'endif':
+                inside.pop()
+            else:
+                inside.append(m.group(2) if m.group(1) == 'ifdef' and m.group(2).startswith('EAE_') else None)
+            continue
+        sections = [x for x in inside if x]
+        assert len(sections) <= 1, line
+        if (sections[0] if sections else None) == section:
+            names.update(re.findall(r'\b(eae_[a-z0-9_]+)\s*\(', line))
+    return sorted(names)
+
+
+def exported(library):
+    """Every dynamic symbol `library` defines (nm -D --defined-only)."""
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', os.path.join(_native.LIB_DIR, library)], check=True, capture_output=True, text=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
 
 
 def test_coder_library_exports_every_declared_symbol():
@@ -29,12 +52,41 @@ def test_coder_library_exports_every_declared_symbol():
 
 def test_hip_library_exports_every_declared_symbol():
     names = declared('eae_hip.h')
-    assert len(names) >= 14
+    assert len(names) >= 50
     lib = ctypes.CDLL(os.path.join(_native.LIB_DIR, 'libeae_hip.so'))
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(_native_hip.HIP_SYMBOLS) == names
     assert b'gfx950' in _native.hip().eae_hip_version()
+
+
+def test_the_product_library_exports_the_product_and_nothing_else():
+    """lib/libeae_hip.so holds exactly what include/eae_hip.h declares outside its two conditional sections: no `eae_hip_debug_*`
+    hook (they change what later launches do: a deployment must not be able to), no experimental coder entry point, no launch
+    stub or helper (csrc/hip/exports.map). The test build holds the product plus both sections, from the same sources."""
+    product = declared('eae_hip.h')
+    experimental = declared('eae_hip.h', 'EAE_EXPERIMENTAL_CODER')
+    hooks = declared('eae_hip.h', 'EAE_TEST_HOOKS')
+    assert sorted(_native_hip.EXPERIMENTAL_CODER_SYMBOLS) == experimental and len(experimental) == 3
+    assert sorted(_native_hip.TEST_HOOK_SYMBOLS) == hooks and len(hooks) == 4
+    assert all('debug' in name for name in hooks) and not any('debug' in name for name in product + experimental)
+    assert exported('libeae_hip.so') == product
+    assert not any('debug' in name or 'trailing' in name or 'fused' in name for name in exported('libeae_hip.so'))
+    assert exported('libeae_hip_test.so') == sorted(product + experimental + hooks)
+
+
+def test_the_product_library_refuses_the_experimental_coder_by_name(monkeypatch):
+    """Asking the product library for a chunked or fused round trip says what is missing and where it lives, before anything is
+    allocated or launched (no GPU needed); so does a codec asked for `coder_chunks`."""
+    from autoencoder_based_image_compression_amd import device as dev
+    monkeypatch.delenv('EAE_HIP_LIB', raising=False)
+    monkeypatch.setattr(_native, '_hip', None)
+    assert not _native.has_experimental_coder()
+    with pytest.raises(dev.ExperimentalCoderMissing, match='libeae_hip_test.so'):
+        dev.coder_trailing_workspace(128, 1536, 10, 'cpu')
+    monkeypatch.setattr(_native, '_hip', _native.hip_test())
+    assert _native.has_experimental_coder()
+    assert int(_native.hip().eae_hip_coder_trailing_workspace_bytes(128, 1536, 10)) > 0
 
 
 def test_hip_library_contains_gfx950_code_objects():

@@ -378,6 +378,8 @@ def test_batch_full_kodak_batch(gold, dev):
 
 
 # ---- the chunked round trip: emit pass and decoder trailing the encoder core (eae_hip_coder_roundtrip_trailing) ------------
+# Experimental, compiled into the test build only (include/eae_hip.h, -DEAE_EXPERIMENTAL_CODER): these tests run on
+# lib/libeae_hip_test.so (fixture `test_library`, tests/conftest.py).
 
 def trailing_code(dev, planar, probs, prob_row, chunks):
     """chunks == 'fused': the three serial stages of a group as one workgroup (eae_hip_coder_roundtrip_fused)."""
@@ -394,7 +396,7 @@ def trailing_code(dev, planar, probs, prob_row, chunks):
 
 @pytest.mark.parametrize('chunks', [1, 2, 3, 4, 8, 16, 'fused'])
 @pytest.mark.parametrize('scale', [0.3, 4., 300.])
-def test_trailing_round_trip_equals_the_host_coder(gold, dev, scale, chunks):
+def test_trailing_round_trip_equals_the_host_coder(gold, dev, scale, chunks, test_library):
     """One Kodak image's worth of maps (and a ragged second group) at three densities: whatever the number of chunks, the streams,
     bit counts, statuses and stages are the host coder's, and the round trip finds nothing to complain about."""
     rng = numpy.random.RandomState(int(scale*10) + (99 if chunks == 'fused' else chunks))
@@ -414,7 +416,7 @@ def test_trailing_round_trip_equals_the_host_coder(gold, dev, scale, chunks):
     assert numpy.array_equal(out[keep], planar[keep])
 
 
-def test_trailing_round_trip_large_maps_and_long_pending_runs(gold, dev):
+def test_trailing_round_trip_large_maps_and_long_pending_runs(gold, dev, test_library):
     """The maps of test_batch_large_maps_long_pending_runs_and_every_window_tier (128 x 128 latents; nearly dead maps whose pending
     E3 runs make the emit pass give up, streams from a few words to thousands): a decoder chunk that finds too few bits in memory
     parks, the general kernel recodes what the fast encoder hands over, and the result is the host coder's."""
@@ -436,7 +438,7 @@ def test_trailing_round_trip_large_maps_and_long_pending_runs(gold, dev):
         assert assert_equals_host(streams, planar, probs, rows, ('large', chunks)).all()
 
 
-def test_trailing_round_trip_fuzz_including_errors(gold, dev):
+def test_trailing_round_trip_fuzz_including_errors(gold, dev, test_library):
     """Random sizes, L, magnitudes, a few invalid probabilities and skipped maps: the statuses and stages after the chunked round
     trip are those after encode_batch + decode_batch(expected), the bytes and bit counts the host coder's."""
     rng = numpy.random.RandomState(321)
@@ -463,7 +465,7 @@ def test_trailing_round_trip_fuzz_including_errors(gold, dev):
     assert {0, 1, 4} <= seen
 
 
-def test_trailing_round_trip_finds_a_difference(gold, dev):
+def test_trailing_round_trip_finds_a_difference(gold, dev, test_library):
     """The comparison at the end of the round trip is a real one: symbols that change between the encoder's read and the
     decoder's comparison (here: the caller's buffer rewritten behind the call) give status 6 for that map only."""
     rng = numpy.random.RandomState(5)

@@ -441,10 +441,27 @@ def test_the_product_mode_at_kodak_size_equals_the_conservative_one():
                 assert numpy.array_equal(r[key], want[k % 3][key]), (k, key)
 
 
+def test_the_product_library_has_no_chunked_coder():
+    """`coder_chunks > 1` on lib/libeae_hip.so: the constructor says that the chunked round trip is experimental and where it lives,
+    and nothing is left behind (no worker thread yet, no stream); the default (one chunk) is what every other test here runs."""
+    from autoencoder_based_image_compression_amd import _native, codec
+    from autoencoder_based_image_compression_amd import device as dev
+    import bench
+    if _native.has_experimental_coder():
+        pytest.skip('EAE_HIP_LIB names a build with the experimental coder')
+    with numpy.load(GOLD) as g:
+        probabilities = g['real_probabilities_1']
+    variables = bench.synthetic_model(0.25)
+    with pytest.raises(dev.ExperimentalCoderMissing, match='libeae_hip_test.so'):
+        codec.BatchCodec(variables, False, variables['piecewise_linear_function/bin_widths'], numpy.zeros(128, dtype=numpy.float32), probabilities,
+                         67, 1, 128, 192, coder_chunks=4)
+
+
 @pytest.mark.parametrize('graphs', [False, True])
-def test_a_trailing_coder_gives_the_same_results(graphs):
+def test_a_trailing_coder_gives_the_same_results(graphs, test_library):
     """One image per batch: the coder's chains cut into launches that overlap (`coder_chunks`) against the two calls one after
-    the other (`coder_chunks=1`, the default), launched kernel by kernel and replayed as hipGraphs."""
+    the other (`coder_chunks=1`, the default), launched kernel by kernel and replayed as hipGraphs. The chunked form is
+    experimental: it exists in the test build of the library only (fixture `test_library`)."""
     from autoencoder_based_image_compression_amd import codec
     import bench
     with numpy.load(GOLD) as g:

@@ -333,7 +333,7 @@ def _mid_forms(mode, first, count, seed=0):
     return (int(out[0].item()), int(out[1].item()))
 
 
-def test_sqrt_mid_equals_sqrtf_on_every_float_of_its_range():
+def test_sqrt_mid_equals_sqrtf_on_every_float_of_its_range(test_library):
     """v_sqrt_f32 + the two neighbours + two FMA residuals + two selects (hipcc's own correctly rounded sequence without the scaling
     of tiny inputs and the class check) against sqrtf, EXHAUSTIVELY over everything `gdn_tile`'s guard lets through: every float
     from 2^-96 to +inf and every NaN (fminf skips NaNs, so they reach the short form): 0 results differ. Below 2^-96 and for
@@ -350,7 +350,7 @@ def test_sqrt_mid_equals_sqrtf_on_every_float_of_its_range():
     assert bad_below > 0                      # the guard is not decoration
 
 
-def test_div_mid_equals_the_division_on_its_range():
+def test_div_mid_equals_the_division_on_its_range(test_library):
     """v_rcp_f32 + one Newton step + quotient + two FMA corrections + the final FMA (hipcc's own correctly rounded division without
     v_div_scale / v_div_fixup) against `/` on 2^33 operand pairs of the guarded range (2^-60 <= |x| <= 2^60, 2^-20 <= s <= 2^40):
     every exponent pair, random mantissas and the extreme ones (0, all ones, equal), both signs."""

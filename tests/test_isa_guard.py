@@ -49,11 +49,12 @@ def test_the_pattern_is_found_in_both_directions_and_nowhere_else():
     assert isa_guard.scan(FINE, 'fine') == []
 
 
-def test_the_shipped_library_is_clean():
+@pytest.mark.parametrize('library', ['libeae_hip.so', 'libeae_hip_test.so'])
+def test_the_shipped_library_is_clean(library):
     import isa_guard
-    lib = os.path.join(ROOT, 'autoencoder_based_image_compression_amd', 'lib', 'libeae_hip.so')
+    lib = os.path.join(ROOT, 'autoencoder_based_image_compression_amd', 'lib', library)
     if not os.path.isfile(lib):
-        pytest.skip('libeae_hip.so not built')
+        pytest.skip(library + ' not built')
     blobs = isa_guard.code_objects(lib)
     assert len(blobs) >= 10                       # one code object per kernel file
     assert isa_guard.check([lib]) == []
@@ -105,22 +106,26 @@ def test_a_64_bit_shift_fed_from_the_last_register_of_the_allocation_is_found():
     assert isa_guard.scan(SHIFT_FINE, 'fine') == []
 
 
-def test_allocations_from_the_shipped_metadata():
+@pytest.mark.parametrize('library', ['libeae_hip.so', 'libeae_hip_test.so'])
+def test_allocations_from_the_shipped_metadata(library):
     import isa_guard
-    lib = os.path.join(ROOT, 'autoencoder_based_image_compression_amd', 'lib', 'libeae_hip.so')
+    lib = os.path.join(ROOT, 'autoencoder_based_image_compression_amd', 'lib', library)
     if not os.path.isfile(lib):
-        pytest.skip('libeae_hip.so not built')
+        pytest.skip(library + ' not built')
     alloc = {}
     for blob in isa_guard.code_objects(lib):
         alloc.update(isa_guard.allocations(blob))
     # every coder kernel reserves the last register of ITS OWN allocation (EAE_KEEP_LAST_VGPR_FREE(EAE_RES_*), coder_simd.hip, coder_device.hip): a kernel
     # that outgrows its number lands in the next granule with an unreserved last register -- fix the number, not this test
     own = {'15binarise_kernel': 48, '22bac_encode_core_kernelILb0E': 48, '11emit_kernelILb0E': 40, '22bac_decode_core_kernelILb0E': 56, '17debinarise_kernel': 24,
-           '17coder_pipe_kernel': 64, '22bac_encode_core_kernelILb1E': 48, '11emit_kernelILb1E': 40, '22bac_decode_core_kernelILb1E': 64,      # the chunked round trip's
            'coder_maps_kernelILi0ELb0E': 56, 'coder_maps_kernelILi1ELb0E': 56, 'coder_maps_kernelILi1ELb1E': 24, 'coder_maps_kernelILi2ELb0E': 56,
            'decoder_maps_kernelILb0ELb0E': 48, 'decoder_maps_kernelILb0ELb1E': 24, 'decoder_maps_kernelILb1ELb0E': 56, 'decoder_maps_kernelILb1ELb1E': 32}
+    # the experimental round trips' kernels (-DEAE_EXPERIMENTAL_CODER): in the test build only, absent from the product
+    experimental = {'17coder_pipe_kernel': 64, '22bac_encode_core_kernelILb1E': 48, '11emit_kernelILb1E': 40, '22bac_decode_core_kernelILb1E': 64}
     for (name, want) in own.items():
         assert [v for (k, v) in alloc.items() if name in k] == [want], name
+    for (name, want) in experimental.items():
+        assert [v for (k, v) in alloc.items() if name in k] == ([want] if library == 'libeae_hip_test.so' else []), name
     assert all(v % 8 == 0 and 8 <= v <= 512 for v in alloc.values()) and len(alloc) > 50
     assert not any('latent_wave_kernelILb1ELb1' in k for k in alloc)       # kernels with AccVGPRs are left out: their top registers are accumulators
 

@@ -63,6 +63,11 @@ _CODER_BEHIND_TCONV1 = os.environ.get('EAE_CODER_BEHIND_TCONV1')
 _SEQUENCE_POLL_SECONDS = float(os.environ.get('EAE_WORKER_SEQUENCE_POLL_SECONDS', '0.0001'))
 _SEQUENCE_TIMEOUT_SECONDS = float(os.environ.get('EAE_WORKER_SEQUENCE_TIMEOUT_SECONDS', '60'))
 _LONG_SLEEP = os.environ.get('EAE_WORKER_LONG_SLEEP', '1') != '0'      # the one long sleep in front of the polls (`_Worker._wait_sequence`)
+# `Ticket.result()` called before anybody has started on the ticket's step does the waiting and the bookkeeping ITSELF (the caller is
+# blocked anyway: no wake-up of the worker, no hand-over back), and around the moment the step is expected it watches the step counter
+# without sleeping, for at most this long (seconds of one CPU per call; 0 = never: sleeps and polls like the worker)
+_RESULT_SPIN_SECONDS = float(os.environ.get('EAE_RESULT_SPIN_SECONDS', '0.00015'))
+_RESULT_BY_CALLER = os.environ.get('EAE_RESULT_BY_CALLER', '1') != '0'      # 0: results are always formed by the worker thread (rounds 1-5)
 
 
 def _short_sleeps_for_this_thread():
@@ -129,6 +134,7 @@ class Ticket(object):
         self.decoded_event = None             # with keep_reconstruction: recorded behind the synthesis transform: wait for it on another
         #                                       stream before reading `reconstruction_uint8` there (valid until the slot comes round again)
         self._coder_span = None               # (start, stop) timing events on the coder stream (BatchCodec(time_coder=True))
+        self._job = None                      # (_Job, _Worker) until somebody has started on the step's results
 
     def coder_ms(self):
         """Milliseconds the coder launches of this batch took on their stream (from the moment the symbols were ready to the
@@ -140,7 +146,15 @@ class Ticket(object):
     def result(self):
         """Blocks until the batch is through; dict of numpy arrays, one entry per image:
         'nb_bits' int64 (lossless code incl. the exception map's entropy cost), 'coder_bits' int64, 'exception_bits' int64,
-        'sse' int64 (sum of squared uint8 differences), 'nb_deads' int64."""
+        'sse' int64 (sum of squared uint8 differences), 'nb_deads' int64.
+        When the result worker has not started on this step yet (one step at a time: the caller is here a few microseconds after
+        `submit`), the calling thread waits for the device and forms the results itself (`_Worker.process`)."""
+        pending = self._job
+        if pending is not None:
+            self._job = None
+            (job, worker) = pending
+            if _RESULT_BY_CALLER and not self._done.is_set() and job.claim():
+                worker.process(job, by_caller=True)
         self._done.wait()
         if self._error is not None:
             raise self._error
@@ -149,6 +163,22 @@ class Ticket(object):
 
 class StepTimeout(RuntimeError):
     """The device did not report a submitted step within EAE_WORKER_SEQUENCE_TIMEOUT_SECONDS: the codec is unusable from here on."""
+
+
+class _Job(object):
+    """What the results of one submitted step are made from; whoever claims it first -- the result worker taking it off its queue, or
+    the caller's `Ticket.result()` -- waits for the device and forms the results."""
+    __slots__ = ('fields', '_claimed')
+
+    def __init__(self, *fields):
+        self.fields = fields
+        self._claimed = threading.Lock()
+
+    def claim(self):
+        return self._claimed.acquire(False)
+
+
+_THREAD = threading.local()
 
 
 class _Worker(threading.Thread):
@@ -174,6 +204,37 @@ class _Worker(threading.Thread):
     failed = None           # StepTimeout: the device stopped reporting; the codec refuses further work (BatchCodec.submit)
     _sleep = staticmethod(time.sleep)          # (a test drives `_wait_sequence` with a clock of its own: tests/test_host_logic.py)
     _now = staticmethod(time.monotonic)
+
+    _caller_waits = ()      # the last waits of `_wait_sequence_by_caller` (seconds)
+
+    def _wait_sequence_by_caller(self, words, expected):
+        """`_wait_sequence` for the thread that called `Ticket.result()` on a step nobody had started on: that thread is blocked
+        anyway, so nothing is handed over and what is left is to notice the device's last write as soon as it lands. ONE sleep up to
+        shortly before the moment the step is expected to be through -- the shortest of the last three such waits, less a third of the
+        spin budget: a lower bound as long as the regime lasts, and a change of regime (another shape of use, steps queued behind each
+        other) shows as waits that differ, which switches the sleep off --, then the step counter is read in a loop for at most
+        EAE_RESULT_SPIN_SECONDS of CPU, then polls like the worker's."""
+        started = self._now()
+        waits = self._caller_waits
+        steady = _LONG_SLEEP and len(waits) == 3 and max(waits) < 1.25*min(waits)
+        first = (min(waits) - _RESULT_SPIN_SECONDS/3.) if steady else 0.
+        deadline = None
+        if first > _SEQUENCE_POLL_SECONDS:
+            self._sleep(first)
+        spin_until = self._now() + _RESULT_SPIN_SECONDS
+        for (index, value) in enumerate(expected):
+            while ((int(words[index]) - value) & 0xFFFFFFFF) >= 0x80000000:      # words[index] < value, wrap-around safe
+                now = self._now()
+                if now < spin_until:
+                    continue
+                self._sleep(0.5*_SEQUENCE_POLL_SECONDS)
+                if deadline is None:
+                    deadline = now + _SEQUENCE_TIMEOUT_SECONDS
+                elif now > deadline:
+                    raise StepTimeout('the device has not reported step {0} of this slot after {1:.0f} s (step counter at {2}): the slot\'s '
+                                      'buffers may still be written to, so this codec takes no further batches -- close it'.format(
+                                          value, _SEQUENCE_TIMEOUT_SECONDS, int(words[index])))
+        self._caller_waits = (waits + (min(self._now() - started, 0.05),))[-3:]
 
     def _wait_sequence(self, words, expected):
         """Until the step counters the device leaves in pinned memory (`words`: numpy int32 view) have reached `expected`. Every
@@ -211,65 +272,74 @@ class _Worker(threading.Thread):
             job = self.jobs.get()
             if job is None:
                 return
-            (ticket, events, views, symbols_host, slot_free, recount, fetch, sequence) = job
-            try:
-                if sequence is not None:
-                    self._wait_sequence(*sequence)
-                for event in events:
-                    self._wait(event)
-                if fetch is not None:
-                    # The copy back is issued HERE, behind events that have completed: on this runtime an asynchronous copy
-                    # whose stream still waits for an event holds the calling thread until it can start (the launch thread would
-                    # submit the next step only after this one is decoded: 4.5 instead of 3.2 ms per step).
-                    (reconstruction, pinned, stream) = fetch
-                    with torch.cuda.device(reconstruction.device), torch.cuda.stream(stream):
-                        pinned.copy_(reconstruction, non_blocking=True)
-                        copied = torch.cuda.Event()
-                        copied.record()
-                    self._wait(copied)
-                    ticket.reconstruction_host = pinned.numpy()
-                (results, hist, overflow, flags, checks, sse) = [v.numpy() for v in views]
-                # the last word of the squared-error block: tiles that a cut conv launch of this batch left unfinished
-                # (device.conv_workspace_collect); nothing of this batch can be trusted then
-                (sse, unfinished) = (sse[:-1], int(sse[-1]))
-                if unfinished != 0:
-                    raise dev.SplitHandOffTimeout('{} tiles of a cut conv launch were not handed over: the results of this batch '
-                                                  'are invalid (the workspace has been reset; later batches are unaffected)'.format(unfinished))
-                if symbols_host is not None:
-                    # encode + decode + compare per map on the host cores, like compress_lossless + the caller's assert
-                    (_, nb_bits) = lossless_compression.code_planar_symbols(symbols_host.numpy(), self.host_probabilities,
-                                                                           self.idx_map_exception, nb_threads=self.host_threads,
-                                                                           roundtrip=True, verify_only=True)
-                    results = numpy.zeros_like(results)
-                    results[0] = nb_bits.reshape(-1)
-                if results[2].any():
-                    bad = int(numpy.flatnonzero(results[2])[0])
-                    if int(results[2, bad]) == 6:
-                        raise AssertionError('\nArrays are not equal\nThe lossless compression has altered the centered quantized data.')
-                    from .kodak.lossless import interface_cython
-                    interface_cython.raise_for_status(int(results[2, bad]), int(results[3, bad]))
-                if int(checks[0]) != 0:
-                    raise AssertionError('The rounded array elements cannot be represented as 16-bit signed integers.')
-                n = ticket.nb_images
-                coder_bits = (results[0].astype(numpy.int64) + results[1].astype(numpy.int64)).reshape(n, self.nb_maps).sum(axis=1)
-                exception_bits = numpy.zeros(n, dtype=numpy.int64)
-                if hist.size:
-                    if int(overflow.sum()) != 0:
-                        # a symbol beyond +-hist_radius: the reference's histogram runs from the smallest to the largest symbol
-                        # whatever they are (lossless/compression.py:68-75, tools.py:376-388), so count again over all of int16
-                        hist = recount()
-                    exception_bits = lossless_compression.exception_maps_nb_bits(hist.astype(numpy.int64), self.map_size)
-                ticket._values = {'nb_bits': coder_bits + exception_bits, 'coder_bits': coder_bits,
-                                  'exception_bits': exception_bits, 'sse': sse.astype(numpy.int64).copy(),
-                                  'nb_deads': (flags == 0).sum(axis=1).astype(numpy.int64)}
-            except StepTimeout as exc:    # nothing says the device is through with this slot: no later submit may reuse it
-                self.failed = exc
-                ticket._error = exc
-            except Exception as exc:      # surfaced by Ticket.result()
-                ticket._error = exc
-            finally:
-                slot_free.set()
-                ticket._done.set()
+            if job.claim():          # (else the caller's `Ticket.result()` got there first and does it itself)
+                self.process(job)
+
+    def process(self, job, by_caller=False):
+        """Waits until the device is through with the step, then forms the ticket's results from the slot's pinned blocks (or the
+        exception `result()` raises), frees the slot. On the worker thread, or on the caller's (`Ticket.result()`)."""
+        (ticket, events, views, symbols_host, slot_free, recount, fetch, sequence) = job.fields
+        try:
+            if by_caller and not getattr(_THREAD, 'short_sleeps', False):
+                _short_sleeps_for_this_thread()
+                _THREAD.short_sleeps = True
+            if sequence is not None:
+                (self._wait_sequence_by_caller if by_caller else self._wait_sequence)(*sequence)
+            for event in events:
+                self._wait(event)
+            if fetch is not None:
+                # The copy back is issued HERE, behind events that have completed: on this runtime an asynchronous copy
+                # whose stream still waits for an event holds the calling thread until it can start (the launch thread would
+                # submit the next step only after this one is decoded: 4.5 instead of 3.2 ms per step).
+                (reconstruction, pinned, stream) = fetch
+                with torch.cuda.device(reconstruction.device), torch.cuda.stream(stream):
+                    pinned.copy_(reconstruction, non_blocking=True)
+                    copied = torch.cuda.Event()
+                    copied.record()
+                self._wait(copied)
+                ticket.reconstruction_host = pinned.numpy()
+            (results, hist, overflow, flags, checks, sse) = [v.numpy() for v in views]
+            # the last word of the squared-error block: tiles that a cut conv launch of this batch left unfinished
+            # (device.conv_workspace_collect); nothing of this batch can be trusted then
+            (sse, unfinished) = (sse[:-1], int(sse[-1]))
+            if unfinished != 0:
+                raise dev.SplitHandOffTimeout('{} tiles of a cut conv launch were not handed over: the results of this batch '
+                                              'are invalid (the workspace has been reset; later batches are unaffected)'.format(unfinished))
+            if symbols_host is not None:
+                # encode + decode + compare per map on the host cores, like compress_lossless + the caller's assert
+                (_, nb_bits) = lossless_compression.code_planar_symbols(symbols_host.numpy(), self.host_probabilities,
+                                                                       self.idx_map_exception, nb_threads=self.host_threads,
+                                                                       roundtrip=True, verify_only=True)
+                results = numpy.zeros_like(results)
+                results[0] = nb_bits.reshape(-1)
+            if results[2].any():
+                bad = int(numpy.flatnonzero(results[2])[0])
+                if int(results[2, bad]) == 6:
+                    raise AssertionError('\nArrays are not equal\nThe lossless compression has altered the centered quantized data.')
+                from .kodak.lossless import interface_cython
+                interface_cython.raise_for_status(int(results[2, bad]), int(results[3, bad]))
+            if int(checks[0]) != 0:
+                raise AssertionError('The rounded array elements cannot be represented as 16-bit signed integers.')
+            n = ticket.nb_images
+            coder_bits = (results[0].astype(numpy.int64) + results[1].astype(numpy.int64)).reshape(n, self.nb_maps).sum(axis=1)
+            exception_bits = numpy.zeros(n, dtype=numpy.int64)
+            if hist.size:
+                if int(overflow.sum()) != 0:
+                    # a symbol beyond +-hist_radius: the reference's histogram runs from the smallest to the largest symbol
+                    # whatever they are (lossless/compression.py:68-75, tools.py:376-388), so count again over all of int16
+                    hist = recount()
+                exception_bits = lossless_compression.exception_maps_nb_bits(hist.astype(numpy.int64), self.map_size)
+            ticket._values = {'nb_bits': coder_bits + exception_bits, 'coder_bits': coder_bits,
+                              'exception_bits': exception_bits, 'sse': sse.astype(numpy.int64).copy(),
+                              'nb_deads': (flags == 0).sum(axis=1).astype(numpy.int64)}
+        except StepTimeout as exc:    # nothing says the device is through with this slot: no later submit may reuse it
+            self.failed = exc
+            ticket._error = exc
+        except Exception as exc:      # surfaced by Ticket.result()
+            ticket._error = exc
+        finally:
+            slot_free.set()
+            ticket._done.set()
 
 
 def default_nb_in_flight(h_in, w_in):
@@ -621,9 +691,11 @@ class BatchCodec(object):
                 ticket.reconstruction_uint8 = reconstruction       # valid until this slot is replayed again
             if self._slot_views[slot] is None:
                 self._slot_views[slot] = self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],)
-            self._worker.jobs.put((ticket, () if sequence_mode else (coded, decoded), self._slot_views[slot], None,
-                                   self._slot_free[slot], lambda: self._recount_exception_maps(slot), self._fetch_job(slot, reconstruction),
-                                   (self._seq_host[slot], expected) if sequence_mode else None))
+            job = _Job(ticket, () if sequence_mode else (coded, decoded), self._slot_views[slot], None,
+                       self._slot_free[slot], lambda: self._recount_exception_maps(slot), self._fetch_job(slot, reconstruction),
+                       (self._seq_host[slot], expected) if sequence_mode else None)
+            ticket._job = (job, self._worker)
+            self._worker.jobs.put(job)
             self._counts[slot] = list(expected)
             return ticket
         except BaseException:
@@ -720,9 +792,11 @@ class BatchCodec(object):
             ticket.fed_event = fed[0] if fed else None
             if self.keep_reconstruction:
                 ticket.reconstruction_uint8 = reconstruction
-            self._worker.jobs.put((ticket, () if sequence_mode else (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],),
-                                   self._pinned_symbols[slot], self._slot_free[slot], lambda: self._recount_exception_maps(slot),
-                                   self._fetch_job(slot, reconstruction), (self._seq_host[slot], expected) if sequence_mode else None))
+            job = _Job(ticket, () if sequence_mode else (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],),
+                       self._pinned_symbols[slot], self._slot_free[slot], lambda: self._recount_exception_maps(slot),
+                       self._fetch_job(slot, reconstruction), (self._seq_host[slot], expected) if sequence_mode else None)
+            ticket._job = (job, self._worker)
+            self._worker.jobs.put(job)
             self._counts[slot] = list(expected)
             return ticket
         except BaseException:

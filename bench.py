@@ -529,6 +529,35 @@ def launch_rooflines(run_events, pixels_per_step, fuse_latent, map_symbols):
     return (out, per_launch_ms, flops)
 
 
+def children_alone_on_the_gpu(args, h_in, w_in):
+    """The two side figures that are measured in processes of their own, run one after the other BEFORE this process initialises the
+    GPU, so that each has the GPU to itself: (1) `library_user`: what a user of the package gets who sets nothing -- a child whose
+    environment does not hold GPU_MAX_HW_QUEUES imports the package (which asks for its queues itself) and runs the headline workload
+    in the default product mode; (2) `single_image_pipelined`: one image per step with twenty steps in flight (twenty busy streams).
+    Round 6 measured why they must not run while this process holds its context: the same `library_user` child gave 2,928 Mpx/s
+    behind the parent's legs (sixteen hardware queues of a live process next to its own) and 3,153-3,160 alone
+    (profiles/r06_library_user.md). Children, never an exec."""
+    out = {}
+    same_model = ['--bin-width', repr(args.bin_width)] + (['--checkpoint', args.checkpoint] if args.checkpoint else []) + (
+        ['--learned-bin-widths'] if args.learned_bin_widths else [])
+    try:
+        env = {k: v for (k, v) in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), '--only-library-user', '--no-cpu-baseline', '--steps', str(args.steps),
+                                '--warmup', str(args.warmup), '--batch', str(args.batch), '--height', str(h_in), '--width', str(w_in)] + same_model,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, check=True, text=True, env=env)
+        out['library_user'] = json.loads([ln for ln in child.stdout.splitlines() if ln.startswith('{')][-1])['library_user']
+    except Exception as exc:      # a side figure must never cost the run its headline
+        out['library_user'] = {'error': '{0}: {1}'.format(type(exc).__name__, exc)}
+    try:
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), '--only-single-image-pipelined', '--no-cpu-baseline'] + same_model,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, check=True, text=True,
+                               env=dict(os.environ, GPU_MAX_HW_QUEUES='24'))      # twenty busy streams + the default one
+        out['single_image_pipelined'] = json.loads([ln for ln in child.stdout.splitlines() if ln.startswith('{')][-1])['single_image_pipelined']
+    except Exception as exc:
+        out['single_image_pipelined'] = {'pipelined_error': '{0}: {1}'.format(type(exc).__name__, exc)}
+    return out
+
+
 def main(args):
     inputs = load_inputs(args)
     if inputs['images'] is not None:
@@ -560,6 +589,10 @@ def main(args):
                               'coder_streams': args.coder_streams or auto_coder_streams(h_in, w_in), 'usable_cpus': usable_cpus()}))
         dist.destroy_process_group()
         return
+    early = {}
+    if (rank == 0 and world == 1 and not args.no_single_image and not (args.only_single_image_pipelined or args.only_library_user or args.only_dropin_surface)
+            and args.batch != 1 and (h_in, w_in) == (512, 768) and torch.cuda.device_count() > 0):
+        early = children_alone_on_the_gpu(args, h_in, w_in)      # BEFORE this process initialises the GPU (counting devices does not)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU fallback for the product path.')
     if share_gpu:
@@ -603,7 +636,7 @@ def main(args):
             'value': round(args.batch*h_in*w_in*args.steps/one['elapsed']/1e6, 3), 'unit': 'Mpixels/s',
             'ms_per_step': round(one['elapsed']/args.steps*1e3, 4), 'steps': args.steps,
             'hw_queues': package.HW_QUEUES[0], 'hw_queues_set_by': package.HW_QUEUES[1], 'env_GPU_MAX_HW_QUEUES': os.environ.get('GPU_MAX_HW_QUEUES'),
-            'mode': 'codec.BatchCodec(**codec.product_mode(h, w)) in a fresh process whose environment did not hold GPU_MAX_HW_QUEUES'}}))
+            'mode': 'codec.BatchCodec(**codec.product_mode(h, w)) in a fresh process, alone on the GPU, whose environment ' + ('did not hold GPU_MAX_HW_QUEUES' if package.HW_QUEUES[1] == 'package' else 'held GPU_MAX_HW_QUEUES')}}))
         return
     if args.only_dropin_surface:
         # diagnostic: the statistics that feed the coder as run_pipeline derives them, then the leg alone
@@ -798,33 +831,12 @@ def main(args):
         except Exception as exc:      # a side figure must never cost the run its headline
             line['dropin_surface'] = {'error': '{0}: {1}'.format(type(exc).__name__, exc)}
     if side and 'single_image' in line:
-        # the pipelined figure of one image per step, measured in a process of its own (this one waits, its GPU idle): the leg needs
-        # twenty busy streams, this process has made fifteen by now, and streams beyond GPU_MAX_HW_QUEUES share hardware queues --
-        # busy ones with busy ones (in here, with fourteen: 0.28-0.36 ms per image where a fresh process measures 0.25, and whatever leg
-        # runs behind it loses up to 8 %). A child process, never an exec: this process has initialised the GPU.
-        try:
-            same_model = ['--bin-width', repr(args.bin_width)] + (['--checkpoint', args.checkpoint] if args.checkpoint else []) + (
-                ['--learned-bin-widths'] if args.learned_bin_widths else [])
-            child = subprocess.run([sys.executable, os.path.abspath(__file__), '--only-single-image-pipelined', '--no-cpu-baseline'] + same_model,
-                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, check=True, text=True,
-                                   env=dict(os.environ, GPU_MAX_HW_QUEUES='24'))      # twenty busy streams + the default one
-            line['single_image'].update(json.loads([ln for ln in child.stdout.splitlines() if ln.startswith('{')][-1])['single_image_pipelined'])
-        except Exception as exc:      # a side figure must never cost the run its headline
-            line['single_image']['pipelined_error'] = '{0}: {1}'.format(type(exc).__name__, exc)
-    if rank == 0 and world == 1 and side:
-        # what a user of the package gets who sets nothing: a fresh child process (never an exec: this process has initialised the GPU)
-        # WITHOUT GPU_MAX_HW_QUEUES in its environment imports the package -- which asks for its queues itself -- and runs the headline
-        try:
-            same_model = ['--bin-width', repr(args.bin_width)] + (['--checkpoint', args.checkpoint] if args.checkpoint else []) + (
-                ['--learned-bin-widths'] if args.learned_bin_widths else [])
-            env = {k: v for (k, v) in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
-            child = subprocess.run([sys.executable, os.path.abspath(__file__), '--only-library-user', '--no-cpu-baseline', '--steps', str(args.steps),
-                                    '--warmup', str(args.warmup), '--batch', str(args.batch), '--height', str(h_in), '--width', str(w_in)] + same_model,
-                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, check=True, text=True, env=env)
-            line['library_user'] = json.loads([ln for ln in child.stdout.splitlines() if ln.startswith('{')][-1])['library_user']
+        # the pipelined figure of one image per step: measured by `children_alone_on_the_gpu` before this process touched the GPU
+        line['single_image'].update(early.get('single_image_pipelined', {'pipelined_error': 'not run'}))
+    if 'library_user' in early:
+        line['library_user'] = early['library_user']
+        if 'value' in line['library_user']:
             line['library_user']['over_headline'] = round(line['library_user']['value']/line['value'], 4)
-        except Exception as exc:      # a side figure must never cost the run its headline
-            line['library_user'] = {'error': '{0}: {1}'.format(type(exc).__name__, exc)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             # the one leg of this file that runs checker code (oracle/): the CPU baseline and, with the same CPU transforms, what
@@ -851,7 +863,7 @@ def single_image_pipelined_leg(ctx, variables, h, w, steps=1000):
     one = run_pipeline(ctx, 1, steps, 30, variables, h, w, coder_streams=streams, transform_streams=streams, use_graphs=True, one_stream_steps=True)
     return {'ms_per_image': round(one['elapsed']/steps*1e3, 4), 'mpixels_per_s': round(steps*h*w/one['elapsed']/1e6, 2), 'steps': steps, 'warmup': 30,
             'host_cpu_ms_per_image': one['host_cpu_ms_per_step'][0], 'steps_in_flight': streams, 'gpu_max_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
-            'pipelined_in': 'a process of its own (GPU_MAX_HW_QUEUES=24 python bench.py --only-single-image-pipelined)'}
+            'pipelined_in': 'a process of its own, alone on the GPU: started before the bench process initialised its GPU context (GPU_MAX_HW_QUEUES=24 python bench.py --only-single-image-pipelined)'}
 
 
 def dropin_surface_leg(ctx, variables, probabilities, map_mean, idx_map_exception, h, w, nb_images=24, batch_size=4, repeats=5):

@@ -429,6 +429,111 @@ def test_the_result_worker_sleeps_long_only_in_a_steady_regime():
     assert sleeps == []
 
 
+def _drive_caller_wait(worker, device_done_at, start):
+    """`_wait_sequence_by_caller` on a clock of the test's own that also moves a microsecond every time it is read (the spin reads it).
+    Returns (sleeps, reads of the clock while spinning, the clock afterwards)."""
+    import numpy
+    clock = [start]
+    words = numpy.zeros(1, dtype=numpy.int32)
+    sleeps = []
+    reads = [0]
+
+    def sleep(seconds):
+        sleeps.append(seconds)
+        clock[0] += seconds
+        if clock[0] >= device_done_at:
+            words[0] = 1
+
+    def now():
+        reads[0] += 1
+        clock[0] += 1e-6
+        if clock[0] >= device_done_at:
+            words[0] = 1
+        return clock[0]
+
+    worker._sleep = sleep
+    worker._now = now
+    worker._wait_sequence_by_caller(words, (1,))
+    return (sleeps, reads[0], clock[0])
+
+
+def test_a_caller_that_waits_for_its_own_step_sleeps_once_and_then_watches_the_counter():
+    """codec._Worker._wait_sequence_by_caller (`Ticket.result()` on a step nobody has started on): nothing known -> the counter is
+    watched for the spin budget, then polled; after three waits that agree, ONE sleep up to a third of the budget before the shortest of
+    them and the counter is watched from there (no poll when the step is on time); waits that stop agreeing switch the sleep off."""
+    from autoencoder_based_image_compression_amd import codec
+    worker = codec._Worker(1536, 128, None, -1, 0)
+    (spin, poll) = (codec._RESULT_SPIN_SECONDS, codec._SEQUENCE_POLL_SECONDS)
+    t = 0.
+    (sleeps, reads, t) = _drive_caller_wait(worker, t + 1e-3, t)
+    assert sleeps and all(abs(x - 0.5*poll) < 1e-12 for x in sleeps) and len(sleeps) >= 10     # spun through the budget, then polls
+    for _ in range(2):
+        (sleeps, reads, t) = _drive_caller_wait(worker, t + 1e-3, t)
+    assert len(worker._caller_waits) == 3 and max(worker._caller_waits) < 1.1e-3
+    (sleeps, reads, t) = _drive_caller_wait(worker, t + 1e-3, t)
+    assert len(sleeps) == 1 and abs(sleeps[0] - (min(worker._caller_waits[:2] + (1e-3,)) - spin/3.)) < 1e-4 and 0.8e-3 < sleeps[0] < 1e-3
+    assert reads*1e-6 <= spin                                                                    # the rest of the wait: reads of the counter, under the budget
+    # a step 8 % slower than the last ones: still inside the budget (a sleep, then the counter)
+    (sleeps, reads, t) = _drive_caller_wait(worker, t + 1.08e-3, t)
+    assert len(sleeps) == 1
+    # another regime (steps of 3 ms): the first one is polled to its end, and while the last three waits disagree nothing sleeps long
+    (sleeps, reads, t) = _drive_caller_wait(worker, t + 3e-3, t)
+    assert len(sleeps) > 10 and sleeps[0] < 1e-3
+    (sleeps, reads, t) = _drive_caller_wait(worker, t + 3e-3, t)
+    assert all(abs(x - 0.5*poll) < 1e-12 for x in sleeps)
+    # a step that is through when the caller looks: neither sleep nor spin
+    (sleeps, reads, t) = _drive_caller_wait(worker, t, t)
+    assert sleeps == [] and reads <= 4
+
+
+def test_whoever_claims_a_step_first_forms_its_results_and_nobody_does_it_twice():
+    """`Ticket.result()` on a step the worker has not taken off its queue claims it and forms the results on the calling thread; the
+    worker then finds the job claimed and leaves it alone."""
+    import threading
+    import numpy
+    from autoencoder_based_image_compression_amd import codec
+
+    class View(object):
+        def __init__(self, array):
+            self.array = array
+
+        def numpy(self):
+            return self.array
+
+    worker = codec._Worker(1536, 128, None, -1, 0)            # never started: whatever gets done is done by the caller
+    words = numpy.zeros(2, dtype=numpy.int32)
+    results = numpy.zeros((4, 2*128), dtype=numpy.int32)
+    results[0] = 100
+    results[1] = 3
+    views = [View(results), View(numpy.zeros((0,), dtype=numpy.int32)), View(numpy.zeros(2, dtype=numpy.int32)),
+             View(numpy.ones((2, 128), dtype=numpy.int32)), View(numpy.zeros(1, dtype=numpy.int32)), View(numpy.array([7, 9, 0], dtype=numpy.int64))]
+    ticket = codec.Ticket(2)
+    slot_free = threading.Event()
+    job = codec._Job(ticket, (), views, None, slot_free, None, None, (words, (1, 1)))
+    ticket._job = (job, worker)
+    worker.jobs.put(job)
+    threading.Timer(0.02, lambda: words.__setitem__(slice(None), 1)).start()      # "the device" reports 20 ms from now
+    values = ticket.result()
+    assert slot_free.is_set() and ticket._job is None
+    assert values['nb_bits'].tolist() == [128*103, 128*103] and values['sse'].tolist() == [7, 9] and values['nb_deads'].tolist() == [0, 0]
+    # the worker comes to the job afterwards: claimed, so not processed again
+    calls = []
+    worker.process = lambda job, by_caller=False: calls.append(job)
+    worker.jobs.put(None)
+    worker.run()
+    assert calls == [] and ticket.result() is values
+    # and the other way round: the worker first, the caller only waits
+    ticket2 = codec.Ticket(2)
+    job2 = codec._Job(ticket2, (), views, None, threading.Event(), None, None, (words, (1, 1)))
+    ticket2._job = (job2, worker)
+    del worker.process
+    worker.jobs.put(job2)
+    worker.jobs.put(None)
+    worker.run()
+    assert ticket2._done.is_set() and not job2.claim()
+    assert ticket2.result()['sse'].tolist() == [7, 9]
+
+
 def test_a_step_the_device_never_reports_fails_the_codec(monkeypatch):
     """The sequence wait gives up after EAE_WORKER_SEQUENCE_TIMEOUT_SECONDS with StepTimeout (the codec then refuses further batches:
     nothing says the device is through with the slot's buffers)."""

@@ -68,6 +68,7 @@ _LONG_SLEEP = os.environ.get('EAE_WORKER_LONG_SLEEP', '1') != '0'      # the one
 # without sleeping, for at most this long (seconds of one CPU per call; 0 = never: sleeps and polls like the worker)
 _RESULT_SPIN_SECONDS = float(os.environ.get('EAE_RESULT_SPIN_SECONDS', '0.00015'))
 _RESULT_BY_CALLER = os.environ.get('EAE_RESULT_BY_CALLER', '1') != '0'      # 0: results are always formed by the worker thread (rounds 1-5)
+_EARLY_PUBLISH = os.environ.get('EAE_EARLY_PUBLISH', '1') != '0'            # 0: a small step's analysis-side blocks reach the host with the coder's only
 
 
 def _short_sleeps_for_this_thread():
@@ -207,20 +208,31 @@ class _Worker(threading.Thread):
 
     _caller_waits = ()      # the last waits of `_wait_sequence_by_caller` (seconds)
 
-    def _wait_sequence_by_caller(self, words, expected):
+    def _wait_sequence_by_caller(self, words, expected, early=None):
         """`_wait_sequence` for the thread that called `Ticket.result()` on a step nobody had started on: that thread is blocked
         anyway, so nothing is handed over and what is left is to notice the device's last write as soon as it lands. ONE sleep up to
         shortly before the moment the step is expected to be through -- the shortest of the last three such waits, less a third of the
         spin budget: a lower bound as long as the regime lasts, and a change of regime (another shape of use, steps queued behind each
         other) shows as waits that differ, which switches the sleep off --, then the step counter is read in a loop for at most
-        EAE_RESULT_SPIN_SECONDS of CPU, then polls like the worker's."""
+        EAE_RESULT_SPIN_SECONDS of CPU, then polls like the worker's.
+        early: called once the LAST counter (the synthesis side, which reports long before the coder's chains end when the step is
+        small) has been reached, if that happens inside the sleep: the part of the results that does not come from the coder is
+        formed while the coder still runs (`process`: 0.06 of the 0.09 ms between the device's last write and `result()` returning)."""
         started = self._now()
         waits = self._caller_waits
         steady = _LONG_SLEEP and len(waits) == 3 and max(waits) < 1.25*min(waits)
-        first = (min(waits) - _RESULT_SPIN_SECONDS/3.) if steady else 0.
+        wake = started + (min(waits) - _RESULT_SPIN_SECONDS/3.) if steady else started
         deadline = None
-        if first > _SEQUENCE_POLL_SECONDS:
-            self._sleep(first)
+        if early is not None and len(expected) > 1:
+            last = len(expected) - 1
+            while wake - self._now() > 2.*_SEQUENCE_POLL_SECONDS:
+                if ((int(words[last]) - expected[last]) & 0xFFFFFFFF) < 0x80000000:
+                    early()
+                    early = None
+                    break
+                self._sleep(min(2.*_SEQUENCE_POLL_SECONDS, wake - self._now()))
+        if wake - self._now() > _SEQUENCE_POLL_SECONDS:
+            self._sleep(wake - self._now())
         spin_until = self._now() + _RESULT_SPIN_SECONDS
         for (index, value) in enumerate(expected):
             while ((int(words[index]) - value) & 0xFFFFFFFF) >= 0x80000000:      # words[index] < value, wrap-around safe
@@ -278,13 +290,45 @@ class _Worker(threading.Thread):
     def process(self, job, by_caller=False):
         """Waits until the device is through with the step, then forms the ticket's results from the slot's pinned blocks (or the
         exception `result()` raises), frees the slot. On the worker thread, or on the caller's (`Ticket.result()`)."""
-        (ticket, events, views, symbols_host, slot_free, recount, fetch, sequence) = job.fields
+        (ticket, events, views, symbols_host, slot_free, recount, fetch, sequence) = job.fields[:8]
+        # the synthesis side's publication carried the analysis side's blocks too (exception-map histograms, dead-map flags, range
+        # check): small steps, whose caller waits for each result -- `BatchCodec._early_publish`
+        early_published = len(job.fields) > 8 and bool(job.fields[8])
         try:
             if by_caller and not getattr(_THREAD, 'short_sleeps', False):
                 _short_sleeps_for_this_thread()
                 _THREAD.short_sleeps = True
+            arrays = [v if isinstance(v, numpy.ndarray) else v.numpy() for v in views]
+            (results, hist, overflow, flags, checks, sse) = arrays
+            early = {}
+
+            def early_part():
+                """Everything that does not come from the coder: in pinned memory once the synthesis side has reported, i.e. while the
+                coder's chains still run when the step is small. Nothing is raised from here (the slot is still in use): an
+                exception is kept and raised behind the waits, after the ones the old order put in front of it."""
+                # the last word of the squared-error block: tiles that a cut conv launch of this batch left unfinished
+                # (device.conv_workspace_collect); nothing of this batch can be trusted then
+                early['unfinished'] = int(sse[-1])
+                early['sse'] = sse[:-1].astype(numpy.int64).copy()
+                early['out_of_range'] = int(checks[0]) != 0
+                early['nb_deads'] = (flags == 0).sum(axis=1).astype(numpy.int64)
+                early['exception_bits'] = numpy.zeros(ticket.nb_images, dtype=numpy.int64)
+                try:
+                    if hist.size and early['unfinished'] == 0 and not early['out_of_range']:
+                        rows = hist
+                        if int(overflow.sum()) != 0:
+                            # a symbol beyond +-hist_radius: the reference's histogram runs from the smallest to the largest symbol
+                            # whatever they are (lossless/compression.py:68-75, tools.py:376-388), so count again over all of int16
+                            rows = recount()
+                        early['exception_bits'] = lossless_compression.exception_maps_nb_bits(rows.astype(numpy.int64), self.map_size)
+                except Exception as exc:
+                    early['error'] = exc
+
             if sequence is not None:
-                (self._wait_sequence_by_caller if by_caller else self._wait_sequence)(*sequence)
+                if by_caller:
+                    self._wait_sequence_by_caller(*sequence, early=early_part if early_published else None)
+                else:
+                    self._wait_sequence(*sequence)
             for event in events:
                 self._wait(event)
             if fetch is not None:
@@ -298,13 +342,11 @@ class _Worker(threading.Thread):
                     copied.record()
                 self._wait(copied)
                 ticket.reconstruction_host = pinned.numpy()
-            (results, hist, overflow, flags, checks, sse) = [v.numpy() for v in views]
-            # the last word of the squared-error block: tiles that a cut conv launch of this batch left unfinished
-            # (device.conv_workspace_collect); nothing of this batch can be trusted then
-            (sse, unfinished) = (sse[:-1], int(sse[-1]))
-            if unfinished != 0:
+            if not early:
+                early_part()
+            if early['unfinished'] != 0:
                 raise dev.SplitHandOffTimeout('{} tiles of a cut conv launch were not handed over: the results of this batch '
-                                              'are invalid (the workspace has been reset; later batches are unaffected)'.format(unfinished))
+                                              'are invalid (the workspace has been reset; later batches are unaffected)'.format(early['unfinished']))
             if symbols_host is not None:
                 # encode + decode + compare per map on the host cores, like compress_lossless + the caller's assert
                 (_, nb_bits) = lossless_compression.code_planar_symbols(symbols_host.numpy(), self.host_probabilities,
@@ -318,20 +360,15 @@ class _Worker(threading.Thread):
                     raise AssertionError('\nArrays are not equal\nThe lossless compression has altered the centered quantized data.')
                 from .kodak.lossless import interface_cython
                 interface_cython.raise_for_status(int(results[2, bad]), int(results[3, bad]))
-            if int(checks[0]) != 0:
+            if early['out_of_range']:
                 raise AssertionError('The rounded array elements cannot be represented as 16-bit signed integers.')
+            if 'error' in early:
+                raise early['error']
             n = ticket.nb_images
             coder_bits = (results[0].astype(numpy.int64) + results[1].astype(numpy.int64)).reshape(n, self.nb_maps).sum(axis=1)
-            exception_bits = numpy.zeros(n, dtype=numpy.int64)
-            if hist.size:
-                if int(overflow.sum()) != 0:
-                    # a symbol beyond +-hist_radius: the reference's histogram runs from the smallest to the largest symbol
-                    # whatever they are (lossless/compression.py:68-75, tools.py:376-388), so count again over all of int16
-                    hist = recount()
-                exception_bits = lossless_compression.exception_maps_nb_bits(hist.astype(numpy.int64), self.map_size)
+            exception_bits = early['exception_bits']
             ticket._values = {'nb_bits': coder_bits + exception_bits, 'coder_bits': coder_bits,
-                              'exception_bits': exception_bits, 'sse': sse.astype(numpy.int64).copy(),
-                              'nb_deads': (flags == 0).sum(axis=1).astype(numpy.int64)}
+                              'exception_bits': exception_bits, 'sse': early['sse'], 'nb_deads': early['nb_deads']}
         except StepTimeout as exc:    # nothing says the device is through with this slot: no later submit may reuse it
             self.failed = exc
             ticket._error = exc
@@ -532,6 +569,11 @@ class BatchCodec(object):
         self._coder_streams = [dev.CoderStreams(n_maps, self.map_size, self.truncated_unary_length, self.device,
                                                 results=self._views(self._slot_out[i])[0]) for i in range(self.nb_slots)]
         self._coder_behind_tconv1 = (n_maps > 256) if _CODER_BEHIND_TCONV1 is None else _CODER_BEHIND_TCONV1 != '0'
+        # one or two images per step: the caller usually waits for each result, and what it waits for last is the coder. The analysis
+        # side's blocks (exception-map histograms, dead-map flags, range check) then travel with the synthesis side's publication
+        # already -- one more copy launch on the transform stream, 0.4 ms before the coder ends -- and `Ticket.result()` turns them into
+        # their share of the results while the coder still runs (`_Worker.process`).
+        self._early_publish = n_maps <= 256 and _EARLY_PUBLISH
         self.coder_chunks = int(default_coder_chunks(n_maps) if coder_chunks is None else coder_chunks)
         if self.coder_chunks > 1 and coder != 'device':
             self.coder_chunks = 1
@@ -693,7 +735,7 @@ class BatchCodec(object):
                 self._slot_views[slot] = self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],)
             job = _Job(ticket, () if sequence_mode else (coded, decoded), self._slot_views[slot], None,
                        self._slot_free[slot], lambda: self._recount_exception_maps(slot), self._fetch_job(slot, reconstruction),
-                       (self._seq_host[slot], expected) if sequence_mode else None)
+                       (self._seq_host[slot], expected) if sequence_mode else None, self._early_publish)
             ticket._job = (job, self._worker)
             self._worker.jobs.put(job)
             self._counts[slot] = list(expected)
@@ -794,7 +836,8 @@ class BatchCodec(object):
                 ticket.reconstruction_uint8 = reconstruction
             job = _Job(ticket, () if sequence_mode else (coded, decoded), self._views(self._pinned_out[slot]) + (self._pinned_sse[slot],),
                        self._pinned_symbols[slot], self._slot_free[slot], lambda: self._recount_exception_maps(slot),
-                       self._fetch_job(slot, reconstruction), (self._seq_host[slot], expected) if sequence_mode else None)
+                       self._fetch_job(slot, reconstruction), (self._seq_host[slot], expected) if sequence_mode else None,
+                       self._early_publish)
             ticket._job = (job, self._worker)
             self._worker.jobs.put(job)
             self._counts[slot] = list(expected)
@@ -869,6 +912,12 @@ class BatchCodec(object):
         if self.idx_map_exception >= 0:
             dev.symbol_histograms(self._symbols[slot].view(self._n_maps, self.map_size), self.hist_radius, out=(hist, overflow),
                                   first_map=self.idx_map_exception, map_step=self.nb_maps, zero=False)
+        if self._early_publish:
+            # The analysis side's blocks are final here and reach pinned memory at once (the coder's publication, which also zeroes them
+            # for the slot's next step, copies them again): in FRONT of the event the coder's stream waits for, so the zeroing cannot
+            # overtake this copy. The host looks at them when the synthesis side has reported (`_Worker.process`).
+            first = 4*self._n_maps
+            dev.publish_to_host(self._slot_out[slot][first:], self._pinned_out[slot][first:])
         return q['shifted'] if self.learned else q['t']
 
     def _launch_coder(self, slot, hook=None):

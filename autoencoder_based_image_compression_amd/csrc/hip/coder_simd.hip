@@ -59,7 +59,7 @@ int eae_coder_generic_decode(uint32_t n_maps, uint32_t map_size, int16_t* out, u
 #define EAE_RES_BINARISE 47
 #endif
 #ifndef EAE_RES_ENCODE_CORE
-#define EAE_RES_ENCODE_CORE 47
+#define EAE_RES_ENCODE_CORE 55
 #endif
 #ifndef EAE_RES_EMIT
 #define EAE_RES_EMIT 39
@@ -84,6 +84,7 @@ namespace {
 
 using namespace eae_core;
 using namespace eae_lean;
+
 
 #ifndef EAE_SIMD_PRIO
 #define EAE_SIMD_PRIO 3
@@ -287,35 +288,70 @@ __global__ __launch_bounds__(64) void bac_encode_core_kernel(const SimdParams p)
         steps = j_first + span < steps ? j_first + span : steps;
         if (p.chunk != 0u && in_range) { const uint2 st = p.enc_state[m]; s.lo = st.x; s.hc = st.y; }
     }
-    uint2 ahead = j_first < steps ? *reinterpret_cast<const uint2*>(dec + (size_t)(j_first >> 3) * 512u) : make_uint2(0, 0);
-    for (uint32_t jb = j_first; jb < steps; jb += 8) {
-        const unsigned long long d8 = (unsigned long long)ahead.x | ((unsigned long long)ahead.y << 32);
-        if (jb + 8 < steps) ahead = *reinterpret_cast<const uint2*>(dec + (size_t)((jb >> 3) + 1u) * 512u);
+    // Memory in the loop, and what the loop must NOT wait for (round 6). A round reads eight decision bytes per lane and stores two
+    // 16-byte groups of records; what the chain needs is the decisions of the round in hand, requested two rounds earlier. Every
+    // load and store of the loop is issued unconditionally -- a round beyond the group's last reads the last round again, a lane
+    // with nothing to store stores into the unused tail of its own record region (entries dcap + 8 .. dcap + 11: the stop record
+    // is at most entry dcap, a group store reaches at most dcap + 3) -- because a memory instruction behind a branch makes the
+    // compiler's `s_waitcnt vmcnt` a wait for EVERYTHING in flight: rounds 3-5 had the prefetch and the stores behind `if`s and so
+    // waited at every round for the stores issued a moment earlier (the round as long as a store's way to memory, 1.2 us for
+    // 0.67 us of arithmetic: one Kodak image's core 277 us where the chain is 150).
+    const uint32_t last_round = (steps ? steps - 1u : 0u) >> 3;
+    auto decisions_of = [&](uint32_t round) __attribute__((always_inline)) {
+        return *reinterpret_cast<const uint2*>(dec + (size_t)(round < last_round ? round : last_round) * 512u);
+    };
+    uint32_t* const sink = rec + p.dcap + 8u;
+    const uint32_t nd_here = CHUNKED ? (nd < steps ? nd : steps) : nd;      // (a chunk ends at `steps`; the rounds that pad a trip below must not go on)
+    auto round_of_eight = [&](const uint2& d, uint32_t jb) __attribute__((always_inline)) {
+        const unsigned long long d8 = (unsigned long long)d.x | ((unsigned long long)d.y << 32);
         // the eight probabilities first: they depend on the decisions only, so their LDS latency stays out of the interval's
         // dependency chain (a byte beyond the map's last decision may hold anything: its context is masked into the staged rows'
         // range, the value is never used)
-        double pq[8];
-#pragma unroll
-        for (uint32_t q = 0; q < 8; q++) {
+        auto probability = [&](uint32_t q) __attribute__((always_inline)) {
             const uint32_t ctx = (uint32_t)(d8 >> (8u * q + 1u)) & 31u;
-            pq[q] = probs[(ctx < L ? ctx : 0u) * 64u + lane];
-        }
+            return probs[(ctx < L ? ctx : 0u) * 64u + lane];
+        };
         uint32_t r[8];
-        if (jb + 8u <= nd_all) {
+        if (jb + 8u <= nd_all && jb + 8u <= steps) {
             // every lane that codes at all has these eight decisions: no mask per step (a lane without a map computes on zeros and
             // stores nothing). Two thirds of the rounds of a Kodak batch: a map has at least one decision per symbol.
+            double pq[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) pq[q] = probability(q);
 #pragma unroll
             for (uint32_t q = 0; q < 8; q++) r[q] = encode_step(s, pq[q], ((uint32_t)(d8 >> (8u * q)) & 1u) != 0u);
         } else {
+            // the last rounds of the group's chain: a step only for the lanes that still have one
 #pragma unroll
             for (uint32_t q = 0; q < 8; q++) {
-                r[q] = 0u;
-                if (jb + q < nd) r[q] = encode_step(s, pq[q], ((uint32_t)(d8 >> (8u * q)) & 1u) != 0u);
+                const Interval before = s;
+                const uint32_t rec_q = encode_step(s, probability(q), ((uint32_t)(d8 >> (8u * q)) & 1u) != 0u);
+                const bool has = jb + q < nd_here;
+                s.lo = has ? s.lo : before.lo;
+                s.hc = has ? s.hc : before.hc;
+                r[q] = has ? rec_q : 0u;
             }
         }
         // four records per 16-byte store (up to three entries beyond the map's last decision: the pad of rcap)
-        if (jb < nd) *reinterpret_cast<uint4*>(rec + jb) = make_uint4(r[0], r[1], r[2], r[3]);
-        if (jb + 4u < nd) *reinterpret_cast<uint4*>(rec + jb + 4u) = make_uint4(r[4], r[5], r[6], r[7]);
+        *reinterpret_cast<uint4*>(jb < nd_here ? rec + jb : sink) = make_uint4(r[0], r[1], r[2], r[3]);
+        *reinterpret_cast<uint4*>(jb + 4u < nd_here ? rec + jb + 4u : sink) = make_uint4(r[4], r[5], r[6], r[7]);
+    };
+    // Three rounds per trip, three registers of decisions: each is asked for again the moment its round is through and is used
+    // two rounds later (a register that is reloaded while its old value is still being used would be copied across the loop's back
+    // edge, and a copy of a register in flight is a wait for it). A chain that is not a multiple of three rounds is padded with
+    // empty ones (every step masked, the stores into the sink).
+    uint2 da = decisions_of(j_first >> 3), db = decisions_of((j_first >> 3) + 1u), dc = decisions_of((j_first >> 3) + 2u);
+    // (the first three arrive before the loop: what the loop's own waits count are then the steady state's six memory operations
+    // between a request and its use, not the two of the first trip)
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    for (uint32_t jb = j_first; jb < steps; jb += 24) {
+        const uint32_t round = jb >> 3;
+        round_of_eight(da, jb);
+        da = decisions_of(round + 3u);
+        round_of_eight(db, jb + 8u);
+        db = decisions_of(round + 4u);
+        round_of_eight(dc, jb + 16u);
+        dc = decisions_of(round + 5u);
     }
     if (live) {
         if (retry) p.status[m] = RETRY;                 // the general kernel reproduces the exact code and stage

@@ -60,9 +60,15 @@ int main() {
     for (int blocks : {1, 256, 1024}) {
         std::vector<uint32_t> o0(blocks * 64), o1(blocks * 64);
         std::vector<long long> c0(blocks), c1(blocks);
+        float ms0 = 0.f;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         for (int rep = 0; rep < 2; rep++) {
+            CK(hipEventRecord(e0, 0));
             hipLaunchKernelGGL(chain_kernel<0>, dim3(blocks), dim3(64), 0, 0, dp, db, steps, dout, dcy);
+            CK(hipEventRecord(e1, 0));
             CK(hipDeviceSynchronize());
+            CK(hipEventElapsedTime(&ms0, e0, e1));
             CK(hipMemcpy(o0.data(), dout, blocks * 256, hipMemcpyDeviceToHost)); CK(hipMemcpy(c0.data(), dcy, blocks * 8, hipMemcpyDeviceToHost));
             hipLaunchKernelGGL(chain_kernel<1>, dim3(blocks), dim3(64), 0, 0, dp, db, steps, dout, dcy);
             CK(hipDeviceSynchronize());
@@ -70,8 +76,9 @@ int main() {
         }
         int differ = 0;
         for (int i = 0; i < 64; i++) differ += o0[i] != o1[i];
-        std::printf("%4d wave(s): FP64 form %.1f cycles per decision, integer form %.1f (clock64 ticks / %d steps; lanes whose results differ: %d of 64 -- 48-bit P unverified here)\n",
-                    blocks, c0[0] / (double)steps, c1[0] / (double)steps, steps, differ);
+        std::printf("%4d wave(s): FP64 form %.1f cycles per decision, integer form %.1f (clock64 ticks / %d steps; lanes whose results differ: %d of 64 -- 48-bit P unverified here); "
+                    "FP64 launch %.3f ms by HIP events = %.1f ns per decision = %.2f GHz if a tick is a cycle\n",
+                    blocks, c0[0] / (double)steps, c1[0] / (double)steps, steps, differ, ms0, ms0 * 1e6 / steps, (c0[0] / (double)steps) / (ms0 * 1e6 / steps));
     }
     return 0;
 }

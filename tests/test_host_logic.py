@@ -486,6 +486,50 @@ def test_a_caller_that_waits_for_its_own_step_sleeps_once_and_then_watches_the_c
     assert sleeps == [] and reads <= 4
 
 
+def test_the_part_of_the_results_that_does_not_wait_for_the_coder_is_formed_while_the_coder_runs():
+    """`_wait_sequence_by_caller(..., early=)`: once the regime is steady, the synthesis side's counter (the last word) is polled
+    during the long sleep and `early` runs as soon as it has been reached -- well before the coder's counter moves --; without a
+    steady regime the wait does not call it (`process` does, behind the waits)."""
+    import numpy
+    from autoencoder_based_image_compression_amd import codec
+    worker = codec._Worker(1536, 128, None, -1, 0)
+
+    def drive(synthesis_at, coder_at, start):
+        clock = [start]
+        words = numpy.zeros(2, dtype=numpy.int32)
+        called = []
+
+        def tick():
+            if clock[0] >= synthesis_at:
+                words[1] = 1
+            if clock[0] >= coder_at:
+                words[0] = 1
+
+        def sleep(seconds):
+            clock[0] += seconds
+            tick()
+
+        def now():
+            clock[0] += 1e-6
+            tick()
+            return clock[0]
+
+        worker._sleep = sleep
+        worker._now = now
+        worker._wait_sequence_by_caller(words, (1, 1), early=lambda: called.append(clock[0]))
+        return (called, clock[0])
+
+    t = 0.
+    for _ in range(3):                                        # nothing known yet: the wait never calls `early`
+        (called, t) = drive(t + 0.4e-3, t + 1e-3, t)
+        assert called == []
+    (called, t2) = drive(t + 0.4e-3, t + 1e-3, t)             # steady: called once, between the two reports
+    assert len(called) == 1 and t + 0.4e-3 <= called[0] < t + 0.7e-3 and t2 >= t + 1e-3
+    t = t2
+    (called, t2) = drive(t + 0.99e-3, t + 1e-3, t)            # the synthesis side reports inside the spin: left to `process`
+    assert called == []
+
+
 def test_whoever_claims_a_step_first_forms_its_results_and_nobody_does_it_twice():
     """`Ticket.result()` on a step the worker has not taken off its queue claims it and forms the results on the calling thread; the
     worker then finds the job claimed and leaves it alone."""

@@ -70,6 +70,9 @@ int eae_coder_generic_decode(uint32_t n_maps, uint32_t map_size, int16_t* out, u
 #ifndef EAE_RES_DEBINARISE
 #define EAE_RES_DEBINARISE 23
 #endif
+#ifndef EAE_RES_DEBINARISE_STAGED
+#define EAE_RES_DEBINARISE_STAGED 39
+#endif
 #ifndef EAE_RES_DECODE_CORE_CHUNKED
 #define EAE_RES_DECODE_CORE_CHUNKED 63      // the resumable form of the decoder core (a parked state to load and store)
 #endif
@@ -94,6 +97,8 @@ constexpr int32_t RETRY = -100;           // internal: recode this map with the 
 constexpr uint32_t kMaxFastL = 32;        // contexts staged in LDS: 33 x 64 lanes x 8 B = 17 KB
 constexpr uint32_t kRecordPad = 12;       // records beyond a map's decisions: the stop record + the tail of the last 16-byte store
 constexpr uint32_t kRing = 32;            // decoder: stream words per lane in LDS (a step takes <= 30 bits: 8 steps <= 8 words)
+constexpr uint32_t kBypassStage = 512;    // debinarise: words of a map's bypass stream staged in LDS (a multiple of 512: 16,384 bits, several times a map's at 3 bpp)
+constexpr uint32_t kDebinariseStage = 1024;      // debinarise: prefix bytes / expected symbols staged in LDS at a time (5.6 KB of LDS per wavefront in all)
 constexpr uint32_t kEmitWords = 224;      // emit: 64-bit words of one tile of 256 records in LDS (56 bits per record on average: beyond that the general kernel)
 
 struct SimdParams {
@@ -783,8 +788,9 @@ extern "C" int eae_hip_debug_hwid_probe(unsigned int* out8) {
 // ---------------------------------------------------------------------------------------------------------------------
 // (5) one wavefront per map: prefixes + bypass stream -> symbols; compare with the encoder's input
 // ---------------------------------------------------------------------------------------------------------------------
+template <bool STAGED>
 __global__ __launch_bounds__(64) void debinarise_kernel(const SimdParams p) {
-    EAE_KEEP_LAST_VGPR_FREE(EAE_RES_DEBINARISE);
+    if (STAGED) { EAE_KEEP_LAST_VGPR_FREE(EAE_RES_DEBINARISE_STAGED); } else { EAE_KEEP_LAST_VGPR_FREE(EAE_RES_DEBINARISE); }
     __shared__ uint32_t ytile[80];                     // the bypass words a tile of 64 symbols can touch: 64 x 34 bits + alignment
     const uint32_t m = blockIdx.x, lane = threadIdx.x;
     const int32_t row = p.prob_row ? p.prob_row[m] : (int32_t)m;
@@ -802,19 +808,73 @@ __global__ __launch_bounds__(64) void debinarise_kernel(const SimdParams p) {
     int16_t* out = p.decoded ? p.decoded + (size_t)m * size : nullptr;
     uint32_t ybase = 0;                                // bypass bits consumed so far
     bool bad = false, differ = false;
+    // STAGED (small steps: eae_hip_coder_decode_batch): everything the tile loop reads comes through LDS -- the first kBypassStage
+    // words of the bypass stream once (a map whose bypass stream is longer reads the rest tile by tile from memory), prefix bytes
+    // and expected symbols 1,024 symbols at a time, loads clamped instead of masked, eight per lane in flight. With its loads inside
+    // the tile loop a tile begins by waiting for them and -- the compiler can only wait for everything in flight -- for the stores
+    // of the tile before: 1 us per tile, 25 us for the 24 tiles of a Kodak map where the staged form takes 16. For large batches
+    // (thousands of these wavefronts at once, their latency hidden by each other) the plain form is kept: the staged one's 5.6 KB of
+    // LDS and 40 registers cost conv_2 3 % when it runs beside it (profiles/r06_coder_cores.md).
+    __shared__ uint32_t ystage[STAGED ? kBypassStage + 80u : 1u];
+    __shared__ uint8_t pstage[STAGED ? kDebinariseStage : 1u];
+    __shared__ int16_t estage[STAGED ? kDebinariseStage : 1u];
+    if (STAGED) {
+        const uint32_t have = ywords < kBypassStage ? ywords : kBypassStage, last = ywords ? ywords - 1u : 0u;
+        for (uint32_t k = 0; k < have; k += 512u) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+                const uint32_t w = k + u * 64u + lane;
+                v[u] = gbyp[w < last ? w : last];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+                const uint32_t w = k + u * 64u + lane;
+                if (w < kBypassStage) ystage[w] = w < ywords ? v[u] : 0u;
+            }
+        }
+        // zero beyond the stream (what a tile's window may still read), up to the end of the staging area
+        for (uint32_t w = have + lane; w < kBypassStage + 80u; w += 64u) ystage[w] = 0u;
+    }
     for (uint32_t t = 0; t < size; t += 64u) {
-        // the window of the bypass stream this tile can touch, zero beyond the stream
+        if (STAGED && (t & (kDebinariseStage - 1u)) == 0u) {
+            const uint32_t last = size - 1u;
+            __syncthreads();                                   // (one wavefront: the reads of the last chunk are before these writes)
+            for (uint32_t k = 0; k < kDebinariseStage && t + k < size; k += 512u) {
+                uint8_t pv[8];
+                int16_t ev[8];
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) {
+                    const uint32_t i = t + k + u * 64u + lane, at_i = i < last ? i : last;
+                    pv[u] = prefix[at_i];
+                    ev[u] = expected ? expected[at_i] : (int16_t)0;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 8; u++) {
+                    pstage[k + u * 64u + lane] = pv[u];
+                    estage[k + u * 64u + lane] = ev[u];
+                }
+            }
+            __syncthreads();
+        }
+        // the window of the bypass stream this tile can touch, zero beyond the stream: inside the staged words, or (long streams)
+        // loaded for this tile
         const uint32_t w0 = ybase >> 5;
-        ytile[lane] = w0 + lane < ywords ? gbyp[w0 + lane] : 0u;
-        if (lane < 16u) ytile[64u + lane] = w0 + 64u + lane < ywords ? gbyp[w0 + 64u + lane] : 0u;
+        // (a window is words w0 .. w0 + 79: staged, or zero behind a stream that was staged whole)
+        const bool in_stage = STAGED && (ywords <= kBypassStage ? w0 <= kBypassStage : w0 + 80u <= kBypassStage);
+        if (!in_stage) {
+            ytile[lane] = w0 + lane < ywords ? gbyp[w0 + lane] : 0u;
+            if (lane < 16u) ytile[64u + lane] = w0 + 64u + lane < ywords ? gbyp[w0 + 64u + lane] : 0u;
+        }
+        const uint32_t* const window = in_stage ? ystage + w0 : ytile;
         auto bits_at = [&](uint32_t pos) {             // 32 stream bits from position `pos`, the first in time at bit 0
             const uint32_t rel = pos - (w0 << 5), q = rel >> 5, sh = rel & 31u;
-            const unsigned long long two = (unsigned long long)ytile[q] | ((unsigned long long)ytile[q + 1u] << 32);
+            const unsigned long long two = (unsigned long long)window[q] | ((unsigned long long)window[q + 1u] << 32);
             return (uint32_t)(two >> sh);
         };
         const uint32_t i = t + lane;
         const bool valid = i < size;
-        uint32_t a = valid ? (uint32_t)prefix[i] : 0u;
+        uint32_t a = valid ? (uint32_t)(STAGED ? pstage[i & (kDebinariseStage - 1u)] : prefix[i]) : 0u;
         const bool nonzero = a != 0u;
         uint32_t ntot;
         uint32_t at = wave_exclusive_scan(nonzero ? 1u : 0u, ntot);      // sign bits of the symbols below this lane ...
@@ -846,7 +906,7 @@ __global__ __launch_bounds__(64) void debinarise_kernel(const SimdParams p) {
         if (nonzero && !(bits_at(spos) & 1u)) v = -v;
         if (valid) {
             if (out) out[i] = (int16_t)v;
-            if (expected && expected[i] != (int16_t)v) differ = true;
+            if (expected && (STAGED ? estage[i & (kDebinariseStage - 1u)] : expected[i]) != (int16_t)v) differ = true;
         }
         ybase += ntot + extra_tot;
     }
@@ -1432,7 +1492,9 @@ int eae_hip_coder_decode_batch(uint32_t n_maps, uint32_t map_size, int16_t* symb
     const bool fast = fast_applies(L) && map_size && have_ws && !check_simd_layout(map_size, L, streams, stride);
     if (fast) {
         hipLaunchKernelGGL(bac_decode_core_kernel<false>, dim3((n_maps + 63u) / 64u), dim3(64), decode_lds_bytes(L), s, p);
-        hipLaunchKernelGGL(debinarise_kernel, dim3(n_maps), dim3(64), 0, s, p);
+        // (small steps: the staged form, whose tile loop waits for no memory; see the kernel)
+        if (n_maps <= 256u) hipLaunchKernelGGL(debinarise_kernel<true>, dim3(n_maps), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL(debinarise_kernel<false>, dim3(n_maps), dim3(64), 0, s, p);
     } else {
         hipLaunchKernelGGL(mark_kernel, dim3((n_maps + 255u) / 256u), dim3(256), 0, s, p);
     }
@@ -1571,7 +1633,7 @@ int eae_hip_coder_roundtrip_trailing(uint32_t n_maps, uint32_t map_size, const i
         d.chunk = chunks - 2u;
         d.nchunks = chunks - 1u;
         hipLaunchKernelGGL(bac_decode_core_kernel<true>, per_group, wave, decode_lds_bytes(L), t->decode, d);
-        hipLaunchKernelGGL(debinarise_kernel, per_map, wave, 0, t->decode, d);
+        hipLaunchKernelGGL(debinarise_kernel<false>, per_map, wave, 0, t->decode, d);
         rc = eae_coder_generic_decode(n_maps, map_size, d.decoded, L, probs, prob_row, streams, stride, bac_bits, bypass_bits, status, stage,
                                       RETRY, t->decode);
         if (rc) return trailing_join(t, s, rc);
@@ -1607,7 +1669,7 @@ int eae_hip_coder_roundtrip_fused(uint32_t n_maps, uint32_t map_size, const int1
     int rc = eae_coder_generic_encode(n_maps, map_size, symbols, L, probs, prob_row, streams, stride, bac_bits, bypass_bits, status, stage, RETRY, s);
     if (rc) return rc;
     hipLaunchKernelGGL(pipe_restore_kernel, flat, dim3(256), 0, s, p);
-    hipLaunchKernelGGL(debinarise_kernel, per_map, wave, 0, s, p);
+    hipLaunchKernelGGL(debinarise_kernel<false>, per_map, wave, 0, s, p);
     rc = eae_coder_generic_decode(n_maps, map_size, p.decoded, L, probs, prob_row, streams, stride, bac_bits, bypass_bits, status, stage, RETRY, s);
     if (rc) return rc;
     hipLaunchKernelGGL(compare_kernel, per_map, wave, 0, s, p);

@@ -515,6 +515,49 @@ def test_steps_on_one_stream_give_the_same_results(graphs, batch):
     assert sum(int(r['nb_bits'].sum()) for r in results[True]) > 0
 
 
+@pytest.mark.parametrize('graphs', [False, True])
+@pytest.mark.parametrize('by_caller, early', [(False, False), (True, False), (True, True), (False, True)])
+def test_who_forms_the_results_and_when_changes_nothing(graphs, by_caller, early, monkeypatch):
+    """Small steps (round 6): the results formed by the worker thread or by the thread that called `result()` (`codec._Job`), with the
+    analysis side's blocks published at the end of the step or ahead of the coder (`BatchCodec._early_publish`: exception-map bits,
+    dead-map counts and squared errors then formed while the coder still runs): every combination gives the same values, one step
+    at a time and with steps in flight, with an exception map whose histogram overflows its radius on the way (the recount
+    path) -- and the range-check error still arrives as the reference's AssertionError."""
+    from autoencoder_based_image_compression_amd import codec
+    import bench
+    with numpy.load(GOLD) as g:
+        probabilities = g['real_probabilities_1']
+    variables = bench.synthetic_model(0.25)
+    images = torch.from_numpy(bench.synthetic_images(13, 4, 128, 192)).cuda()
+    mean = numpy.zeros(128, dtype=numpy.float32)
+    kwargs = {'nb_in_flight': 3, 'nb_transform_streams': 3, 'use_graphs': True} if graphs else {}
+
+    def run(publishes_early):
+        with codec.BatchCodec(variables, False, variables['piecewise_linear_function/bin_widths'], mean, probabilities, 67, 1, 128, 192,
+                              hist_radius=2, **kwargs) as c:                      # (radius 2: the exception map's histogram overflows, `recount`)
+            assert c._early_publish == publishes_early
+            one_at_a_time = [c.submit(images[j:j + 1]).result() for j in [0, 1, 2, 3]*4]
+            tickets = [c.submit(images[j:j + 1]) for j in [3, 2, 1, 0]*3]
+            return one_at_a_time + [t.result() for t in tickets]
+
+    monkeypatch.setattr(codec, '_RESULT_BY_CALLER', False)
+    monkeypatch.setattr(codec, '_EARLY_PUBLISH', False)
+    want = run(False)
+    monkeypatch.setattr(codec, '_RESULT_BY_CALLER', by_caller)
+    monkeypatch.setattr(codec, '_EARLY_PUBLISH', early)
+    got = run(early)
+    assert len(got) == len(want) == 28
+    for (a, b) in zip(want, got):
+        assert sorted(a) == sorted(b) and all(numpy.array_equal(a[k], b[k]) for k in a)
+    assert sum(int(r['exception_bits'].sum()) for r in got) > 0
+    # the range check of the quantiser (tools.py:130-132) through the same path: a bin width that takes symbols out of int16
+    tiny = dict(variables)
+    tiny['piecewise_linear_function/bin_widths'] = numpy.full(128, 1e-7, dtype=numpy.float32)
+    with codec.BatchCodec(tiny, False, tiny['piecewise_linear_function/bin_widths'], mean, probabilities, 67, 1, 128, 192, **kwargs) as c:
+        with pytest.raises(AssertionError, match='16-bit signed integers'):
+            c.submit(images[0:1]).result()
+
+
 @pytest.mark.parametrize('words', [2, 50, 4096, 300001])
 def test_publish_step_copies_clears_and_counts(words):
     """include/eae_hip.h: eae_hip_publish_step on its own -- the block reaches pinned memory whole, the source is zeroed from `clear_from`

@@ -258,6 +258,37 @@ def test_batch_encoder_and_decoder_equal_the_host_coder(gold, dev, scale):
     assert status[5] != 0 and not numpy.delete(status, 5).any()
 
 
+@pytest.mark.parametrize('n', [70, 256, 257])
+def test_batch_decoder_small_steps_long_bypass_streams(gold, dev, n):
+    """The data-parallel pass behind the decoder core has two forms (round 6): at most 256 maps -> `debinarise_kernel<true>`, which
+    stages prefix bytes and expected symbols 1,024 at a time and the first 512 words of the bypass stream in LDS (longer streams: the
+    rest tile by tile from memory); more -> the plain form. Maps of 2,500 symbols (two chunk boundaries and a ragged chunk), bypass
+    streams from a few bits to thousands of words in one batch, a ragged last group: symbols and statuses equal the host coder's."""
+    rng = numpy.random.RandomState(n)
+    probs = gold['real_probabilities_1']
+    scale = rng.choice([0.05, 0.5, 5., 300., 3000.], size=(n, 1))
+    planar = numpy.clip(numpy.round(rng.laplace(size=(n, 2500))*scale), -32768, 32767).astype(numpy.int16)
+    prob_row = (numpy.arange(n) % 128).astype(numpy.int32)
+    prob_row[67::128] = -1
+    (streams, sym, p, rows) = batch_code(dev, planar, probs, prob_row)
+    assert assert_equals_host(streams, planar, probs, prob_row, n).all()
+    bypass_words = (streams.bypass_bits.cpu().numpy().astype(numpy.int64) + 31)//32
+    assert bypass_words.max() > 1500 and bypass_words[prob_row >= 0].min() < 64       # both sides of the 512 staged words
+    keep = prob_row >= 0
+    ws = dev.coder_workspace(n, 2500, probs.shape[1], 'cuda')
+    out = dev.coder_decode_batch(streams, p, rows, workspace=ws).cpu().numpy()
+    assert not streams.status.cpu().numpy().any()
+    assert numpy.array_equal(out[keep], planar[keep])
+    dev.coder_decode_batch(streams, p, rows, expected=sym, workspace=ws)
+    assert not streams.status.cpu().numpy().any()
+    other = sym.clone()
+    other[3, 2499] += 1                                         # the last symbol of the ragged chunk
+    other[5, 1024] -= 1                                         # the first symbol of the second chunk
+    dev.coder_decode_batch(streams, p, rows, expected=other, workspace=ws)
+    status = streams.status.cpu().numpy()
+    assert status[3] == 6 and status[5] == 6 and not numpy.delete(status, [3, 5]).any()
+
+
 def test_batch_large_maps_long_pending_runs_and_every_window_tier(gold, dev):
     """Maps of 128 x 128 latents (a 2048 x 2048 image): near-dead maps under a very skewed p0 build runs of pending E3 bits far
     beyond 47 (emit_kernel's long-queue path and its give-up to the general kernel), and the stream lengths run from a few words

@@ -652,6 +652,16 @@ def main(args):
     # that kernel's own next to nothing but the coder's side streams ------------------------------------------------------
     roof = run_pipeline(ctx, args.batch, min(args.steps, 30), min(args.warmup, 5), variables, h_in, w_in, coder=args.coder,
                         coder_streams=min(coder_streams, 3), transform_streams=1, use_graphs=False, min_seconds=0.3, max_blocks=5, record=True)
+    # (the same leg with the transforms ALONE, rank 0 of a one-GPU run: what each kernel reaches of its roof without the coder's
+    # long-lived waves beside it -- `roofline.transforms_alone`; `roofline` itself stays the path as it runs)
+    roof_alone = None
+    if world == 1 and not args.no_single_image and not os.environ.get('EAE_BENCH_NO_CODER'):
+        os.environ['EAE_BENCH_NO_CODER'] = '1'
+        try:
+            roof_alone = run_pipeline(ctx, args.batch, min(args.steps, 30), min(args.warmup, 5), variables, h_in, w_in, coder=args.coder,
+                                      coder_streams=min(coder_streams, 3), transform_streams=1, use_graphs=False, min_seconds=0.3, max_blocks=5, record=True)
+        finally:
+            del os.environ['EAE_BENCH_NO_CODER']
     # ---- the headline: the product's default mode (three transform streams, the step replayed as hipGraphs) -------------
     run = run_pipeline(ctx, args.batch, args.steps, args.warmup, variables, h_in, w_in, coder=args.coder, coder_streams=coder_streams,
                        transform_streams=args.transform_streams, use_graphs=args.graphs, min_seconds=args.min_seconds,
@@ -678,6 +688,18 @@ def main(args):
                           'command at the default shape, committed with the profile summaries -- a constant of the build, not measured by this run')
     blocks = run['block_seconds']
     roof_ms = roof['elapsed']/min(args.steps, 30)*1e3
+    transforms_alone = None
+    if roof_alone is not None:
+        (pk_a, ms_a, fl_a) = launch_rooflines(roof_alone['events'], pixels_per_step, args.fuse_latent, args.batch*128*(h_in//16)*(w_in//16))
+        g_a = {k: v for (k, v) in ms_a.items() if k in GEMM_LAUNCHES}
+        g_a_ms = sum(sum(v) for v in g_a.values())
+        g_a_flop = sum(fl_a[k]*pixels_per_step*len(v) for (k, v) in g_a.items())
+        transforms_alone = {'note': 'the same launch-by-launch leg with no coder launched (EAE_BENCH_NO_CODER=1): each kernel without the coder\'s waves beside it',
+                            'achieved': round(g_a_flop/(g_a_ms*1e-3)/1e12, 3) if g_a_ms > 0 else 0.,
+                            'frac': round(g_a_flop/(g_a_ms*1e-3)/1e12/PEAK_F32_MFMA_TFLOPS, 4) if g_a_ms > 0 else 0.,
+                            'one_stream_ms_per_step': round(roof_alone['elapsed']/min(args.steps, 30)*1e3, 4),
+                            'per_kernel': {k: {'avg_ms': v['avg_ms'], 'frac': v.get('frac')} for (k, v) in pk_a.items() if not k.startswith('coder')}}
+        del roof_alone
     line = {
         'metric': 'Mpixels/s encode+decode ({0} {1}x{2} luma), bitstream bit-exact'.format(
             'Kodak' if (h_in, w_in) == (512, 768) else 'synthetic', w_in, h_in),
@@ -716,7 +738,7 @@ def main(args):
                      'per_launch_frac': {k: round(flops[k]*pixels_per_step/(sum(v)/len(v)*1e-3)/1e12/PEAK_F32_MFMA_TFLOPS, 4)
                                          for (k, v) in gemm.items()},
                      'algorithmic_flop_per_launch': {k: flops[k]*pixels_per_step for k in GEMM_LAUNCHES},
-                     'per_kernel': per_kernel, 'peak_hbm_tbytes_per_s': PEAK_HBM_TBS},
+                     'per_kernel': per_kernel, 'peak_hbm_tbytes_per_s': PEAK_HBM_TBS, 'transforms_alone': transforms_alone},
     }
     line['exchange'] = args.exchange
     # a scaling curve needs one GPU per rank: ranks sharing a GPU (EAE_BENCH_SHARE_GPU) or a single rank measure none

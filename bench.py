@@ -655,7 +655,7 @@ def main(args):
     # (the same leg with the transforms ALONE, rank 0 of a one-GPU run: what each kernel reaches of its roof without the coder's
     # long-lived waves beside it -- `roofline.transforms_alone`; `roofline` itself stays the path as it runs)
     roof_alone = None
-    if world == 1 and not args.no_single_image and not os.environ.get('EAE_BENCH_NO_CODER'):
+    if world == 1 and not os.environ.get('EAE_BENCH_NO_CODER'):
         os.environ['EAE_BENCH_NO_CODER'] = '1'
         try:
             roof_alone = run_pipeline(ctx, args.batch, min(args.steps, 30), min(args.warmup, 5), variables, h_in, w_in, coder=args.coder,

@@ -58,6 +58,9 @@ def parse_args(argv=None):
                              '`idx_map_exception.pkl` and `binary_probabilities_<multiplier>.npy` (lossless/stats.py:243-320; e.g. the '
                              'reference\'s lossless/results/1_10000/training_index_10/)')
     parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--no-transforms-alone', action='store_true',
+                        help='skip the second launch-by-launch leg (the transforms without the coder: `roofline.transforms_alone`); the profile commands of '
+                             'scratch/r06/collect_final.sh pass it so that a kernel\'s rocprofv3 average is over the launches `roofline` itself times')
     parser.add_argument('--no-dropin-surface', action='store_true',
                         help='skip the `dropin_surface` leg (the mirror of the reference\'s fix_gamma through the reference\'s own call '
                              'surface: numpy in, numpy out, batch_size 4)')
@@ -655,7 +658,7 @@ def main(args):
     # (the same leg with the transforms ALONE, rank 0 of a one-GPU run: what each kernel reaches of its roof without the coder's
     # long-lived waves beside it -- `roofline.transforms_alone`; `roofline` itself stays the path as it runs)
     roof_alone = None
-    if world == 1 and not os.environ.get('EAE_BENCH_NO_CODER'):
+    if world == 1 and not args.no_transforms_alone and not os.environ.get('EAE_BENCH_NO_CODER'):
         os.environ['EAE_BENCH_NO_CODER'] = '1'
         try:
             roof_alone = run_pipeline(ctx, args.batch, min(args.steps, 30), min(args.warmup, 5), variables, h_in, w_in, coder=args.coder,

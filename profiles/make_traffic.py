@@ -85,7 +85,7 @@ def main():
     result['hbm_bytes_per_launch'] = sum(result[n]['hbm_read_bytes'] + result[n]['hbm_write_bytes'] for n in names)/4.
     result['algorithmic_bytes_per_launch'] = sum(algorithmic.values())/4.
     result['note'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE (separate passes) on `python3 bench.py '
-                      '--steps 3 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-side --transform-streams 1 --no-graphs --coder-streams 3` (batch {}; scratch/r06/collect_final.sh); counters are in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md '
+                      '--steps 3 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-side --no-dropin-surface --no-transforms-alone --transform-streams 1 --no-graphs --coder-streams 3` (batch {}; scratch/r06/collect_final.sh); counters are in KB; FETCH_SIZE doubled per MI355X_MICROARCH.md '
                       '(16-B/lane loads are tallied at half); FETCH_SIZE counts L2 misses including Infinity Cache hits; per-launch average '
                       'over the four conv GEMM launches of a step. MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs).'
                       .format(batch))

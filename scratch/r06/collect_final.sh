@@ -8,14 +8,14 @@ mkdir -p $OUT
 python bench.py --steps 20 --warmup 10 > $OUT/bench_driver_cmd.json 2> $OUT/bench_driver_cmd.err
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_onestream -- python3 $ROOT/bench.py --no-cpu-baseline --no-side --no-dropin-surface --transform-streams 1 --no-graphs --coder-streams 3 --steps 30 --warmup 5 --min-seconds 0 --max-blocks 1 > $OUT/bench_onestream_under_rocprof.json 2> $OUT/trace_onestream.err
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_product -- python3 $ROOT/bench.py --no-cpu-baseline --no-side --no-dropin-surface --steps 30 --warmup 5 --min-seconds 0 --max-blocks 1 > $OUT/bench_product_under_rocprof.json 2> $OUT/trace_product.err
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_onestream -- python3 $ROOT/bench.py --no-cpu-baseline --no-side --no-dropin-surface --no-transforms-alone --transform-streams 1 --no-graphs --coder-streams 3 --steps 30 --warmup 5 --min-seconds 0 --max-blocks 1 > $OUT/bench_onestream_under_rocprof.json 2> $OUT/trace_onestream.err
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_product -- python3 $ROOT/bench.py --no-cpu-baseline --no-side --no-dropin-surface --no-transforms-alone --steps 30 --warmup 5 --min-seconds 0 --max-blocks 1 > $OUT/bench_product_under_rocprof.json 2> $OUT/trace_product.err
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" \
             "insts:SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
             "active:SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
             "wait:SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_LDS"; do
   name=${pass%%:*}; counters=${pass#*:}
-  timeout 400 rocprofv3 --pmc $counters --output-format csv -d $OUT/pmc_$name -- python3 $ROOT/bench.py --steps 3 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-side --no-dropin-surface --transform-streams 1 --no-graphs --coder-streams 3 > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
+  timeout 400 rocprofv3 --pmc $counters --output-format csv -d $OUT/pmc_$name -- python3 $ROOT/bench.py --steps 3 --warmup 1 --min-seconds 0 --no-cpu-baseline --no-side --no-dropin-surface --no-transforms-alone --transform-streams 1 --no-graphs --coder-streams 3 > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
   echo "pmc pass $name rc=$?"
 done
 cd $ROOT

@@ -573,7 +573,8 @@ class BatchCodec(object):
         # side's blocks (exception-map histograms, dead-map flags, range check) then travel with the synthesis side's publication
         # already -- one more copy launch on the transform stream, 0.4 ms before the coder ends -- and `Ticket.result()` turns them into
         # their share of the results while the coder still runs (`_Worker.process`).
-        self._early_publish = n_maps <= 256 and _EARLY_PUBLISH
+        # (not with `one_stream_steps`: that mode is for many small steps in flight, where the launching thread's time per step is the rate)
+        self._early_publish = n_maps <= 256 and _EARLY_PUBLISH and not one_stream_steps
         self.coder_chunks = int(default_coder_chunks(n_maps) if coder_chunks is None else coder_chunks)
         if self.coder_chunks > 1 and coder != 'device':
             self.coder_chunks = 1

@@ -887,7 +887,7 @@ def single_image_pipelined_leg(ctx, variables, h, w, steps=1000):
     thread's work per step."""
     # first, with nothing else in the process: ONE image at a time, each waited for before the next is submitted (the default schedule,
     # coder beside the synthesis transform) -- `Ticket.result()` finds the step unclaimed and waits for the device itself (codec._Job)
-    alone = run_pipeline(ctx, 1, 100, 10, variables, h, w, coder_streams=1, transform_streams=1, use_graphs=True, serial=True, min_seconds=0.5, max_blocks=9)
+    alone = run_pipeline(ctx, 1, 100, 10, variables, h, w, coder_streams=1, transform_streams=1, use_graphs=True, serial=True, min_seconds=1.5, max_blocks=21)
     streams = max(2, min(20, int(os.environ.get('GPU_MAX_HW_QUEUES', '4')) - 2))      # 14 / 20 streams with 16 / 24 queues: 0.250 / 0.228 ms per image; 28 with 32: 0.53
     one = run_pipeline(ctx, 1, steps, 30, variables, h, w, coder_streams=streams, transform_streams=streams, use_graphs=True, one_stream_steps=True)
     return {'ms_per_image': round(one['elapsed']/steps*1e3, 4), 'mpixels_per_s': round(steps*h*w/one['elapsed']/1e6, 2), 'steps': steps, 'warmup': 30,

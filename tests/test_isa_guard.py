@@ -130,6 +130,50 @@ def test_allocations_from_the_shipped_metadata(library):
     assert not any('latent_wave_kernelILb1ELb1' in k for k in alloc)       # kernels with AccVGPRs are left out: their top registers are accumulators
 
 
+def test_the_encoder_core_does_not_wait_for_its_own_stores():
+    """Round 6: a memory instruction behind a branch makes the compiler's `s_waitcnt vmcnt` a wait for everything in flight, and the
+    encoder core's loop had its prefetch and its record stores behind `if`s: every round of eight decisions waited for the stores
+    issued a moment earlier (277 us for one Kodak image's core where the chain is 150). The shipped loop must wait with a COUNT --
+    three rounds per trip, each round's decisions requested two rounds ahead: six memory operations between a request and its use."""
+    import re
+    import isa_guard
+    lib = os.path.join(ROOT, 'autoencoder_based_image_compression_amd', 'lib', 'libeae_hip.so')
+    if not os.path.isfile(lib):
+        pytest.skip('libeae_hip.so not built')
+    body = None
+    for blob in isa_guard.code_objects(lib):
+        text = isa_guard.disassemble(blob)
+        if 'bac_encode_core_kernelILb0E' not in text:
+            continue
+        (lines, take) = ([], False)
+        for line in text.split('\n'):
+            if re.match(r'^[0-9a-f]+ <.*>:$', line):
+                take = 'bac_encode_core_kernelILb0E' in line
+            elif take:
+                lines.append(line)
+        body = lines
+    assert body, 'the encoder core is not in the library'
+    address = []
+    for line in body:
+        m = re.search(r'//\s*([0-9A-Fa-f]{12}):', line)
+        address.append(int(m.group(1), 16) if m else None)
+    loops = []
+    for (i, line) in enumerate(body):
+        m = re.match(r'\s*(s_cbranch_\w+|s_branch)\s+(\d+)', line)
+        if m and address[i] is not None and int(m.group(2)) >= 32768:               # a backward branch
+            target = address[i] + 4 + (int(m.group(2)) - 65536)*4
+            if target in address:
+                loops.append((address.index(target), i))
+    # the decision loop: the longest loop, with its three reloads and six record stores
+    (first, last) = max(loops, key=lambda ab: ab[1] - ab[0])
+    segment = body[first:last + 1]
+    loads = [x for x in segment if 'global_load_dwordx2' in x]
+    stores = [x for x in segment if 'global_store_dwordx4' in x]
+    waits = [re.search(r'vmcnt\((\d+)\)', x).group(1) for x in segment if 's_waitcnt' in x and 'vmcnt' in x]
+    assert len(loads) == 3 and len(stores) == 6, (len(loads), len(stores))
+    assert waits == ['6', '6', '6'], waits
+
+
 def test_the_first_decoder_core_is_rejected():
     """Round 3's first form of the decoder core (-DEAE_DECODE_TOPUP_ZEROS, kept buildable) used 40 of 40 registers and shifted its
     stream window by v39: the guard must reject exactly that build, and pass the shipped form of the same file."""
